@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (run in the build container only).
+
+    python tests/golden/make_golden.py [--only unit|model2|model16]
+
+The reference (/root/reference/code) is imported as-is; the only stand-ins are the five
+trivial MONAI symbols its U-Net ICL files import: MONAI is
+not installed and there is no network.  Nothing from the reference is copied: the .npz
+files hold seeds, shapes and OUTPUT numbers only.  Weights and inputs come from
+icl_amd.utils.hashfill (bit-identical on every platform), keyed by state_dict name.
+
+Parity mode: every nn.Dropout.p and DropPath.drop_prob forced to 0, model
+kept in train() so BatchNorm uses batch statistics; eval() only for the inference branch.
+"""
+import argparse
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from icl_amd.utils.hashfill import (fill_like_reference_init, synthetic_labels,  # noqa: E402
+                                    synthetic_volume)
+
+REF = "/root/reference/code"
+
+
+def install_monai_stub():
+    class DropPath(nn.Module):
+        def __init__(self, drop_prob=0.0, scale_by_keep=True):
+            super().__init__()
+            self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+
+        def forward(self, x):
+            if self.drop_prob == 0.0 or not self.training:
+                return x
+            keep = 1 - self.drop_prob
+            m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+            return x * (m / keep if self.scale_by_keep else m)
+
+    class _Conv:
+        CONV = "conv"
+
+        def __getitem__(self, key):
+            return {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}[key[1]]
+
+    def ensure_tuple_rep(x, d):
+        return tuple(x) if isinstance(x, (tuple, list)) else (x,) * d
+
+    def optional_import(mod, name=""):
+        m = importlib.import_module(mod)
+        return (getattr(m, name) if name else m), True
+
+    monai = types.ModuleType("monai")
+    nets = types.ModuleType("monai.networks")
+    layers = types.ModuleType("monai.networks.layers")
+    utils = types.ModuleType("monai.utils")
+    layers.DropPath, layers.Conv, layers.trunc_normal_ = DropPath, _Conv(), nn.init.trunc_normal_
+    utils.ensure_tuple_rep, utils.optional_import = ensure_tuple_rep, optional_import
+    monai.networks, monai.utils, nets.layers = nets, utils, layers
+    sys.modules.update({"monai": monai, "monai.networks": nets,
+                        "monai.networks.layers": layers, "monai.utils": utils})
+
+
+def import_reference():
+    install_monai_stub()
+    sys.argv = ["x"]
+    sys.path.insert(0, REF)
+    from networks.unet_3D import unet_3D
+    from networks import unet_3D_icl as m3
+    from networks.utils import UnetConv3, UnetUp3_CT
+    from utils import losses
+    return dict(unet_3D=unet_3D, m3=m3, UnetConv3=UnetConv3, UnetUp3_CT=UnetUp3_CT, losses=losses)
+
+
+def parity_mode(model):
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+        if m.__class__.__name__ == "DropPath":
+            m.drop_prob = 0.0
+    return model
+
+
+def fill(model, seed=1337):
+    fill_like_reference_init(list(model.named_parameters()), seed)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def grads_of(model):
+    return {k: (None if p.grad is None else npy(p.grad)) for k, p in model.named_parameters()}
+
+
+# ---------------------------------------------------------------- unit vectors
+def gen_unit(R, out):
+    torch.manual_seed(0)
+    d = {}
+    # A1: UnetConv3(3->4) on [2,3,8,8,8]
+    m = R["UnetConv3"](3, 4, True, kernel_size=(3, 3, 3), padding_size=(1, 1, 1))
+    fill(m)
+    x = synthetic_volume((2, 3, 8, 8, 8), 11).requires_grad_()
+    y = m(x)
+    gy = synthetic_volume(tuple(y.shape), 12)
+    y.backward(gy)
+    d["conv3_y"], d["conv3_gx"] = npy(y), npy(x.grad)
+    for k, g in grads_of(m).items():
+        d["conv3_g." + k] = g
+    # A3: UnetUp3_CT(8, 4): skip [2,4,8,8,8], deep [2,8,4,4,4]
+    m = R["UnetUp3_CT"](8, 4, True)
+    fill(m)
+    s = synthetic_volume((2, 4, 8, 8, 8), 13).requires_grad_()
+    dd = synthetic_volume((2, 8, 4, 4, 4), 14).requires_grad_()
+    y = m(s, dd)
+    y.backward(synthetic_volume(tuple(y.shape), 15))
+    d["up_y"], d["up_gskip"], d["up_gdeep"] = npy(y), npy(s.grad), npy(dd.grad)
+    for k, g in grads_of(m).items():
+        d["up_g." + k] = g
+    # A2/A5/A7: plain unet_3D nc=3 in_channels=2 on [1,2,32,32,32] (eval: dropout identity)
+    m = R["unet_3D"](n_classes=3, in_channels=2)
+    fill(m)
+    m.eval()
+    x = synthetic_volume((1, 2, 32, 32, 32), 16).requires_grad_()
+    y = m(x)
+    y.backward(synthetic_volume(tuple(y.shape), 17))
+    d["unet32_y"], d["unet32_gx"] = npy(y), npy(x.grad)
+    d["unet32_keys"] = np.array(list(m.state_dict().keys()))
+    for k, g in grads_of(m).items():
+        d["unet32_gn." + k] = np.float64(np.linalg.norm(g.astype(np.float64)))
+    d["unet32_g.final.weight"] = grads_of(m)["final.weight"]
+    d["unet32_g.conv1.conv1.0.weight"] = grads_of(m)["conv1.conv1.0.weight"]
+    d["unet32_g.center.conv2.0.weight_sub"] = grads_of(m)["center.conv2.0.weight"][::16, ::16]
+    # B1-B6: InherentConsistent tiny, both modes
+    m3 = R["m3"]
+    for tag, train in (("tr", True), ("ev", False)):
+        al = m3.InherentConsistent(in_chans=(32, 16, 8), depths=(2, 2, 2), patch_size=(2, 2, 2),
+                                   input_resolution=[2, 4, 8], num_classes=3, num_heads=(4, 2, 1))
+        parity_mode(al)
+        fill(al)
+        al.train(train)
+        feats = [synthetic_volume((2, 32, 2, 2, 2), 21).requires_grad_(),
+                 synthetic_volume((2, 16, 4, 4, 4), 22).requires_grad_(),
+                 synthetic_volume((2, 8, 8, 8, 8), 23).requires_grad_()]
+        maps, qs = al(feats, "labeled")
+        maps_u, qs_u = al(feats, qs, "unlabeled")
+        loss = sum((mm * synthetic_volume(tuple(mm.shape), 30 + i)).sum() for i, mm in enumerate(maps)) \
+            + sum((mm * synthetic_volume(tuple(mm.shape), 40 + i)).sum() for i, mm in enumerate(maps_u))
+        loss.backward()
+        for i in range(3):
+            d[f"al_{tag}_map{i}"], d[f"al_{tag}_q{i}"] = npy(maps[i]), npy(qs[i])
+            d[f"al_{tag}_mapu{i}"], d[f"al_{tag}_qu{i}"] = npy(maps_u[i]), npy(qs_u[i])
+            d[f"al_{tag}_gfeat{i}"] = npy(feats[i].grad)
+        for k, g in grads_of(al).items():
+            if g is None:
+                continue
+            d[f"al_{tag}_gn." + k] = np.float64(np.linalg.norm(g.astype(np.float64)))
+            if g.size <= 4096:
+                d[f"al_{tag}_g." + k] = g
+            else:  # big token-axis MLPs: strided sample
+                d[f"al_{tag}_gs." + k] = g.reshape(-1)[::37].copy()
+        d[f"al_{tag}_none"] = np.array([k for k, g in grads_of(al).items() if g is None])
+        if train:  # BN running stats after the two train-mode calls
+            for k, v in al.state_dict().items():
+                if "running" in k:
+                    d["al_tr_buf." + k] = npy(v)
+    # single modules: Query_Attention(8, heads 2), Class_Decoder(dim 8, res 2^3)
+    qa = m3.Query_Attention(8, num_heads=2, qkv_bias=True)
+    fill(qa)
+    q = synthetic_volume((2, 3, 8), 51).requires_grad_()
+    xx = synthetic_volume((2, 8, 8), 52).requires_grad_()
+    o, a = qa(q, xx)
+    (o.sum() + (a * synthetic_volume(tuple(a.shape), 53)).sum()).backward()
+    d["qa_o"], d["qa_a"], d["qa_gq"], d["qa_gx"] = npy(o), npy(a), npy(q.grad), npy(xx.grad)
+    # L1-L5 at the hard-coded 96^3
+    L = R["losses"]
+    nc = 3
+    lab = synthetic_labels((1, 96, 96, 96), 61, nc)
+    logit = synthetic_volume((1, nc, 96, 96, 96), 62).requires_grad_()
+    dl = L.DiceLoss(nc)
+    l1 = dl(torch.softmax(logit, 1), lab.unsqueeze(1))
+    l2 = nn.CrossEntropyLoss()(logit, lab)
+    (l1 + l2).backward()
+    d["loss_dice"], d["loss_ce"] = npy(l1), npy(l2)
+    d["loss_dice_ce_glogit_sub"] = npy(logit.grad)[:, :, ::8, ::8, ::8]
+    maps = [synthetic_volume((1, nc, r, r, r), 63 + i).requires_grad_() for i, r in enumerate((6, 12, 24))]
+    la = L.AuxLoss3D(nc)(maps, lab)
+    la.backward()
+    d["loss_aux"] = npy(la)
+    for i in range(3):
+        d[f"loss_aux_g{i}"] = npy(maps[i].grad)
+        maps[i].grad = None
+    pred = synthetic_volume((1, nc, 96, 96, 96), 70).requires_grad_()
+    lp = L.PseudoSoftLoss3D(nc)(maps, pred)
+    lp.backward()
+    d["loss_pse"] = npy(lp)
+    assert pred.grad is None
+    for i in range(3):
+        d[f"loss_pse_g{i}"] = npy(maps[i].grad)
+        maps[i].grad = None
+    maps_b = [synthetic_volume((1, nc, r, r, r), 73 + i).requires_grad_() for i, r in enumerate((6, 12, 24))]
+    lc = L.softmax_mse_loss(maps, maps_b)
+    lc.backward()
+    d["loss_con"] = npy(lc)
+    assert maps_b[0].grad is None
+    for i in range(3):
+        d[f"loss_con_g{i}"] = npy(maps[i].grad)
+    np.savez_compressed(os.path.join(out, "unit.npz"), **d)
+    print("unit.npz", sum(v.nbytes for v in d.values()) / 1e6, "MB (raw)")
+
+
+# ---------------------------------------------------------------- full model vectors
+def gen_model(R, out, nc):
+    m3, L = R["m3"], R["losses"]
+    model = m3.unet_3D_icl(n_classes=nc, in_channels=1)
+    parity_mode(model)
+    fill(model)
+    d = {}
+    d["keys"] = np.array(list(model.state_dict().keys()))
+    d["param_keys"] = np.array([k for k, _ in model.named_parameters()])
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, nc)
+    # inference branch, eval mode
+    model.eval()
+    with torch.no_grad():
+        y = model(vol[:1], inference=True)
+    d["inf_logits_sub"] = npy(y)[:, :, ::8, ::8, ::8]
+    d["inf_logits_mean"] = npy(y.double().mean(dim=(0, 2, 3, 4)))
+    d["inf_logits_l2"] = npy(y.double().pow(2).sum(dim=(0, 2, 3, 4)).sqrt())
+    d["inf_logits_slab"] = npy(y)[:, :, 40:44, 40:56, 40:56]
+    # training step, train mode (dropout / drop-path prob 0)
+    model.train()
+    outs = model(vol[:1], vol[1:])
+    for name, t in (("final_lab", outs[0]), ("final_unlab", outs[1])):
+        d[name + "_sub"] = npy(t)[:, :, ::8, ::8, ::8]
+        d[name + "_l2"] = npy(t.double().pow(2).sum(dim=(0, 2, 3, 4)).sqrt())
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            d[f"{name}{i}"] = npy(t)
+    soft = torch.softmax(outs[0], 1)
+    l_ce = nn.CrossEntropyLoss()(outs[0], lab)
+    l_dice = L.DiceLoss(nc)(soft, lab.unsqueeze(1))
+    l_aux = L.AuxLoss3D(nc)(outs[2], lab)
+    l_pse = L.PseudoSoftLoss3D(nc)(outs[3], outs[1])
+    l_con = L.softmax_mse_loss(outs[3], outs[4])
+    w_pse = 0.1 if nc == 16 else 1.0  # AMOS trainer weight (…AMOS22.py:230)
+    loss = l_dice + l_ce + l_aux + w_pse * l_pse + 10 * l_con
+    d["losses"] = np.array([float(l_dice), float(l_ce), float(l_aux), float(l_pse), float(l_con), float(loss)])
+    # soft dice per class of the labeled prediction (metric parity, 1e-4)
+    sd = []
+    for c in range(nc):
+        t = (lab == c).float()
+        p = soft[:, c]
+        sd.append(float((2 * (p * t).sum() + 1e-5) / ((p * p).sum() + (t * t).sum() + 1e-5)))
+    d["soft_dice"] = np.array(sd)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    opt.zero_grad()
+    loss.backward()
+    gn, none = {}, []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            none.append(k)
+        else:
+            gn[k] = float(p.grad.double().pow(2).sum().sqrt())
+    d["grad_none"] = np.array(none)
+    d["grad_norm_keys"] = np.array(list(gn.keys()))
+    d["grad_norms"] = np.array(list(gn.values()))
+    sd_ = dict(model.named_parameters())
+    for k in ("final.weight", "final.bias", "conv1.conv1.0.weight", "sspa.guided_Q",
+              "sspa.class_decoders.0.attn.fc_q.weight", "uscl.attn_convs1.2.weight",
+              "sspa.attn_convs0.2.block.depthwise.weight", "sspa.query_convs.0.weight"):
+        d["grad." + k] = npy(sd_[k].grad)
+    d["grad.sspa.class_decoders.2.mlp2.fc1.weight_sub"] = npy(
+        sd_["sspa.class_decoders.2.mlp2.fc1.weight"].grad)[::432, ::432]
+    d["grad.center.conv2.0.weight_sub"] = npy(sd_["center.conv2.0.weight"].grad)[::16, ::16]
+    opt.step()
+    d["post_sgd_norms"] = np.array([float(p.detach().double().pow(2).sum().sqrt())
+                                    for _, p in model.named_parameters()])
+    d["post_sgd.final.weight"] = npy(sd_["final.weight"])
+    d["post_sgd.conv1.conv1.0.weight"] = npy(sd_["conv1.conv1.0.weight"])
+    np.savez_compressed(os.path.join(out, f"model_unet3d_icl_nc{nc}.npz"), **d)
+    print(f"model nc={nc}: losses", d["losses"], "grad_none", len(none))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="all")
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    R = import_reference()
+    if a.only in ("all", "unit"):
+        gen_unit(R, HERE)
+    if a.only in ("all", "model2"):
+        gen_model(R, HERE, 2)
+    if a.only in ("all", "model16"):
+        gen_model(R, HERE, 16)

@@ -1,0 +1,187 @@
+"""Pin the CPU oracle (oracle/icl_oracle.py) to golden vectors captured from the real reference.
+
+Fixtures: tests/golden/unit.npz, model_unet3d_icl_nc{2,16}.npz, made by tests/golden/make_golden.py.
+Tolerance: the oracle and the reference both run torch-CPU fp32 kernels, so they agree to
+rounding; 2e-5 relative leaves room for thread-count dependent summation order.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from icl_amd.utils.hashfill import synthetic_labels, synthetic_volume
+from oracle import icl_oracle as O
+
+TOL = 2e-5
+
+
+def test_unetconv3_matches_reference(golden_unit):
+    g = golden_unit
+    p = O.make_params(O.unet_conv3_shapes("m.", 3, 4), requires_grad=True, strip="m.")
+    x = synthetic_volume((2, 3, 8, 8, 8), 11).requires_grad_()
+    y = O.unet_conv3(p, "m", x)
+    y.backward(synthetic_volume(tuple(y.shape), 12))
+    assert rel_err(y.detach(), g["conv3_y"]) < TOL
+    assert rel_err(x.grad, g["conv3_gx"]) < TOL
+    for k, t in p.items():
+        gg = g["conv3_g." + k[2:]]
+        if k.endswith("bias"):  # bias grads before an InstanceNorm are pure rounding noise
+            assert np.abs(t.grad.numpy()).max() < 1e-4 and np.abs(gg).max() < 1e-4
+        else:
+            assert rel_err(t.grad, gg) < 1e-4, k
+
+
+def test_up3ct_matches_reference(golden_unit):
+    g = golden_unit
+    p = O.make_params(O.unet_conv3_shapes("m.conv.", 12, 4), requires_grad=True, strip="m.")
+    s = synthetic_volume((2, 4, 8, 8, 8), 13).requires_grad_()
+    d = synthetic_volume((2, 8, 4, 4, 4), 14).requires_grad_()
+    y = O.unet_up3_ct(p, "m", s, d)
+    y.backward(synthetic_volume(tuple(y.shape), 15))
+    assert rel_err(y.detach(), g["up_y"]) < TOL
+    assert rel_err(s.grad, g["up_gskip"]) < 1e-4
+    assert rel_err(d.grad, g["up_gdeep"]) < 1e-4
+
+
+def test_plain_unet3d_32_matches_reference(golden_unit):
+    g = golden_unit
+    shapes = O.backbone_shapes(3, 2)
+    assert [k for k, _ in shapes] == list(g["unet32_keys"])  # 38-key checkpoint contract
+    assert len(shapes) == 38
+    p = O.make_params(shapes, requires_grad=True)
+    x = synthetic_volume((1, 2, 32, 32, 32), 16).requires_grad_()
+    y, feats = O.backbone(p, x)
+    y.backward(synthetic_volume(tuple(y.shape), 17))
+    assert rel_err(y.detach(), g["unet32_y"]) < 1e-4
+    assert rel_err(x.grad, g["unet32_gx"]) < 1e-3
+    for k, t in p.items():
+        ref = float(g["unet32_gn." + k])
+        if k.endswith("bias") and k != "final.bias":
+            continue
+        got = float(t.grad.double().norm())
+        assert abs(got - ref) <= 1e-3 * max(ref, 1e-6), k
+    assert rel_err(p["final.weight"].grad, g["unet32_g.final.weight"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag,train", [("tr", True), ("ev", False)])
+def test_aligner_matches_reference(golden_unit, tag, train):
+    g = golden_unit
+    chans, res, heads, nc = (32, 16, 8), (2, 4, 8), (4, 2, 1), 3
+    p = O.make_params(O.aligner_shapes("a.", chans, res, nc, heads), requires_grad=True, strip="a.")
+    p.update(O.aligner_buffers("a.", heads))
+    feats = [synthetic_volume((2, 32, 2, 2, 2), 21).requires_grad_(),
+             synthetic_volume((2, 16, 4, 4, 4), 22).requires_grad_(),
+             synthetic_volume((2, 8, 8, 8, 8), 23).requires_grad_()]
+    maps, qs = O.inherent_consistent(p, "a", feats, heads, None, "labeled", train)
+    maps_u, qs_u = O.inherent_consistent(p, "a", feats, heads, qs, "unlabeled", train)
+    loss = sum((m * synthetic_volume(tuple(m.shape), 30 + i)).sum() for i, m in enumerate(maps)) \
+        + sum((m * synthetic_volume(tuple(m.shape), 40 + i)).sum() for i, m in enumerate(maps_u))
+    loss.backward()
+    for i in range(3):
+        assert rel_err(maps[i].detach(), g[f"al_{tag}_map{i}"]) < 1e-4
+        assert rel_err(qs[i].detach(), g[f"al_{tag}_q{i}"]) < 1e-4
+        assert rel_err(maps_u[i].detach(), g[f"al_{tag}_mapu{i}"]) < 1e-4
+        assert rel_err(qs_u[i].detach(), g[f"al_{tag}_qu{i}"]) < 1e-4
+        assert rel_err(feats[i].grad, g[f"al_{tag}_gfeat{i}"]) < 1e-3
+    none = set(g[f"al_{tag}_none"])
+    for k, t in p.items():
+        if not t.requires_grad:
+            continue
+        name = k[2:]
+        if name in none:
+            assert t.grad is None, name
+            continue
+        ref = float(g[f"al_{tag}_gn." + name])
+        got = float(t.grad.double().norm())
+        assert abs(got - ref) <= 2e-3 * max(ref, 1e-5), (name, got, ref)
+
+
+def test_query_attention_reshape_quirk(golden_unit):
+    g = golden_unit
+    shapes = [("q.fc_q.weight", (8, 8)), ("q.fc_q.bias", (8,)), ("q.fc_kv.weight", (16, 8)),
+              ("q.fc_kv.bias", (16,)), ("q.proj.weight", (8, 8)), ("q.proj.bias", (8,))]
+    p = O.make_params(shapes, strip="q.")
+    q = synthetic_volume((2, 3, 8), 51).requires_grad_()
+    x = synthetic_volume((2, 8, 8), 52).requires_grad_()
+    o, a = O.query_attention(p, "q", q, x, 2)
+    (o.sum() + (a * synthetic_volume(tuple(a.shape), 53)).sum()).backward()
+    assert rel_err(o.detach(), g["qa_o"]) < TOL
+    assert rel_err(a.detach(), g["qa_a"]) < TOL
+    assert rel_err(q.grad, g["qa_gq"]) < 1e-4
+    assert rel_err(x.grad, g["qa_gx"]) < 1e-4
+
+
+def test_losses_match_reference(golden_unit):
+    g = golden_unit
+    nc = 3
+    lab = synthetic_labels((1, 96, 96, 96), 61, nc)
+    logit = synthetic_volume((1, nc, 96, 96, 96), 62).requires_grad_()
+    l1 = O.dice_loss(torch.softmax(logit, 1), lab.unsqueeze(1), nc)
+    l2 = torch.nn.functional.cross_entropy(logit, lab)
+    (l1 + l2).backward()
+    assert abs(float(l1) - float(g["loss_dice"])) < 1e-6
+    assert abs(float(l2) - float(g["loss_ce"])) < 1e-6
+    assert rel_err(logit.grad[:, :, ::8, ::8, ::8], g["loss_dice_ce_glogit_sub"]) < 1e-4
+    maps = [synthetic_volume((1, nc, r, r, r), 63 + i).requires_grad_() for i, r in enumerate((6, 12, 24))]
+    la = O.aux_loss_3d(maps, lab, nc)
+    la.backward()
+    assert abs(float(la) - float(g["loss_aux"])) < 2e-6
+    for i in range(3):
+        assert rel_err(maps[i].grad, g[f"loss_aux_g{i}"]) < 1e-4
+        maps[i].grad = None
+    pred = synthetic_volume((1, nc, 96, 96, 96), 70).requires_grad_()
+    lp = O.pseudo_soft_loss_3d(maps, pred)
+    lp.backward()
+    assert pred.grad is None  # detached target (losses.py:294)
+    assert abs(float(lp) - float(g["loss_pse"])) < 2e-6
+    for i in range(3):
+        assert rel_err(maps[i].grad, g[f"loss_pse_g{i}"]) < 1e-4
+        maps[i].grad = None
+    maps_b = [synthetic_volume((1, nc, r, r, r), 73 + i).requires_grad_() for i, r in enumerate((6, 12, 24))]
+    lc = O.softmax_mse_loss(maps, maps_b)
+    lc.backward()
+    assert maps_b[0].grad is None
+    assert abs(float(lc) - float(g["loss_con"])) < 1e-7
+    for i in range(3):
+        assert rel_err(maps[i].grad, g[f"loss_con_g{i}"]) < 1e-4
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("nc", [2])
+def test_full_model_step_matches_reference(nc):
+    """SURVEY.md §8 T1 at BASELINE config 2 shape: forward 5-tuple, 5 losses, grad norms,
+    grad-None set and one SGD step of the 785 M parameter model against the reference."""
+    g = load_golden(f"model_unet3d_icl_nc{nc}.npz")
+    shapes = O.unet_3d_icl_shapes(nc)
+    assert [k for k, _ in shapes] == list(g["param_keys"])
+    p = O.make_params(shapes, requires_grad=True)
+    p.update(O.aligner_buffers("sspa.", O.UNET3D_HEADS))
+    p.update(O.aligner_buffers("uscl.", O.UNET3D_HEADS))
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, nc)
+    with torch.no_grad():
+        y = O.unet_3d_icl_forward(p, vol[:1], inference=True)
+    assert rel_err(y[:, :, ::8, ::8, ::8], g["inf_logits_sub"]) < 1e-4
+    outs = O.unet_3d_icl_forward(p, vol[:1], vol[1:], training=True)
+    assert rel_err(outs[0].detach()[:, :, ::8, ::8, ::8], g["final_lab_sub"]) < 1e-4
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            assert rel_err(t.detach(), g[f"{name}{i}"]) < 2e-4, (name, i)
+    total, parts = O.icl_losses(outs, lab, nc)
+    got = [float(parts[k]) for k in ("dice", "ce", "aux", "pse", "con")] + [float(total)]
+    assert np.allclose(got, g["losses"], rtol=0, atol=1e-5), (got, g["losses"])
+    total.backward()
+    none = [k for k, _ in shapes if p[k].grad is None]
+    assert none == list(g["grad_none"]) and len(none) == 33
+    ref = dict(zip(g["grad_norm_keys"], g["grad_norms"]))
+    for k, r in ref.items():
+        if k.endswith("bias") and ".0.bias" in k:
+            continue  # conv bias before InstanceNorm: rounding noise
+        got = float(p[k].grad.double().norm())
+        assert abs(got - r) <= 2e-3 * max(r, 1e-7) + 1e-9, (k, got, r)
+    assert rel_err(p["final.weight"].grad, g["grad.final.weight"]) < 1e-4
+    bufs = {}
+    O.sgd_step(p, {k: p[k].grad for k, _ in shapes}, bufs, lr=0.01)
+    post = np.array([float(p[k].detach().double().norm()) for k, _ in shapes])
+    assert np.allclose(post, g["post_sgd_norms"], rtol=1e-6)
+    assert rel_err(p["final.weight"].detach(), g["post_sgd.final.weight"]) < 1e-6
