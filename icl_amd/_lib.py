@@ -1,0 +1,88 @@
+"""ctypes binding of libicl_hip.so (C ABI: include/icl_hip.h).
+
+The product path has no fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  `_use_library_for_tests` exists only so that tests/ can point the same binding at the
+CPU-fiber emulation build of the very same kernels (tests/hipemu) in the GPU-less build container.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libicl_hip.so")
+
+_lib = None
+_lib_path = None
+_host_pointers_ok = False  # True only for the test-only emulation library
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+_SIGNATURES = {
+    "icl_abi_version": (c_int, []),
+    "icl_last_error": (c_char_p, []),
+    "icl_conv3d_packed_elems": (c_int64, [I, I, I, I]),
+    "icl_conv3d_pack_weights": (c_int, [P, P, I, I, I, I, P]),
+    "icl_conv3d_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, I, L, L, P]),
+    "icl_conv3d_wgrad": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, L, L, P]),
+    "icl_norm_ws_bytes": (c_int64, [I, I, L]),
+    "icl_norm_fwd": (c_int, [P, P, P, P, P, P, P, P, I, I, L, I, I, I, F, F, P, P]),
+    "icl_norm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, L, I, I, I, P, P]),
+    "icl_rstd_from_var": (c_int, [P, P, I, F, P]),
+    "icl_maxpool2_fwd": (c_int, [P, P, P, L, I, I, I, P]),
+    "icl_maxpool2_bwd": (c_int, [P, P, P, L, I, I, I, P]),
+    "icl_trilinear_fwd": (c_int, [P, P, I, I, I, I, I, I, I, I, L, P]),
+    "icl_trilinear_bwd": (c_int, [P, P, I, I, I, I, I, I, I, I, L, P]),
+    "icl_copy_rows": (c_int, [P, P, L, L, L, L, P]),
+    "icl_dwconv3_fwd": (c_int, [P, P, P, I, I, I, I, I, I, P]),
+    "icl_dwconv3_wgrad": (c_int, [P, P, P, I, I, I, I, I, P]),
+    "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def _load(path: str):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"icl_amd: HIP library {path} not found — build it with `python -m icl_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib():
+    global _lib, _lib_path
+    if _lib is None:
+        _lib_path = os.environ.get("ICL_HIP_LIB", DEFAULT_LIB)
+        _lib = _load(_lib_path)
+    return _lib
+
+
+def lib_path():
+    lib()
+    return _lib_path
+
+
+def host_pointers_ok() -> bool:
+    return _host_pointers_ok
+
+
+def _use_library_for_tests(path: str | None, host_pointers: bool = True):
+    """TESTS ONLY: route the binding to another build of the same ABI (the CPU emulation)."""
+    global _lib, _lib_path, _host_pointers_ok
+    if path is None:
+        _lib, _lib_path, _host_pointers_ok = None, None, False
+        return
+    _lib, _lib_path, _host_pointers_ok = _load(path), path, host_pointers
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().icl_last_error()
+        raise RuntimeError(f"icl_hip {what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,29 @@
+// device_env_hip.h — the gfx950 device environment the kernels in kernels/*.h are written against.
+// (tests/hipemu/hipemu.h is a CPU-fiber implementation of the same names, used by tests only.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// v_mfma_f32_16x16x4_f32 — exact f32 (k-ordered fmaf chain), 32-cycle issue per SIMD.
+// lane l: A[row l&15][k l>>4], B[k l>>4][col l&15]; D[row (l>>4)*4+r][col l&15] in reg r.
+__device__ __forceinline__ f32x4 icl_mfma_16x16x4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_32x32x2_f32 — lane l: A[row l&31][k l>>5], B[k l>>5][col l&31];
+// D[row (r&3)+8*(r>>2)+4*(l>>5)][col l&31] in reg r.
+__device__ __forceinline__ f32x16 icl_mfma_32x32x2(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+#define ICL_DYN_LDS(type, name)                                              \
+  extern __shared__ __attribute__((aligned(16))) unsigned char icl_dyn_lds_raw[]; \
+  type* name = reinterpret_cast<type*>(icl_dyn_lds_raw)
+
+#define ICL_LAUNCH(kern, grid, block, lds, stream, ...) \
+  hipLaunchKernelGGL(kern, (grid), (block), (lds), (stream), __VA_ARGS__)
+#define ICL_MEMSET_ASYNC(ptr, val, bytes, stream) ((void)hipMemsetAsync((ptr), (val), (bytes), (stream)))
+#define ICL_LAST_LAUNCH_ERROR() ((int)hipGetLastError())
+#define ICL_ERROR_STRING(e) hipGetErrorString((hipError_t)(e))

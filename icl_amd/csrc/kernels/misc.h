@@ -1,0 +1,99 @@
+// misc.h — depthwise 3x3x3 convolution (SeparableConv3d.depthwise, /root/reference/code/networks/
+// unet_3D_icl.py:320-323) and counter-based dropout (nn.Dropout(p=0.3), unet_3D_icl.py:67-68).
+// Both HBM-bound elementwise/stencil kernels, x fastest for coalescing.
+#pragma once
+
+namespace icl {
+
+// y[n,c,z,y,x] = sum_tap w[c][tap] * x[n,c,z+dz-1,y+dy-1,x+dx-1]; flip=1 uses w[c][26-tap] (dgrad).
+__global__ __launch_bounds__(256) void dwconv3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                          long NC, int C, int D, int H, int W, int flip) {
+  const long S = (long)D * H * W;
+  const long total = NC * S;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(o % W);
+    long t = o / W;
+    const int oy = (int)(t % H);
+    t /= H;
+    const int oz = (int)(t % D);
+    const long nc = t / D;
+    const int c = (int)(nc % C);
+    const float* xp = x + nc * S;
+    const float* wc = w + c * 27;
+    float acc = 0.f;
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz) {
+      const int z = oz + dz - 1;
+      if (z < 0 || z >= D) continue;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int yy = oy + dy - 1;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int xx = ox + dx - 1;
+          if (xx < 0 || xx >= W) continue;
+          const int tap = (dz * 3 + dy) * 3 + dx;
+          acc += wc[flip ? 26 - tap : tap] * xp[((long)z * H + yy) * W + xx];
+        }
+      }
+    }
+    y[o] = acc;
+  }
+}
+
+// gw[c][tap] += sum over a chunk of (n, voxels) of gy * shifted x.  grid (chunks, C); gw pre-zeroed.
+__global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gw,
+                                                            int N, int C, int D, int H, int W, long chunk) {
+  const int c = blockIdx.y;
+  const long S = (long)D * H * W;
+  const long total = (long)N * S;
+  const long lo = (long)blockIdx.x * chunk;
+  const long hi = lo + chunk < total ? lo + chunk : total;
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.f;
+  for (long e = lo + threadIdx.x; e < hi; e += 256) {
+    const long n = e / S;
+    const long v = e - n * S;
+    const int ox = (int)(v % W);
+    const long t = v / W;
+    const int oy = (int)(t % H), oz = (int)(t / H);
+    const float g = gy[(n * C + c) * S + v];
+    const float* xp = x + (n * C + c) * S;
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz) {
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int z = oz + dz - 1, yy = oy + dy - 1, xx = ox + dx - 1;
+          if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
+            acc[(dz * 3 + dy) * 3 + dx] += g * xp[((long)z * H + yy) * W + xx];
+        }
+      }
+    }
+  }
+  __shared__ float red[4];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) {
+    const float s = block_sum<256>(acc[i], red);
+    if (threadIdx.x == 0) atomicAdd(gw + c * 27 + i, s);
+  }
+}
+
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+
+// y = keep ? x*scale : 0 with keep(i) = hash(seed, i) >= thresh; the same (seed) regenerates the mask in backward.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, unsigned seed,
+                                                      unsigned thresh, float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const unsigned h = mix32((unsigned)i * 0x9E3779B1u + seed) ^ mix32((unsigned)(i >> 32) + seed * 0x85EBCA77u);
+    y[i] = h >= thresh ? x[i] * scale : 0.f;
+  }
+}
+
+}  // namespace icl

@@ -1,0 +1,204 @@
+// norm.h — instance/batch normalisation (+ReLU) over NC[D]HW fp32 rows, forward and backward.
+//
+// Reference ops: nn.InstanceNorm3d(eps 1e-5, no affine) + ReLU inside UnetConv3
+// (/root/reference/code/networks/utils.py:104-109) and nn.BatchNorm3d (batch statistics in
+// train mode) + ReLU inside SeparableConv3d (networks/unet_3D_icl.py:317-345).
+//
+// A tensor is R = N*C rows of S contiguous floats.  Row r belongs to group r (instance norm)
+// or r % C (batch norm).  All kernels are HBM-bound: rows are cut into chunks of kChunk
+// elements so that even R = 16 rows (the 96^3 layers) fill the chip with workgroups.
+//   forward : stats pass (read x) -> finalize (tiny) -> apply pass (read x, write y)
+//   backward: partial sums pass (read gy, x) -> group reduce (tiny) -> apply (read gy, x, write gx)
+// Algorithmic HBM bytes per element: 12 B forward, 20 B backward.
+#pragma once
+
+namespace icl {
+
+constexpr int kNormChunk = 8192;  // elements per workgroup
+constexpr int kNormThreads = 256;
+
+// part[(r*nchunks + ch)*3 + {0,1,2}] = (count, mean, M2) of x[r, ch*chunk : (ch+1)*chunk]
+__global__ __launch_bounds__(kNormThreads) void rowstats_partial_kernel(
+    const float* __restrict__ x, float* __restrict__ part, long S, int nchunks) {
+  const int ch = blockIdx.x;
+  const long r = blockIdx.y;
+  const long lo = (long)ch * kNormChunk;
+  const long hi = (lo + kNormChunk < S) ? lo + kNormChunk : S;
+  const float* xr = x + r * S;
+  // shifted sums per thread (shift = first element seen) -> (n, mean, M2)
+  float n = 0.f, shift = 0.f, s1 = 0.f, s2 = 0.f;
+  for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
+    const float v = xr[i];
+    if (n == 0.f) shift = v;
+    const float d = v - shift;
+    s1 += d;
+    s2 += d * d;
+    n += 1.f;
+  }
+  float mean = 0.f, m2 = 0.f;
+  if (n > 0.f) {
+    mean = shift + s1 / n;
+    m2 = s2 - s1 * s1 / n;
+    if (m2 < 0.f) m2 = 0.f;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float nb = __shfl_xor(n, m, 64), mb = __shfl_xor(mean, m, 64), qb = __shfl_xor(m2, m, 64);
+    // symmetric merge so every lane ends with the same value
+    float na = n, ma = mean, qa = m2;
+    welford_merge(na, ma, qa, nb, mb, qb);
+    if (na > 0.f) { n = na; mean = ma; m2 = qa; }
+  }
+  __shared__ float red[3 * (kNormThreads / 64)];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { red[wid * 3] = n; red[wid * 3 + 1] = mean; red[wid * 3 + 2] = m2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tn = red[0], tm = red[1], tq = red[2];
+    for (int w = 1; w < kNormThreads / 64; ++w) welford_merge(tn, tm, tq, red[w * 3], red[w * 3 + 1], red[w * 3 + 2]);
+    float* p = part + (r * nchunks + ch) * 3;
+    p[0] = tn; p[1] = tm; p[2] = tq;
+  }
+}
+
+// One thread per group: merge chunk summaries of every row in the group.
+// groups = R (instance) or C (batch).  Optionally updates BatchNorm running stats.
+__global__ void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean,
+                                      float* __restrict__ rstd, int R, int C, int nchunks, int batch_mode,
+                                      float eps, float* running_mean, float* running_var, float momentum) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int groups = batch_mode ? C : R;
+  if (g >= groups) return;
+  float n = 0.f, m = 0.f, q = 0.f;
+  const int step = batch_mode ? C : R;
+  for (int r = g; r < R; r += step) {
+    const float* p = part + (long)r * nchunks * 3;
+    for (int ch = 0; ch < nchunks; ++ch) welford_merge(n, m, q, p[ch * 3], p[ch * 3 + 1], p[ch * 3 + 2]);
+  }
+  const float var = q / n;  // biased, as the normalisation uses
+  mean[g] = m;
+  rstd[g] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = n > 1.f ? q / (n - 1.f) : var;
+    running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * m;
+    running_var[g] = (1.f - momentum) * running_var[g] + momentum * unbiased;
+  }
+}
+
+// rstd from given variances (eval-mode BatchNorm): rstd[c] = 1/sqrt(var[c]+eps)
+__global__ void rstd_from_var_kernel(const float* __restrict__ var, float* __restrict__ rstd, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) rstd[c] = 1.0f / sqrtf(var[c] + eps);
+}
+
+// y = act(((x-mean[g])*rstd[g]) * gamma[c] + beta[c]); act 0 = identity, 1 = ReLU.
+// grid (nchunks, R)
+__global__ __launch_bounds__(kNormThreads) void norm_act_fwd_kernel(
+    const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    long S, int C, int batch_mode, int act) {
+  const long r = blockIdx.y;
+  const int c = (int)(r % C);
+  const int g = batch_mode ? c : (int)r;
+  const float m = mean[g], rs = rstd[g];
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const float sc = rs * ga, sh = be - m * rs * ga;
+  const long lo = (long)blockIdx.x * kNormChunk;
+  const long hi = (lo + kNormChunk < S) ? lo + kNormChunk : S;
+  const float* xr = x + r * S;
+  float* yr = y + r * S;
+  if ((S & 3) == 0) {
+    const float4* x4 = reinterpret_cast<const float4*>(xr);
+    float4* y4 = reinterpret_cast<float4*>(yr);
+    for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += kNormThreads) {
+      float4 v = x4[i];
+      v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+      if (act) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      y4[i] = v;
+    }
+  } else {
+    for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
+      float v = xr[i] * sc + sh;
+      yr[i] = act ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+
+// Backward partial sums per (row, chunk): p1 = sum h, p2 = sum h*xhat, h = gy * [y > 0 if act].
+__global__ __launch_bounds__(kNormThreads) void norm_act_bwd_partial_kernel(
+    const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ part, long S, int C, int nchunks, int batch_mode, int act) {
+  const long r = blockIdx.y;
+  const int c = (int)(r % C);
+  const int g = batch_mode ? c : (int)r;
+  const float m = mean[g], rs = rstd[g];
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const long lo = (long)blockIdx.x * kNormChunk;
+  const long hi = (lo + kNormChunk < S) ? lo + kNormChunk : S;
+  const float* xr = x + r * S;
+  const float* gr = gy + r * S;
+  float p1 = 0.f, p2 = 0.f;
+  for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
+    const float xh = (xr[i] - m) * rs;
+    float h = gr[i];
+    if (act && !(xh * ga + be > 0.f)) h = 0.f;
+    p1 += h;
+    p2 += h * xh;
+  }
+  __shared__ float red[kNormThreads / 64];
+  p1 = block_sum<kNormThreads>(p1, red);
+  p2 = block_sum<kNormThreads>(p2, red);
+  if (threadIdx.x == 0) {
+    float* p = part + (r * nchunks + blockIdx.x) * 2;
+    p[0] = p1; p[1] = p2;
+  }
+}
+
+// One thread per group: P1/P2 over all rows+chunks of the group -> gsum[g*2..]; optional dgamma/dbeta
+// (per channel, summed over the batch as well when instance mode has affine — unused by the reference).
+__global__ void norm_bwd_group_reduce_kernel(const float* __restrict__ part, float* __restrict__ gsum,
+                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int C,
+                                             int nchunks, int batch_mode) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int groups = batch_mode ? C : R;
+  if (g >= groups) return;
+  const int step = batch_mode ? C : R;
+  float p1 = 0.f, p2 = 0.f;
+  for (int r = g; r < R; r += step) {
+    const float* p = part + (long)r * nchunks * 2;
+    for (int ch = 0; ch < nchunks; ++ch) { p1 += p[ch * 2]; p2 += p[ch * 2 + 1]; }
+  }
+  gsum[g * 2] = p1;
+  gsum[g * 2 + 1] = p2;
+  if (batch_mode && dgamma) { dgamma[g] = p2; dbeta[g] = p1; }
+}
+
+// gx = rstd*gamma*(h - (P1 + xhat*P2)/M)   (batch statistics)   or   rstd*gamma*h   (fixed statistics)
+__global__ __launch_bounds__(kNormThreads) void norm_act_bwd_apply_kernel(
+    const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ gsum, float* __restrict__ gx, long S, int C, int batch_mode, int act,
+    float inv_count, int use_batch_stats) {
+  const long r = blockIdx.y;
+  const int c = (int)(r % C);
+  const int g = batch_mode ? c : (int)r;
+  const float m = mean[g], rs = rstd[g];
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const float a1 = use_batch_stats ? gsum[g * 2] * inv_count : 0.f;
+  const float a2 = use_batch_stats ? gsum[g * 2 + 1] * inv_count : 0.f;
+  const float k = rs * ga;
+  const long lo = (long)blockIdx.x * kNormChunk;
+  const long hi = (lo + kNormChunk < S) ? lo + kNormChunk : S;
+  const float* xr = x + r * S;
+  const float* gr = gy + r * S;
+  float* o = gx + r * S;
+  for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
+    const float xh = (xr[i] - m) * rs;
+    float h = gr[i];
+    if (act && !(xh * ga + be > 0.f)) h = 0.f;
+    o[i] = k * (h - a1 - xh * a2);
+  }
+}
+
+}  // namespace icl

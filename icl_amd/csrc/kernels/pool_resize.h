@@ -1,0 +1,167 @@
+// pool_resize.h — MaxPool3d(2), trilinear resize (align_corners=False) and strided row copy.
+//
+// Reference ops: nn.MaxPool3d(kernel_size=2) (/root/reference/code/networks/unet_3D_icl.py:41-53),
+// nn.Upsample(scale_factor=2, mode='trilinear') in UnetUp3_CT (networks/utils.py:264) and
+// F.interpolate(size=[96,96,96], mode='trilinear') in the losses (utils/losses.py:263,292).
+// All HBM-bound; x is the fastest index everywhere so loads/stores coalesce.
+#pragma once
+
+namespace icl {
+
+// ---- MaxPool3d 2x2x2, stride 2 (even extents).  idx = argmax in (dz,dy,dx) scan order with
+// strict '>' so the first maximum wins, as ATen's max_pool3d does.
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           unsigned char* __restrict__ idx, long NC, int Do, int Ho, int Wo) {
+  const long total = NC * Do * Ho * Wo;
+  const int H = Ho * 2, W = Wo * 2;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(o % Wo);
+    long t = o / Wo;
+    const int oy = (int)(t % Ho);
+    t /= Ho;
+    const int oz = (int)(t % Do);
+    const long nc = t / Do;
+    const float* p = x + ((nc * (Do * 2) + oz * 2) * H + oy * 2) * (long)W + ox * 2;
+    float best = p[0];
+    int bi = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const float v = p[((k >> 2) * H + ((k >> 1) & 1)) * (long)W + (k & 1)];
+      if (v > best) { best = v; bi = k; }
+    }
+    y[o] = best;
+    idx[o] = (unsigned char)bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ idx,
+                                                           float* __restrict__ gx, long NC, int Do, int Ho, int Wo) {
+  const long total = NC * Do * Ho * Wo;
+  const int H = Ho * 2, W = Wo * 2;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(o % Wo);
+    long t = o / Wo;
+    const int oy = (int)(t % Ho);
+    t /= Ho;
+    const int oz = (int)(t % Do);
+    const long nc = t / Do;
+    float* p = gx + ((nc * (Do * 2) + oz * 2) * H + oy * 2) * (long)W + ox * 2;
+    const float g = gy[o];
+    const int bi = idx[o];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      float2 v = make_float2(bi == k ? g : 0.f, bi == k + 1 ? g : 0.f);
+      *reinterpret_cast<float2*>(p + ((k >> 2) * H + ((k >> 1) & 1)) * (long)W) = v;
+    }
+  }
+}
+
+// ---- trilinear, align_corners=False: ATen's area_pixel_compute_source_index
+//   src = rscale*(dst+0.5)-0.5, clamped at 0;  i0 = floor(src), i1 = i0 + (i0 < in-1), l1 = src-i0, l0 = 1-l1
+struct LinTap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ LinTap lin_tap(int dst, float rscale, int in_size) {
+  float src = rscale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  LinTap t;
+  t.i0 = (int)src;
+  if (t.i0 > in_size - 1) t.i0 = in_size - 1;
+  t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+
+// y[n][c] planes are Do*Ho*Wo apart; batches y_bstride apart (lets the caller write into the
+// channel slice of a concat buffer).  x is dense [N][C][Di][Hi][Wi].
+__global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C,
+                                                            int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                                            float rz, float ry, float rx, long y_bstride) {
+  const long per_n = (long)C * Do * Ho * Wo;
+  const long total = (long)N * per_n;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(o % Wo);
+    long t = o / Wo;
+    const int oy = (int)(t % Ho);
+    t /= Ho;
+    const int oz = (int)(t % Do);
+    t /= Do;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    const LinTap tz = lin_tap(oz, rz, Di), ty = lin_tap(oy, ry, Hi), tx = lin_tap(ox, rx, Wi);
+    const float* p = x + ((long)n * C + c) * Di * Hi * Wi;
+    const long z0 = (long)tz.i0 * Hi * Wi, z1 = (long)tz.i1 * Hi * Wi;
+    const long y0 = (long)ty.i0 * Wi, y1 = (long)ty.i1 * Wi;
+    const float v =
+        tz.l0 * (ty.l0 * (tx.l0 * p[z0 + y0 + tx.i0] + tx.l1 * p[z0 + y0 + tx.i1]) +
+                 ty.l1 * (tx.l0 * p[z0 + y1 + tx.i0] + tx.l1 * p[z0 + y1 + tx.i1])) +
+        tz.l1 * (ty.l0 * (tx.l0 * p[z1 + y0 + tx.i0] + tx.l1 * p[z1 + y0 + tx.i1]) +
+                 ty.l1 * (tx.l0 * p[z1 + y1 + tx.i0] + tx.l1 * p[z1 + y1 + tx.i1]));
+    y[(long)n * y_bstride + (((long)c * Do + oz) * Ho + oy) * Wo + ox] = v;
+  }
+}
+
+// weight with which output index o contributes to input index i along one axis (exact transpose of lin_tap)
+__device__ __forceinline__ float lin_w(int o, int i, float rscale, int in_size) {
+  const LinTap t = lin_tap(o, rscale, in_size);
+  return (t.i0 == i ? t.l0 : 0.f) + (t.i1 == i ? t.l1 : 0.f);
+}
+
+// conservative [lo, hi] range of output indices that can touch input index i
+__device__ __forceinline__ void lin_range(int i, float rscale, int out_size, int& lo, int& hi) {
+  const float inv = 1.0f / rscale;
+  lo = (int)floorf(((float)i - 1.0f + 0.5f) * inv - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 1.0f + 0.5f) * inv - 0.5f) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out_size - 1) hi = out_size - 1;
+}
+
+// Backward (gather form, deterministic): one WAVE per input voxel, lanes sweep the output support.
+// gy planes Do*Ho*Wo apart, batches gy_bstride apart.  grid-stride over input voxels, 4 waves/block.
+__global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int N, int C,
+                                                            int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                                            float rz, float ry, float rx, long gy_bstride) {
+  const long total = (long)N * C * Di * Hi * Wi;
+  const int lane = threadIdx.x & 63;
+  const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  for (long v = wave0; v < total; v += nwaves) {
+    const int ix = (int)(v % Wi);
+    long t = v / Wi;
+    const int iy = (int)(t % Hi);
+    t /= Hi;
+    const int iz = (int)(t % Di);
+    t /= Di;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    int zl, zh, yl, yh, xl, xh;
+    lin_range(iz, rz, Do, zl, zh);
+    lin_range(iy, ry, Ho, yl, yh);
+    lin_range(ix, rx, Wo, xl, xh);
+    const int nz = zh - zl + 1, ny = yh - yl + 1, nx = xh - xl + 1;
+    const int cnt = nz * ny * nx;
+    const float* g = gy + (long)n * gy_bstride + (long)c * Do * Ho * Wo;
+    float acc = 0.f;
+    for (int e = lane; e < cnt; e += 64) {
+      const int ex = e % nx;
+      const int r = e / nx;
+      const int ey = r % ny, ez = r / ny;
+      const int oz = zl + ez, oy = yl + ey, ox = xl + ex;
+      const float w = lin_w(oz, iz, rz, Di) * lin_w(oy, iy, ry, Hi) * lin_w(ox, ix, rx, Wi);
+      if (w != 0.f) acc += w * g[((long)oz * Ho + oy) * Wo + ox];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) gx[v] = acc;
+  }
+}
+
+// dst[r*dst_stride + i] = src[r*src_stride + i], i < row_elems (row_elems % 4 == 0 fast path)
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows,
+                                                        long row_elems, long src_stride, long dst_stride) {
+  const long total = rows * row_elems;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / row_elems, i = e - r * row_elems;
+    dst[r * dst_stride + i] = src[r * src_stride + i];
+  }
+}
+
+}  // namespace icl

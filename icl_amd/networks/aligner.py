@@ -1,0 +1,217 @@
+"""The two train-only aligner heads of ICL (``sspa`` / ``uscl``): multi-scale prototype cross-attention.
+
+Mirror of ``InherentConsistent`` / ``Class_Decoder`` / ``Query_Attention`` / ``MLP`` / ``SeparableConv3d``
+(/root/reference/code/networks/unet_3D_icl.py:155-345) with identical parameter names, built on
+icl_amd.ops.  Quirks reproduced on purpose: reshape-based head split, pre-softmax
+logits returned as the "attention", ``q + drop_path(q)`` doubling, token-axis ``mlp2``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .layers import Conv3d
+
+
+class Linear(nn.Module):
+    def __init__(self, fin, fout, bias=True, device=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin, device=device))
+        self.bias = nn.Parameter(torch.empty(fout, device=device)) if bias else None
+        b = 1.0 / math.sqrt(fin)
+        with torch.no_grad():
+            self.weight.uniform_(-b, b)
+            if self.bias is not None:
+                self.bias.uniform_(-b, b)
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, dim, device=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim, device=device))
+        self.bias = nn.Parameter(torch.zeros(dim, device=device))
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, 1e-5)
+
+
+class BatchNorm3d(nn.Module):
+    """nn.BatchNorm3d parameters/buffers; forward fused with the following ReLU."""
+
+    def __init__(self, c, device=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c, device=device))
+        self.bias = nn.Parameter(torch.zeros(c, device=device))
+        self.register_buffer("running_mean", torch.zeros(c, device=device))
+        self.register_buffer("running_var", torch.ones(c, device=device))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long, device=device))
+
+    def forward(self, x):
+        if self.training:
+            self.num_batches_tracked += 1
+        return ops.batch_norm_relu(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu=True)
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth (MONAI DropPath semantics)."""
+
+    def __init__(self, p=0.0):
+        super().__init__()
+        self.drop_prob = p
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = torch.empty((x.shape[0],) + (1,) * (x.ndim - 1), device=x.device).bernoulli_(keep)
+        return x * (mask / keep)
+
+
+class MLP(nn.Module):
+    """fc2(GELU_erf(fc1(x))) — unet_3D_icl.py:299-315."""
+
+    def __init__(self, fin, hidden, device=None):
+        super().__init__()
+        self.fc1 = Linear(fin, hidden, device=device)
+        self.fc2 = Linear(hidden, fin, device=device)
+
+    def forward(self, x):
+        return self.fc2(ops.gelu(self.fc1(x)))
+
+
+class Query_Attention(nn.Module):  # noqa: N801
+    """unet_3D_icl.py:270-297."""
+
+    def __init__(self, dim, num_heads, device=None):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.fc_q = Linear(dim, dim, device=device)
+        self.fc_kv = Linear(dim, dim * 2, device=device)
+        self.proj = Linear(dim, dim, device=device)
+
+    def forward(self, q, x):
+        B, N, C = x.shape
+        nc, h = q.shape[1], self.num_heads
+        qh = self.fc_q(q).reshape(B, h, nc, C // h)          # reshape quirk (:287)
+        kv = self.fc_kv(x)                                    # [B, N, 2C] = [B, N, (k|v), h, d]
+        out, logits = ops.prototype_attention(qh, kv, h, self.scale)   # out [B,h,nc,d], logits [B,h,nc,N]
+        out = self.proj(out.reshape(B, nc, C))                # reshape quirk (:293)
+        return out, logits.permute(0, 2, 1, 3)
+
+
+class Class_Decoder(nn.Module):  # noqa: N801
+    """unet_3D_icl.py:244-268."""
+
+    def __init__(self, dim, n_tokens, num_heads, drop_path=0.0, device=None):
+        super().__init__()
+        self.norm1 = LayerNorm(dim, device)
+        self.norm1_query = LayerNorm(dim, device)
+        self.attn = Query_Attention(dim, num_heads, device)
+        self.drop_path = DropPath(drop_path)
+        self.norm2 = LayerNorm(dim, device)
+        self.mlp = MLP(dim, int(dim * 4.0), device)
+        self.norm3 = LayerNorm(n_tokens, device)
+        self.mlp2 = MLP(n_tokens, n_tokens, device)
+
+    def forward(self, query, feat):
+        query, attn = self.attn(self.norm1_query(query), self.norm1(feat))
+        query = query + self.drop_path(query)
+        query = query + self.drop_path(self.mlp(self.norm2(query)))
+        attn = attn + self.drop_path(attn)
+        attn = attn + self.drop_path(self.mlp2(self.norm3(attn)))
+        return query, attn
+
+
+class _SepBlock(nn.Module):
+    """The ``block`` Sequential of SeparableConv3d(relu_first=False) (unet_3D_icl.py:336-343)."""
+
+    def __init__(self, planes, device=None):
+        super().__init__()
+        self.depthwise = Conv3d(planes, planes, 3, bias=False, groups=planes, device=device)
+        self.bn_depth = BatchNorm3d(planes, device)
+        self.pointwise = Conv3d(planes, planes, 1, bias=False, device=device)
+        self.bn_point = BatchNorm3d(planes, device)
+
+    def forward(self, x):
+        x = self.bn_depth(self.depthwise(x))      # BN + ReLU fused
+        return self.bn_point(self.pointwise(x))   # BN + ReLU fused
+
+
+class SeparableConv3d(nn.Module):
+    def __init__(self, planes, device=None):
+        super().__init__()
+        self.block = _SepBlock(planes, device)
+
+    def forward(self, x):
+        return self.block(x)
+
+
+class Conv1d(nn.Module):
+    """nn.Conv1d(cin, cout, 1) == per-token Linear (query_convs, unet_3D_icl.py:197)."""
+
+    def __init__(self, cin, cout, device=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 1, device=device))
+        self.bias = nn.Parameter(torch.empty(cout, device=device))
+        b = 1.0 / math.sqrt(cin)
+        with torch.no_grad():
+            self.weight.uniform_(-b, b)
+            self.bias.uniform_(-b, b)
+
+    def forward(self, q):  # q [B, nc, C] -> [B, nc, C/2]; the reference permutes to [B,C,nc] and back
+        return ops.linear(q, self.weight.squeeze(-1), self.bias)
+
+
+class InherentConsistent(nn.Module):
+    """unet_3D_icl.py:155-242.  ``forward(feats, guided_Q=None, modal='labeled')`` keeps the reference
+    call convention, including ``sspa(feats, 'labeled')`` passing the string positionally (:144-145)."""
+
+    def __init__(self, in_chans: Sequence[int], depths=(2, 2, 2), patch_size=(2, 2, 2),
+                 input_resolution: Sequence[int] = (6, 12, 24), num_classes: int = 2,
+                 num_heads: Sequence[int] = (16, 8, 4), norm_layer=None, patch_norm=False,
+                 spatial_dims: int = 3, drop_path_rate: float = 0.1, device=None):
+        super().__init__()
+        self.in_chans, self.depth = tuple(in_chans), tuple(depths)
+        self.resolutions = tuple(input_resolution)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.proj_layers = nn.ModuleList()
+        self.norm_layers = nn.ModuleList()
+        self.class_decoders = nn.ModuleList()
+        self.attn_convs0 = nn.ModuleList()
+        self.attn_convs1 = nn.ModuleList()
+        self.query_convs = nn.ModuleList()
+        for i in range(len(depths)):
+            c, r, h = in_chans[i], input_resolution[i], num_heads[i]
+            self.proj_layers.append(Conv3d(c, c, 1, device=device))
+            self.norm_layers.append(LayerNorm(c, device))
+            self.class_decoders.append(Class_Decoder(c, r ** spatial_dims, h, drop_path=dpr[1], device=device))
+            self.attn_convs0.append(SeparableConv3d(h, device))
+            self.attn_convs1.append(Conv3d(h, 1, 1, device=device))
+            self.query_convs.append(Conv1d(c, c // 2, device))
+        self.guided_Q = nn.Parameter(torch.zeros(1, num_classes, in_chans[0], device=device))
+
+    def forward(self, feats, guided_Q=None, modal="labeled"):
+        bs = feats[0].shape[0]
+        feat_maps, updated_qs = [], []
+        nxt = self.guided_Q.expand(bs, -1, -1) if modal == "labeled" else None
+        for i in range(len(self.depth)):
+            tok = self.proj_layers[i](feats[i]).flatten(2).transpose(1, 2)
+            tok = self.norm_layers[i](tok)
+            q_in = nxt if modal == "labeled" else guided_Q[i].expand(bs, -1, -1)
+            q_out, attn = self.class_decoders[i](q_in, tok)
+            b, nc, h, n = attn.shape
+            r = self.resolutions[i]
+            a = attn.contiguous().view(b * nc, h, r, r, r)
+            a = self.attn_convs1[i](self.attn_convs0[i](a))
+            feat_maps.append(a.reshape(b, nc, r, r, r))
+            nxt = self.query_convs[i](q_out)
+            updated_qs.append(q_out.mean(dim=0, keepdim=True))
+        return feat_maps, updated_qs

@@ -1,0 +1,95 @@
+"""Parameter-holding building blocks whose forward runs on the HIP kernels (icl_amd.ops).
+
+Module/attribute names are chosen so that ``state_dict()`` keys equal the reference's
+(/root/reference/code/networks/utils.py:99-123,260-276 and unet_3D_icl.py:155-345): checkpoints saved by
+the reference trainers load here and vice versa.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class Conv3d(nn.Module):
+    """nn.Conv3d(cin, cout, k, stride 1, padding k//2) parameters; forward = MFMA implicit-GEMM kernel."""
+
+    def __init__(self, cin, cout, ks=3, bias=True, groups=1, device=None, kaiming_normal=False):
+        super().__init__()
+        self.cin, self.cout, self.ks, self.groups = cin, cout, ks, groups
+        self.weight = nn.Parameter(torch.empty(cout, cin // groups, ks, ks, ks, device=device))
+        self.bias = nn.Parameter(torch.empty(cout, device=device)) if bias else None
+        fan_in = (cin // groups) * ks ** 3
+        with torch.no_grad():
+            if kaiming_normal:  # networks_other.py:64-69 via init_weights('kaiming')
+                self.weight.normal_(0.0, math.sqrt(2.0 / fan_in))
+            else:  # torch default: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                self.weight.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+            if self.bias is not None:
+                self.bias.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+
+    def forward(self, x):
+        if self.groups != 1:
+            return ops.depthwise_conv3d(x, self.weight)
+        return ops.conv3d(x, self.weight, self.bias)
+
+
+class InstanceNormReLU(nn.Module):
+    """nn.InstanceNorm3d(c) (eps 1e-5, affine=False) followed by ReLU — one fused kernel pair."""
+
+    def forward(self, x):
+        return ops.instance_norm_relu(x, relu=True)
+
+
+class _Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class ConvBlock(nn.Sequential):
+    """Sequential(Conv3d, InstanceNorm3d, ReLU): keys '0.weight', '0.bias' (utils.py:104-106).
+    Index 1 fuses norm+ReLU; index 2 is kept as a no-op so the child layout matches the reference."""
+
+    def __init__(self, cin, cout, device=None):
+        super().__init__(Conv3d(cin, cout, 3, device=device, kaiming_normal=True), InstanceNormReLU(), _Identity())
+
+
+class UnetConv3(nn.Module):
+    """Two ConvBlocks (networks/utils.py:99-123)."""
+
+    def __init__(self, cin, cout, device=None):
+        super().__init__()
+        self.conv1 = ConvBlock(cin, cout, device)
+        self.conv2 = ConvBlock(cout, cout, device)
+
+    def forward(self, x):
+        return self.conv2(self.conv1(x))
+
+
+class UnetUp3_CT(nn.Module):
+    """Trilinear x2 of the deeper map written straight into the concat buffer, then UnetConv3
+    (networks/utils.py:260-276); channel order [skip, upsampled]."""
+
+    def __init__(self, in_size, out_size, device=None):
+        super().__init__()
+        self.conv = UnetConv3(in_size + out_size, out_size, device)
+        self.up = _Identity()  # nn.Upsample has no parameters; kept for module-tree parity
+
+    def forward(self, skip, deep):
+        return self.conv(ops.upsample2x_concat(skip, deep))
+
+
+class Dropout3(nn.Module):
+    """nn.Dropout(p) on the HIP counter-based mask kernel (unet_3D_icl.py:67-68)."""
+
+    def __init__(self, p=0.3):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        return ops.dropout(x, self.p)

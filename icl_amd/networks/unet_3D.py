@@ -1,0 +1,65 @@
+"""Plain 3D U-Net backbone on the HIP kernels — drop-in for the reference's ``unet_3D``
+(/root/reference/code/networks/unet_3D.py:20-94): same constructor, same 38-key ``state_dict``,
+``forward(inputs) -> logits``.  It is the inference/checkpoint target of the ICL trainers
+(SURVEY.md §0.8)."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .layers import Conv3d, Dropout3, UnetConv3, UnetUp3_CT, _Identity
+
+
+class UNet3DBackbone(nn.Module):
+    """Everything ``unet_3D`` and ``unet_3D_icl`` share (unet_3D_icl.py:28-68): 5 encoder stages,
+    4 decoder stages, 1x1x1 classifier, two Dropout(0.3)."""
+
+    def __init__(self, feature_scale=4, n_classes=21, is_deconv=True, in_channels=3, is_batchnorm=True, device=None):
+        super().__init__()
+        if not is_batchnorm:
+            raise NotImplementedError("the reference only ever builds the InstanceNorm variant (is_batchnorm=True)")
+        self.is_deconv, self.in_channels = is_deconv, in_channels
+        self.is_batchnorm, self.feature_scale = is_batchnorm, feature_scale
+        f = [int(x / feature_scale) for x in (64, 128, 256, 512, 1024)]
+        self.filters = f
+        self.conv1 = UnetConv3(in_channels, f[0], device)
+        self.maxpool1 = _Identity()  # pooling is parameter-free; see _pool below
+        self.conv2 = UnetConv3(f[0], f[1], device)
+        self.maxpool2 = _Identity()
+        self.conv3 = UnetConv3(f[1], f[2], device)
+        self.maxpool3 = _Identity()
+        self.conv4 = UnetConv3(f[2], f[3], device)
+        self.maxpool4 = _Identity()
+        self.center = UnetConv3(f[3], f[4], device)
+        self.up_concat4 = UnetUp3_CT(f[4], f[3], device)
+        self.up_concat3 = UnetUp3_CT(f[3], f[2], device)
+        self.up_concat2 = UnetUp3_CT(f[2], f[1], device)
+        self.up_concat1 = UnetUp3_CT(f[1], f[0], device)
+        self.final = Conv3d(f[0], n_classes, 1, device=device, kaiming_normal=True)
+        self.dropout1 = Dropout3(0.3)
+        self.dropout2 = Dropout3(0.3)
+
+    def run_backbone(self, x):
+        """One stream: returns (logits, [center, up4, up3]) — unet_3D_icl.py:100-117."""
+        from .. import ops
+        c1 = self.conv1(x)
+        c2 = self.conv2(ops.max_pool3d_2(c1))
+        c3 = self.conv3(ops.max_pool3d_2(c2))
+        c4 = self.conv4(ops.max_pool3d_2(c3))
+        center = self.dropout1(self.center(ops.max_pool3d_2(c4)))
+        up4 = self.up_concat4(c4, center)
+        up3 = self.up_concat3(c3, up4)
+        up2 = self.up_concat2(c2, up3)
+        up1 = self.dropout2(self.up_concat1(c1, up2))
+        return self.final(up1), [center, up4, up3]
+
+
+class unet_3D(UNet3DBackbone):  # noqa: N801 — reference class name
+    def forward(self, inputs):
+        return self.run_backbone(inputs)[0]
+
+    @staticmethod
+    def apply_argmax_softmax(pred):
+        return torch.softmax(pred, dim=1)

@@ -1,0 +1,39 @@
+"""3D U-Net with the ICL aligner heads on the HIP kernels — drop-in for the reference's
+``unet_3D_icl`` (/root/reference/code/networks/unet_3D_icl.py:26-153).
+
+``forward(x_lab, x_unlab=None, inference=None)``: truthy ``inference`` returns the labeled-stream logits;
+otherwise the 5-tuple ``(final_lab, final_unlab, feat_Maps_lab, feat_Maps_unlab, feat_Maps_consis)``.
+The two streams run as two separate backbone passes with shared weights, exactly like the reference
+(:100-139), so every per-sample statistic matches.
+"""
+from __future__ import annotations
+
+import torch
+
+from .aligner import InherentConsistent
+from .unet_3D import UNet3DBackbone
+
+
+class unet_3D_icl(UNet3DBackbone):  # noqa: N801 — reference class name
+    def __init__(self, feature_scale=4, n_classes=21, is_deconv=True, in_channels=3, is_batchnorm=True, device=None):
+        super().__init__(feature_scale, n_classes, is_deconv, in_channels, is_batchnorm, device)
+        f = self.filters
+        icl_in_chans = (f[4], f[3], f[2])
+        kw = dict(in_chans=icl_in_chans, depths=(2, 2, 2), patch_size=(2, 2, 2), input_resolution=[6, 12, 24],
+                  num_classes=n_classes, num_heads=(16, 8, 4), device=device)
+        self.sspa = InherentConsistent(**kw)
+        self.uscl = InherentConsistent(**kw)
+
+    def forward(self, x_lab, x_unlab=None, inference=None):
+        final_lab, feats_lab = self.run_backbone(x_lab)
+        if inference:
+            return final_lab
+        final_unlab, feats_unlab = self.run_backbone(x_unlab)
+        feat_maps_lab, updated_qs_lab = self.sspa(feats_lab, "labeled")
+        feat_maps_consis, _ = self.sspa(feats_unlab, "labeled")
+        feat_maps_unlab, _ = self.uscl(feats_unlab, updated_qs_lab, "unlabeled")
+        return final_lab, final_unlab, feat_maps_lab, feat_maps_unlab, feat_maps_consis
+
+    @staticmethod
+    def apply_argmax_softmax(pred):
+        return torch.softmax(pred, dim=1)

@@ -1,0 +1,489 @@
+"""torch.autograd wrappers around the C-ABI HIP kernels (include/icl_hip.h).
+
+PyTorch is plumbing here: tensors own the device memory, autograd owns the graph, the current
+torch stream is handed to every launch.  All arithmetic happens in libicl_hip.so.
+Each function cites the reference operator it replaces (paths relative to /root/reference/code).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+_vp = ctypes.c_void_p
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    if t.is_cuda:
+        return _vp(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
+
+
+def _require(*ts: Optional[torch.Tensor]):
+    for t in ts:
+        if t is None:
+            continue
+        if t.dtype not in (torch.float32, torch.uint8, torch.int64):
+            raise TypeError(f"icl_amd: unsupported dtype {t.dtype}")
+        if not t.is_cuda and not _lib.host_pointers_ok():
+            raise RuntimeError("icl_amd: HIP kernels need device tensors (no CPU fallback)")
+
+
+class KernelTimer:
+    """HIP-event timing of individual kernel launches on the stream they are launched on (bench.py roofline).
+    Usage: ``with KernelTimer() as kt: step()``; ``kt.summary()`` -> {name: (launches, ms_total, flops, bytes)}."""
+
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *a):
+        KernelTimer.active = None
+
+    def region(self, name, flops, nbytes, like):
+        return _TimedRegion(self, name, flops, nbytes, like)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, fl, by in self.records:
+            n, ms, f, b = out.get(name, (0, 0.0, 0.0, 0.0))
+            out[name] = (n + 1, ms + e0.elapsed_time(e1), f + fl, b + by)
+        return out
+
+
+class _TimedRegion:
+    def __init__(self, kt, name, flops, nbytes, like):
+        self.kt, self.name, self.flops, self.nbytes, self.like = kt, name, flops, nbytes, like
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
+        self.e0.record(torch.cuda.current_stream(self.like.device))
+
+    def __exit__(self, *a):
+        self.e1.record(torch.cuda.current_stream(self.like.device))
+        self.kt.records.append((self.name, self.e0, self.e1, self.flops, self.nbytes))
+
+
+class _NullRegion:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullRegion()
+
+
+def _timed(name, flops, nbytes, like):
+    kt = KernelTimer.active
+    if kt is None or not like.is_cuda:
+        return _NULL
+    return kt.region(name, flops, nbytes, like)
+
+
+def _ws(nbytes: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty((max(int(nbytes), 4) + 3) // 4, dtype=torch.float32, device=like.device)
+
+
+# --------------------------------------------------------------------------------------
+# Conv3d (k=3 pad 1 or k=1), stride 1 — nn.Conv3d in networks/utils.py:104,107, unet_3D_icl.py:65
+# --------------------------------------------------------------------------------------
+
+def pack_weights(w: torch.Tensor, mode: int) -> torch.Tensor:
+    L = _lib.lib()
+    cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+    n = L.icl_conv3d_packed_elems(cout, cin, ks, mode)
+    wp = torch.empty(n, dtype=torch.float32, device=w.device)
+    _lib.check(L.icl_conv3d_pack_weights(_ptr(w), _ptr(wp), cout, cin, ks, mode, _stream(w)), "pack_weights")
+    return wp
+
+
+def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_bstride):
+    L = _lib.lib()
+    s = d * h * w
+    # algorithmic work of this launch: 2*taps*Cin*Cout FLOP per voxel; 4*(I+O+W) bytes
+    flops = 2.0 * ks ** 3 * cin * cout * s * n
+    nbytes = 4.0 * (n * s * (cin + cout) + ks ** 3 * cin * cout)
+    with _timed("conv3d_mfma_fwd_kernel", flops, nbytes, x):
+        _lib.check(L.icl_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), n, cin, cout, d, h, w, ks,
+                                    x_bstride, y_bstride, _stream(x)), "conv3d_fwd")
+
+
+class _Conv3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require(x, weight, bias)
+        x = x.contiguous()
+        weight = weight.contiguous()
+        n, cin, d, h, w = x.shape
+        cout, ks = weight.shape[0], weight.shape[2]
+        assert weight.shape[1] == cin and weight.shape[2] == weight.shape[3] == weight.shape[4]
+        y = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
+        wp = pack_weights(weight, 0)
+        s = d * h * w
+        conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, cin * s, y, cout * s)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        L = _lib.lib()
+        gy = gy.contiguous()
+        n, cin, d, h, w = x.shape
+        cout, ks = weight.shape[0], weight.shape[2]
+        s = d * h * w
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            wpt = pack_weights(weight, 1)
+            conv3d_forward_raw(gy, wpt, None, n, cout, cin, d, h, w, ks, cout * s, gx, cin * s)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty_like(weight)
+            gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            ws = _ws(L.icl_conv3d_packed_elems(cout, cin, ks, 0) * 4, x)
+            flops = 2.0 * ks ** 3 * cin * cout * s * n
+            nbytes = 4.0 * (n * s * (cin + cout) + 2 * ks ** 3 * cin * cout)
+            with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):
+                _lib.check(L.icl_conv3d_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(ws), n, cin, cout, d, h, w, ks,
+                                              cin * s, cout * s, _stream(x)), "conv3d_wgrad")
+        return gx, gw, gb
+
+
+def conv3d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Conv3d, kernel 3 (pad 1) or 1 (pad 0), stride 1."""
+    return _Conv3d.apply(x, weight, bias)
+
+
+# --------------------------------------------------------------------------------------
+# InstanceNorm3d / BatchNorm3d (+ReLU) — networks/utils.py:105-109, unet_3D_icl.py:325-340
+# --------------------------------------------------------------------------------------
+
+class _NormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, mode, use_batch_stats, act, eps, momentum):
+        _require(x, gamma, beta, running_mean, running_var)
+        L = _lib.lib()
+        x = x.contiguous()
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        groups = c if mode == 1 else n * c
+        y = torch.empty_like(x)
+        ws = _ws(L.icl_norm_ws_bytes(n, c, s), x)
+        if use_batch_stats:
+            mean = torch.empty(groups, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(groups, dtype=torch.float32, device=x.device)
+            rm, rv = running_mean, running_var
+        else:  # eval-mode BatchNorm: fixed statistics
+            assert mode == 1 and running_mean is not None
+            mean = running_mean.detach().clone()
+            rstd = torch.empty(groups, dtype=torch.float32, device=x.device)
+            _lib.check(L.icl_rstd_from_var(_ptr(running_var), _ptr(rstd), c, eps, _stream(x)), "rstd_from_var")
+            rm = rv = None
+        _lib.check(L.icl_norm_fwd(_ptr(x), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv),
+                                  n, c, s, mode, int(use_batch_stats), act, eps, momentum, _ptr(ws), _stream(x)), "norm_fwd")
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.cfg = (mode, int(use_batch_stats), act)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        mode, ubs, act = ctx.cfg
+        L = _lib.lib()
+        gy = gy.contiguous()
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        gx = torch.empty_like(x)
+        dg = db = None
+        if gamma is not None:
+            dg = torch.empty_like(gamma)
+            db = torch.empty_like(beta)
+        ws = _ws(L.icl_norm_ws_bytes(n, c, s), x)
+        _lib.check(L.icl_norm_bwd(_ptr(gy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(gx), _ptr(dg),
+                                  _ptr(db), n, c, s, mode, ubs, act, _ptr(ws), _stream(x)), "norm_bwd")
+        return gx, dg, db, None, None, None, None, None, None, None
+
+
+def instance_norm_relu(x: torch.Tensor, relu: bool = True, eps: float = 1e-5) -> torch.Tensor:
+    """InstanceNorm3d(affine=False, no running stats) [+ ReLU] fused."""
+    return _NormAct.apply(x, None, None, None, None, 0, True, int(relu), eps, 0.0)
+
+
+def batch_norm_relu(x, gamma, beta, running_mean, running_var, training: bool, relu: bool = True,
+                    eps: float = 1e-5, momentum: float = 0.1) -> torch.Tensor:
+    """BatchNorm3d (batch statistics + running-stat update in training, running stats in eval) [+ ReLU]."""
+    return _NormAct.apply(x, gamma, beta, running_mean, running_var, 1, bool(training), int(relu), eps, momentum)
+
+
+# --------------------------------------------------------------------------------------
+# MaxPool3d(2) — networks/unet_3D_icl.py:41-53
+# --------------------------------------------------------------------------------------
+
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require(x)
+        L = _lib.lib()
+        x = x.contiguous()
+        n, c, d, h, w = x.shape
+        assert d % 2 == 0 and h % 2 == 0 and w % 2 == 0, "MaxPool3d(2) kernels need even extents"
+        y = torch.empty((n, c, d // 2, h // 2, w // 2), dtype=torch.float32, device=x.device)
+        idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+        _lib.check(L.icl_maxpool2_fwd(_ptr(x), _ptr(y), _ptr(idx), n * c, d // 2, h // 2, w // 2, _stream(x)), "maxpool2_fwd")
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        L = _lib.lib()
+        gy = gy.contiguous()
+        n, c, d, h, w = gy.shape
+        gx = torch.empty((n, c, d * 2, h * 2, w * 2), dtype=torch.float32, device=gy.device)
+        _lib.check(L.icl_maxpool2_bwd(_ptr(gy), _ptr(idx), _ptr(gx), n * c, d, h, w, _stream(gy)), "maxpool2_bwd")
+        return gx
+
+
+def max_pool3d_2(x: torch.Tensor) -> torch.Tensor:
+    return _MaxPool2.apply(x)
+
+
+# --------------------------------------------------------------------------------------
+# trilinear resize (align_corners=False) — networks/utils.py:264, utils/losses.py:263,292
+# --------------------------------------------------------------------------------------
+
+class _Trilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        _require(x)
+        L = _lib.lib()
+        x = x.contiguous()
+        n, c, di, hi, wi = x.shape
+        do, ho, wo = size
+        y = torch.empty((n, c, do, ho, wo), dtype=torch.float32, device=x.device)
+        _lib.check(L.icl_trilinear_fwd(_ptr(x), _ptr(y), n, c, di, hi, wi, do, ho, wo, c * do * ho * wo, _stream(x)),
+                   "trilinear_fwd")
+        ctx.in_shape = (n, c, di, hi, wi)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        gy = gy.contiguous()
+        n, c, di, hi, wi = ctx.in_shape
+        do, ho, wo = gy.shape[2:]
+        gx = torch.empty(ctx.in_shape, dtype=torch.float32, device=gy.device)
+        _lib.check(L.icl_trilinear_bwd(_ptr(gy), _ptr(gx), n, c, di, hi, wi, do, ho, wo, c * do * ho * wo, _stream(gy)),
+                   "trilinear_bwd")
+        return gx, None
+
+
+def trilinear_resize(x: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
+    return _Trilinear.apply(x, tuple(int(s) for s in size))
+
+
+class _UpCat(torch.autograd.Function):
+    """cat([skip, upsample2x(deep)], 1) without materialising the upsampled tensor:
+    the resize kernel writes straight into the channel slice of the concat buffer
+    (UnetUp3_CT.forward, networks/utils.py:271-276)."""
+
+    @staticmethod
+    def forward(ctx, skip, deep):
+        _require(skip, deep)
+        L = _lib.lib()
+        skip = skip.contiguous()
+        deep = deep.contiguous()
+        n, cs, d, h, w = skip.shape
+        cd = deep.shape[1]
+        assert deep.shape[0] == n and tuple(deep.shape[2:]) == (d // 2, h // 2, w // 2)
+        s = d * h * w
+        out = torch.empty((n, cs + cd, d, h, w), dtype=torch.float32, device=skip.device)
+        _lib.check(L.icl_copy_rows(_ptr(skip), _ptr(out), n, cs * s, cs * s, (cs + cd) * s, _stream(skip)), "copy_rows")
+        up_view = out[:, cs:]
+        _lib.check(L.icl_trilinear_fwd(_ptr(deep), _vp(up_view.data_ptr()), n, cd, d // 2, h // 2, w // 2, d, h, w,
+                                       (cs + cd) * s, _stream(skip)), "trilinear_fwd")
+        ctx.dims = (n, cs, cd, d, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        g = g.contiguous()
+        n, cs, cd, d, h, w = ctx.dims
+        s = d * h * w
+        gskip = gdeep = None
+        if ctx.needs_input_grad[0]:
+            gskip = torch.empty((n, cs, d, h, w), dtype=torch.float32, device=g.device)
+            _lib.check(L.icl_copy_rows(_ptr(g), _ptr(gskip), n, cs * s, (cs + cd) * s, cs * s, _stream(g)), "copy_rows")
+        if ctx.needs_input_grad[1]:
+            gdeep = torch.empty((n, cd, d // 2, h // 2, w // 2), dtype=torch.float32, device=g.device)
+            gv = g[:, cs:]
+            _lib.check(L.icl_trilinear_bwd(_vp(gv.data_ptr()), _ptr(gdeep), n, cd, d // 2, h // 2, w // 2, d, h, w,
+                                           (cs + cd) * s, _stream(g)), "trilinear_bwd")
+        return gskip, gdeep
+
+
+def upsample2x_concat(skip: torch.Tensor, deep: torch.Tensor) -> torch.Tensor:
+    return _UpCat.apply(skip, deep)
+
+
+# --------------------------------------------------------------------------------------
+# depthwise Conv3d 3^3 (groups = C, no bias) — SeparableConv3d.depthwise, unet_3D_icl.py:320-323
+# --------------------------------------------------------------------------------------
+
+class _DWConv3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        _require(x, weight)
+        L = _lib.lib()
+        x = x.contiguous()
+        weight = weight.contiguous()
+        n, c, d, h, w = x.shape
+        assert tuple(weight.shape) == (c, 1, 3, 3, 3)
+        y = torch.empty_like(x)
+        _lib.check(L.icl_dwconv3_fwd(_ptr(x), _ptr(weight), _ptr(y), n, c, d, h, w, 0, _stream(x)), "dwconv3_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        L = _lib.lib()
+        gy = gy.contiguous()
+        n, c, d, h, w = x.shape
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(L.icl_dwconv3_fwd(_ptr(gy), _ptr(weight), _ptr(gx), n, c, d, h, w, 1, _stream(x)), "dwconv3_dgrad")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(weight)
+            _lib.check(L.icl_dwconv3_wgrad(_ptr(x), _ptr(gy), _ptr(gw), n, c, d, h, w, _stream(x)), "dwconv3_wgrad")
+        return gx, gw
+
+
+def depthwise_conv3d(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    return _DWConv3.apply(x, weight)
+
+
+# --------------------------------------------------------------------------------------
+# Dropout — nn.Dropout(p=0.3), unet_3D_icl.py:67-68
+# --------------------------------------------------------------------------------------
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _require(x)
+        L = _lib.lib()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(L.icl_dropout(_ptr(x), _ptr(y), x.numel(), seed, p, _stream(x)), "dropout")
+        ctx.cfg = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        p, seed = ctx.cfg
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        _lib.check(L.icl_dropout(_ptr(gy), _ptr(gx), gy.numel(), seed, p, _stream(gy)), "dropout_bwd")
+        return gx, None, None
+
+
+_dropout_counter = [0]
+
+
+def dropout(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Tensor:
+    """Training-mode dropout; the seed advances with torch's CPU generator so runs are reproducible under manual_seed."""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return _Dropout.apply(x, float(p), int(seed) & 0xFFFFFFFF)
+
+
+# --------------------------------------------------------------------------------------
+# Aligner token ops (Linear / LayerNorm / GELU / prototype attention), unet_3D_icl.py:244-315.
+# STOP-GAP: these four still dispatch to ATen/rocBLAS on the device; DESIGN.md tracks their
+# replacement by HIP kernels (skinny weight-streaming GEMM for mlp2, fused LN, fused attention).
+# --------------------------------------------------------------------------------------
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    return torch.nn.functional.linear(x, weight, bias)
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    return torch.nn.functional.layer_norm(x, (weight.shape[0],), weight, bias, eps)
+
+
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    return torch.nn.functional.gelu(x)
+
+
+def prototype_attention(qh: torch.Tensor, kv: torch.Tensor, heads: int, scale: float):
+    """qh [B,h,nc,d]; kv [B,N,2*h*d] laid out (k|v, head, d).  Returns (softmax(QK^T*scale) V  [B,h,nc,d],
+    scaled pre-softmax logits [B,h,nc,N])."""
+    B, N, C2 = kv.shape
+    d = C2 // (2 * heads)
+    kvp = kv.reshape(B, N, 2, heads, d).permute(2, 0, 3, 1, 4)
+    k, v = kvp[0], kvp[1]
+    logits = (qh @ k.transpose(-2, -1)) * scale
+    out = logits.softmax(dim=-1) @ v
+    return out, logits
+
+
+# --------------------------------------------------------------------------------------
+# Loss reductions (utils/losses.py L1-L5).  STOP-GAP torch expressions on the device until the fused
+# softmax+Dice/CE/MSE reduction kernels land.
+# --------------------------------------------------------------------------------------
+
+def dice_loss(inputs: torch.Tensor, labels: torch.Tensor, n_classes: int, softmax: bool = False, weight=None):
+    """DiceLoss.forward (losses.py:218-231); labels [B, ...] integer class ids."""
+    p = torch.softmax(inputs, dim=1) if softmax else inputs
+    B = p.shape[0]
+    pf = p.reshape(B, n_classes, -1)
+    lab = labels.reshape(B, 1, -1)
+    cls = torch.arange(n_classes, device=p.device, dtype=lab.dtype).view(1, n_classes, 1)
+    t = (lab == cls).to(p.dtype)
+    inter = (pf * t).sum(dim=(0, 2))
+    z = (pf * pf).sum(dim=(0, 2))
+    y = t.sum(dim=(0, 2))
+    dice = 1 - (2 * inter + 1e-5) / (z + y + 1e-5)
+    if weight is not None:
+        dice = dice * torch.as_tensor(weight, device=p.device, dtype=p.dtype)
+    return dice.sum() / n_classes
+
+
+def cross_entropy_dice(logits: torch.Tensor, labels: torch.Tensor, n_classes: int):
+    """CE(logits, labels) + DiceLoss(softmax=True)(logits, labels) — one AuxLoss3D term (losses.py:268-269)."""
+    return torch.nn.functional.cross_entropy(logits, labels) + dice_loss(logits, labels, n_classes, softmax=True)
+
+
+def soft_dice_loss(a: torch.Tensor, b: torch.Tensor):
+    """softmax_dice_loss (losses.py:42-59): per class 1-(2*sum(sa*sb)+eps)/(sum(sa)+sum(sb)+eps), mean over classes."""
+    n = a.shape[1]
+    sa = torch.softmax(a, dim=1).transpose(0, 1).reshape(n, -1)
+    sb = torch.softmax(b, dim=1).transpose(0, 1).reshape(n, -1)
+    inter = (sa * sb).sum(dim=1)
+    d = 1 - (2 * inter + 1e-5) / (sa.sum(dim=1) + sb.sum(dim=1) + 1e-5)
+    return d.sum() / n
+
+
+def softmax_mse(a: torch.Tensor, b: torch.Tensor):
+    """mean((softmax(a,1) - softmax(b,1))^2) — one scale of softmax_mse_loss (losses.py:82-87)."""
+    return torch.mean((torch.softmax(a, dim=1) - torch.softmax(b, dim=1)) ** 2)

@@ -1,0 +1,81 @@
+"""One ICL training iteration — the build's counterpart of the hot loop in
+/root/reference/code/train_inherent_consistent_unet_3D_BraTS.py:99-121.
+
+    outputs = model(volume[:labeled_bs], volume[labeled_bs:])
+    loss    = dice + ce + aux + w_pse*pse + w_con*consistency          (:105-112; AMOS: w_pse = 0.1)
+    zero_grad -> backward -> [gradient all-reduce when world_size > 1] -> SGD(momentum 0.9, wd 1e-4) step
+    lr      = base_lr * (1 - iter/max_iter)**0.9, computed from the pre-increment iter, used from the next step
+
+The reference trainers can also be used unchanged with ``icl_amd.networks.net_factory_3d`` and
+``icl_amd.utils.losses``; this module exists so bench.py / tests / DDP have one
+function to call, without the per-iteration ``.item()`` syncs of the reference logging (:131-133).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+from torch.nn.modules.loss import CrossEntropyLoss
+
+from .utils import losses as L
+
+
+@dataclass
+class ICLConfig:
+    num_classes: int = 2
+    labeled_bs: int = 1
+    base_lr: float = 0.01
+    max_iterations: int = 30000
+    momentum: float = 0.9
+    weight_decay: float = 1e-4
+    w_pse: float = 1.0     # 0.1 in the AMOS trainer (train_..._AMOS22.py:230)
+    w_con: float = 10.0
+    patch_size: tuple = (96, 96, 96)
+
+
+class ICLTrainer:
+    def __init__(self, model: torch.nn.Module, cfg: ICLConfig, ddp=None):
+        self.model, self.cfg, self.ddp = model, cfg, ddp
+        self.optimizer = torch.optim.SGD(model.parameters(), lr=cfg.base_lr, momentum=cfg.momentum,
+                                         weight_decay=cfg.weight_decay)
+        self.ce_loss = CrossEntropyLoss()
+        self.dice_loss = L.DiceLoss(cfg.num_classes)
+        self.aux_loss = L.AuxLoss3D(cfg.num_classes, cfg.patch_size)
+        self.pse_loss = L.PseudoSoftLoss3D(cfg.num_classes, cfg.patch_size)
+        self.iter_num = 0
+
+    def compute_loss(self, outputs, label_batch):
+        cfg = self.cfg
+        lab = label_batch[:cfg.labeled_bs]
+        outputs_soft = torch.softmax(outputs[0], dim=1)
+        loss_ce = self.ce_loss(outputs[0], lab)
+        loss_dice = self.dice_loss(outputs_soft, lab.unsqueeze(1))
+        loss_aux = self.aux_loss(outputs[2], lab)
+        loss_pse = self.pse_loss(outputs[3], outputs[1])
+        loss_con = L.softmax_mse_loss(outputs[3], outputs[4])
+        loss = loss_dice + loss_ce + loss_aux + cfg.w_pse * loss_pse + cfg.w_con * loss_con
+        return loss, dict(dice=loss_dice, ce=loss_ce, aux=loss_aux, pse=loss_pse, con=loss_con)
+
+    def step(self, volume_batch: torch.Tensor, label_batch: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """One iteration; returns the (device-resident, un-synced) loss terms."""
+        cfg = self.cfg
+        outputs = self.model(volume_batch[:cfg.labeled_bs], volume_batch[cfg.labeled_bs:])
+        loss, parts = self.compute_loss(outputs, label_batch)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.ddp is not None:
+            self.ddp.reduce_gradients()
+        self.optimizer.step()
+        lr = cfg.base_lr * (1.0 - self.iter_num / cfg.max_iterations) ** 0.9
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
+        self.iter_num += 1
+        parts["loss"] = loss.detach()
+        return parts
+
+
+def backbone_state_dict(model: torch.nn.Module):
+    """The checkpoint the reference trainers save: every key without 'sspa'/'uscl' (…BraTS.py:158-162)."""
+    from collections import OrderedDict
+    return OrderedDict((k, v) for k, v in model.state_dict().items() if "sspa" not in k and "uscl" not in k)

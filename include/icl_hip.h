@@ -1,0 +1,80 @@
+/* icl_hip.h — C ABI of libicl_hip.so, the gfx950 (MI355X) kernels behind the ICL hot path.
+ *
+ * The reference (zhuye98/ICL) is pure PyTorch and has no FFI of its own; each entry point below
+ * replaces the ATen operator the reference dispatches at the cited call site
+ * (paths relative to /root/reference/code).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 (unless typed otherwise) owned by the caller;
+ *    the library allocates nothing and keeps no state; `ws` arguments are caller-provided scratch
+ *    whose size comes from the matching *_ws_bytes() query;
+ *  - tensors are dense NC[D]HW unless a batch stride (in elements) is given;
+ *  - `stream` is a hipStream_t; launches are asynchronous on it, no device synchronisation inside;
+ *  - return 0 on success, a negative code on error (-1 bad argument, -2 launch failure);
+ *    icl_last_error() returns a thread-local message.  Nothing throws across the boundary.
+ */
+#ifndef ICL_HIP_H
+#define ICL_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int icl_abi_version(void);
+const char* icl_last_error(void);
+
+/* ---- Conv3d k=3 pad=1 / k=1, stride 1 (networks/utils.py:104,107; networks/unet_3D_icl.py:65,178,196,327).
+ * Weights are used in packed form Wp[taps][KP][NP]: mode 0 (forward) K=Cin,N=Cout; mode 1 (dgrad) K=Cout,N=Cin
+ * with taps flipped.  KP = round_up(K,4), NP = round_up(N,16). */
+int64_t icl_conv3d_packed_elems(int cout, int cin, int ks, int mode);
+int icl_conv3d_pack_weights(const float* w, float* wp, int cout, int cin, int ks, int mode, void* stream);
+/* y[n, 0:cout] = conv(x[n, 0:cin], Wp) + bias (bias may be NULL).  dgrad: call with Wp packed in mode 1,
+ * x = dY, cin/cout swapped, bias NULL.  Batch strides in elements; channel stride is D*H*W. */
+int icl_conv3d_fwd(const float* x, const float* wp, const float* bias, float* y, int n, int cin, int cout, int d, int h,
+                   int w, int ks, int64_t x_bstride, int64_t y_bstride, void* stream);
+/* gw[cout][cin][taps] = sum over batch and voxels; ws >= icl_conv3d_packed_elems(cout,cin,ks,0)*4 bytes.
+ * gbias (may be NULL) [cout] = sum of gy. */
+int icl_conv3d_wgrad(const float* x, const float* gy, float* gw, float* gbias, void* ws, int n, int cin, int cout, int d,
+                     int h, int w, int ks, int64_t x_bstride, int64_t gy_bstride, void* stream);
+
+/* ---- InstanceNorm3d(+ReLU) (networks/utils.py:105-106,108-109) and BatchNorm3d(+ReLU)
+ * (networks/unet_3D_icl.py:325-340).  mode 0 = instance (group = (n,c)), 1 = batch (group = c).
+ * use_batch_stats 0 = normalise with the given mean/rstd... (eval-mode BatchNorm: mean=running_mean,
+ * rstd computed from running_var by icl_rstd_from_var).  act 0 none / 1 ReLU.  gamma/beta/running_* may be NULL. */
+int64_t icl_norm_ws_bytes(int n, int c, int64_t s);
+int icl_norm_fwd(const float* x, float* y, float* mean, float* rstd, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, int n, int c, int64_t s, int mode, int use_batch_stats,
+                 int act, float eps, float momentum, void* ws, void* stream);
+int icl_norm_bwd(const float* gy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                 const float* beta, float* gx, float* dgamma, float* dbeta, int n, int c, int64_t s, int mode,
+                 int use_batch_stats, int act, void* ws, void* stream);
+int icl_rstd_from_var(const float* var, float* rstd, int c, float eps, void* stream);
+
+/* ---- MaxPool3d(2) (networks/unet_3D_icl.py:41-53); idx = uint8 argmax within the 2x2x2 window. */
+int icl_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int64_t nc, int dout, int hout, int wout, void* stream);
+int icl_maxpool2_bwd(const float* gy, const uint8_t* idx, float* gx, int64_t nc, int dout, int hout, int wout, void* stream);
+
+/* ---- trilinear resize, align_corners=False (networks/utils.py:264; utils/losses.py:263,292).
+ * Source index scale per axis = in/out (what ATen uses for size= and for scale_factor=2). */
+int icl_trilinear_fwd(const float* x, float* y, int n, int c, int di, int hi, int wi, int dout, int hout, int wout,
+                      int64_t y_bstride, void* stream);
+int icl_trilinear_bwd(const float* gy, float* gx, int n, int c, int di, int hi, int wi, int dout, int hout, int wout,
+                      int64_t gy_bstride, void* stream);
+
+/* ---- strided row copy (torch.cat([skip, up], 1), networks/utils.py:276) */
+int icl_copy_rows(const float* src, float* dst, int64_t rows, int64_t row_elems, int64_t src_stride, int64_t dst_stride,
+                  void* stream);
+
+/* ---- depthwise Conv3d k=3 pad=1 groups=C, no bias (networks/unet_3D_icl.py:320-323).
+ * w is [C][27]; flip=1 applies the transposed stencil (input gradient). gw [C][27] is overwritten. */
+int icl_dwconv3_fwd(const float* x, const float* w, float* y, int n, int c, int d, int h, int wd, int flip, void* stream);
+int icl_dwconv3_wgrad(const float* x, const float* gy, float* gw, int n, int c, int d, int h, int wd, void* stream);
+
+/* ---- nn.Dropout(p) (networks/unet_3D_icl.py:67-68,110,116): y = keep ? x/(1-p) : 0 with a counter-based
+ * mask keyed by (seed, element index); calling it again with the same seed on dY is the backward. */
+int icl_dropout(const float* x, float* y, int64_t n, uint32_t seed, float p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

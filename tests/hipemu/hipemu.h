@@ -1,0 +1,308 @@
+// hipemu.h — TEST INFRASTRUCTURE: run the HIP kernel sources of icl_amd/csrc on the CPU.
+//
+// The build container has no GPU, so every kernel in icl_amd/csrc/kernels/*.h is written
+// against a small device environment (csrc/device_env_hip.h for the product).  This header
+// is the second implementation of that environment: each "GPU thread" is a ucontext fiber,
+// a workgroup is a set of fibers stepped cooperatively, __syncthreads() and the wave-wide
+// collectives (shuffles, MFMA) are rendezvous points.  Blocks run sequentially per OS
+// thread and are spread over OS threads.  It is slow and only meant for tiny shapes:
+// tests/ uses it to check kernel index math, LDS tiling, MFMA lane maps and the autograd
+// wrappers against the oracle before GPU minutes are spent.  Never part of the product.
+//
+// MFMA lane maps follow /opt/skills/guides/cdna_hip_programming.md §3 (f32 16x16x4:
+// A[l&15][k=l>>4], B[k=l>>4][l&15], D col=l&15,row=(l>>4)*4+reg; fmaf chain in k order).
+#pragma once
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <ucontext.h>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+typedef float f32x4 __attribute__((vector_size(16)));
+typedef float f32x16 __attribute__((vector_size(64)));
+typedef void* hipStream_t;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+
+namespace hipemu {
+
+constexpr int kWave = 64;
+constexpr size_t kStack = 256 * 1024;
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  int state = 0;  // 0 runnable, 1 wait-block, 2 wait-wave, 3 done
+  dim3 tid;
+};
+
+struct Worker {
+  ucontext_t sched;
+  std::vector<Fiber> fibers;
+  int cur = -1;
+  int nthreads = 0;
+  const std::function<void()>* body = nullptr;
+  std::vector<unsigned char> dyn;
+  // wave exchange slots: [wave][lane][4 dwords]
+  std::vector<uint32_t> xch;
+};
+
+inline thread_local Worker* W = nullptr;
+inline thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+
+inline void trampoline() {
+  Worker* w = W;
+  (*w->body)();
+  w->fibers[w->cur].state = 3;
+  swapcontext(&w->fibers[w->cur].ctx, &w->sched);
+}
+
+inline void yield_state(int st) {
+  Worker* w = W;
+  Fiber& f = w->fibers[w->cur];
+  f.state = st;
+  swapcontext(&f.ctx, &w->sched);
+  g_threadIdx = f.tid;  // restored by scheduler too; belt and braces
+}
+
+inline void run_block(Worker* w, dim3 bid, dim3 block) {
+  const int n = block.x * block.y * block.z;
+  w->nthreads = n;
+  if ((int)w->fibers.size() < n) {
+    size_t old = w->fibers.size();
+    w->fibers.resize(n);
+    for (size_t i = old; i < (size_t)n; ++i) w->fibers[i].stack = (char*)malloc(kStack);
+  }
+  w->xch.assign((size_t)((n + kWave - 1) / kWave) * kWave * 4, 0u);
+  g_blockIdx = bid;
+  for (int i = 0; i < n; ++i) {
+    Fiber& f = w->fibers[i];
+    f.state = 0;
+    f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = &w->sched;
+    makecontext(&f.ctx, (void (*)())trampoline, 0);
+  }
+  for (;;) {
+    bool progressed = false;
+    int done = 0;
+    for (int i = 0; i < n; ++i) {
+      Fiber& f = w->fibers[i];
+      if (f.state == 3) { ++done; continue; }
+      if (f.state != 0) continue;
+      w->cur = i;
+      g_threadIdx = f.tid;
+      swapcontext(&w->sched, &f.ctx);
+      progressed = true;
+    }
+    if (done == n) break;
+    // release barriers whose participants have all arrived
+    int live = 0, atblk = 0;
+    for (int i = 0; i < n; ++i) {
+      if (w->fibers[i].state != 3) ++live;
+      if (w->fibers[i].state == 1) ++atblk;
+    }
+    if (live > 0 && atblk == live) {
+      for (int i = 0; i < n; ++i) if (w->fibers[i].state == 1) w->fibers[i].state = 0;
+      progressed = true;
+    }
+    for (int wv = 0; wv * kWave < n; ++wv) {
+      int lo = wv * kWave, hi = std::min(n, lo + kWave), lv = 0, at = 0;
+      for (int i = lo; i < hi; ++i) {
+        if (w->fibers[i].state != 3) ++lv;
+        if (w->fibers[i].state == 2) ++at;
+      }
+      if (lv > 0 && at == lv) {
+        for (int i = lo; i < hi; ++i) if (w->fibers[i].state == 2) w->fibers[i].state = 0;
+        progressed = true;
+      }
+    }
+    if (!progressed) {
+      fprintf(stderr, "hipemu: deadlock in block (%u,%u,%u): divergent barrier\n", bid.x, bid.y, bid.z);
+      abort();
+    }
+  }
+}
+
+inline int emu_threads() {
+  const char* e = getenv("HIPEMU_THREADS");
+  int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+  return n < 1 ? 1 : n;
+}
+
+inline void launch(dim3 grid, dim3 block, size_t dyn_lds, const std::function<void()>& body) {
+  const long nblk = (long)grid.x * grid.y * grid.z;
+  if (nblk == 0) return;
+  std::atomic<long> next{0};
+  auto work = [&]() {
+    Worker w;
+    W = &w;
+    w.body = &body;
+    w.dyn.assign(dyn_lds + 64, 0);
+    g_blockDim = block;
+    g_gridDim = grid;
+    for (;;) {
+      long b = next.fetch_add(1);
+      if (b >= nblk) break;
+      dim3 bid((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y)));
+      run_block(&w, bid, block);
+    }
+    for (auto& f : w.fibers) free(f.stack);
+    W = nullptr;
+  };
+  int nt = (int)std::min<long>(emu_threads(), nblk);
+  if (nt <= 1) { work(); return; }
+  std::vector<std::thread> th;
+  for (int i = 0; i < nt; ++i) th.emplace_back(work);
+  for (auto& t : th) t.join();
+}
+
+inline void* dyn_lds() {
+  uintptr_t p = (uintptr_t)W->dyn.data();
+  return (void*)((p + 63) & ~(uintptr_t)63);
+}
+
+inline int lane_linear() {
+  const dim3& t = g_threadIdx;
+  return (int)(t.x + g_blockDim.x * (t.y + g_blockDim.y * t.z));
+}
+
+// wave-wide exchange of up to 4 dwords per lane: publish, rendezvous, read peer, rendezvous
+inline void wave_publish(const uint32_t* v, int nd) {
+  int lin = lane_linear();
+  memcpy(&W->xch[(size_t)lin * 4], v, nd * 4);
+  yield_state(2);
+}
+inline const uint32_t* wave_peer(int src_lane) {
+  int lin = lane_linear();
+  int base = (lin / kWave) * kWave;
+  return &W->xch[(size_t)(base + src_lane) * 4];
+}
+inline void wave_done() { yield_state(2); }
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::g_threadIdx)
+#define blockIdx (hipemu::g_blockIdx)
+#define blockDim (hipemu::g_blockDim)
+#define gridDim (hipemu::g_gridDim)
+
+static inline void __syncthreads() { hipemu::yield_state(1); }
+
+template <typename T>
+static inline T hipemu_shfl_from(T v, int src) {
+  static_assert(sizeof(T) == 4, "4-byte shuffles only");
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  hipemu::wave_publish(&u, 1);
+  uint32_t r = hipemu::wave_peer(src & 63)[0];
+  hipemu::wave_done();
+  T out;
+  memcpy(&out, &r, 4);
+  return out;
+}
+static inline int hipemu_lane() { return hipemu::lane_linear() & 63; }
+template <typename T> static inline T __shfl_xor(T v, int m, int width = 64) {
+  int l = hipemu_lane();
+  return hipemu_shfl_from(v, (l & ~(width - 1)) | ((l ^ m) & (width - 1)));
+}
+template <typename T> static inline T __shfl_down(T v, int d, int width = 64) {
+  int l = hipemu_lane();
+  int s = (l & (width - 1)) + d;
+  return hipemu_shfl_from(v, s < width ? l + d : l);
+}
+template <typename T> static inline T __shfl(T v, int src, int width = 64) {
+  int l = hipemu_lane();
+  return hipemu_shfl_from(v, (l & ~(width - 1)) | (src & (width - 1)));
+}
+
+static inline float atomicAdd(float* p, float v) {
+  uint32_t* ip = (uint32_t*)p;
+  uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED), neu;
+  float f;
+  do {
+    memcpy(&f, &old, 4);
+    f += v;
+    memcpy(&neu, &f, 4);
+  } while (!__atomic_compare_exchange_n(ip, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  memcpy(&f, &old, 4);
+  return f;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+// v_mfma_f32_16x16x4_f32: D(16x16) = A(16x4) * B(4x16) + C, exact fmaf chain over k = 0..3
+static inline f32x4 icl_mfma_16x16x4(float a, float b, f32x4 c) {
+  uint32_t u[2];
+  memcpy(&u[0], &a, 4);
+  memcpy(&u[1], &b, 4);
+  hipemu::wave_publish(u, 2);
+  int l = hipemu_lane();
+  int col = l & 15;
+  f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      float av, bv;
+      memcpy(&av, &hipemu::wave_peer(k * 16 + row)[0], 4);
+      memcpy(&bv, &hipemu::wave_peer(k * 16 + col)[1], 4);
+      acc = fmaf(av, bv, acc);
+    }
+    d[r] = acc;
+  }
+  hipemu::wave_done();
+  return d;
+}
+
+// v_mfma_f32_32x32x2_f32: lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+// D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+static inline f32x16 icl_mfma_32x32x2(float a, float b, f32x16 c) {
+  uint32_t u[2];
+  memcpy(&u[0], &a, 4);
+  memcpy(&u[1], &b, 4);
+  hipemu::wave_publish(u, 2);
+  int l = hipemu_lane();
+  int col = l & 31;
+  f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) {
+      float av, bv;
+      memcpy(&av, &hipemu::wave_peer(k * 32 + row)[0], 4);
+      memcpy(&bv, &hipemu::wave_peer(k * 32 + col)[1], 4);
+      acc = fmaf(av, bv, acc);
+    }
+    d[r] = acc;
+  }
+  hipemu::wave_done();
+  return d;
+}
+
+#define ICL_DYN_LDS(type, name) type* name = (type*)hipemu::dyn_lds()
+#define ICL_LAUNCH(kern, grid, block, lds, stream, ...) \
+  hipemu::launch((grid), (block), (lds), [=]() { kern(__VA_ARGS__); })
+#define ICL_MEMSET_ASYNC(ptr, val, bytes, stream) ((void)memset((ptr), (val), (bytes)))
+#define ICL_LAST_LAUNCH_ERROR() 0
+#define ICL_ERROR_STRING(e) "hipemu"

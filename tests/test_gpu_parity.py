@@ -1,0 +1,238 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): HIP kernels through the C ABI vs the CPU oracle /
+the golden vectors captured from the reference.  Tolerances: 1e-3 relative on logits, 1e-4 on Dice
+(BASELINE.json north_star); kernel-level checks are much tighter (fp32 reassociation only)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_err
+from icl_amd.utils.hashfill import fill_like_reference_init, synthetic_labels, synthetic_volume
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from icl_amd import _lib
+    assert _lib.lib_path().endswith("libicl_hip.so"), "GPU tests must run on the HIP library"
+    return torch.device("cuda", 0)
+
+
+def _rand(shape, seed):
+    return synthetic_volume(tuple(shape), seed)
+
+
+@pytest.mark.parametrize("n,cin,cout,d,h,w,ks", [
+    (2, 3, 4, 8, 8, 8, 3), (1, 1, 16, 6, 6, 6, 3), (1, 16, 32, 4, 8, 16, 3), (1, 20, 48, 6, 6, 12, 3),
+    (2, 8, 2, 4, 4, 8, 1), (1, 32, 16, 2, 8, 32, 3),
+    (1, 1, 16, 48, 48, 48, 3), (1, 16, 16, 48, 48, 48, 3), (1, 48, 16, 32, 32, 32, 3), (1, 96, 32, 24, 24, 24, 3),
+    (2, 64, 128, 12, 12, 12, 3), (1, 384, 128, 12, 12, 12, 3), (1, 256, 256, 6, 6, 6, 3), (1, 16, 2, 48, 48, 48, 1),
+    (2, 64, 64, 24, 24, 24, 1),
+])
+def test_conv3d(dev, n, cin, cout, d, h, w, ks):
+    from icl_amd import ops
+    x = _rand((n, cin, d, h, w), 1)
+    wt = _rand((cout, cin, ks, ks, ks), 2) * (1.0 / np.sqrt(cin * ks ** 3))
+    b = _rand((cout,), 3) * 0.1
+    gy = _rand((n, cout, d, h, w), 4)
+    xg, wg, bg = (t.to(dev).requires_grad_() for t in (x, wt, b))
+    y = ops.conv3d(xg, wg, bg)
+    y.backward(gy.to(dev))
+    xr, wr, br = (t.clone().requires_grad_() for t in (x, wt, b))
+    yr = F.conv3d(xr, wr, br, padding=ks // 2)
+    yr.backward(gy)
+    assert rel_err(y.detach().cpu(), yr.detach()) < 2e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 2e-5
+    assert rel_err(wg.grad.cpu(), wr.grad) < 1e-4
+    assert rel_err(bg.grad.cpu(), br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 4, 6, 8), (1, 16, 48, 48, 48), (2, 256, 6, 6, 6), (1, 2, 96, 96, 96)])
+def test_instance_norm_relu(dev, shape):
+    from icl_amd import ops
+    x = _rand(shape, 5) * 2 + 0.7
+    gy = _rand(shape, 6)
+    xg = x.to(dev).requires_grad_()
+    y = ops.instance_norm_relu(xg)
+    y.backward(gy.to(dev))
+    xr = x.clone().requires_grad_()
+    yr = F.relu(F.instance_norm(xr, eps=1e-5))
+    yr.backward(gy)
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 5e-5
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_batch_norm_relu(dev, training):
+    from icl_amd import ops
+    shape = (4, 8, 12, 12, 12)
+    x = _rand(shape, 7) + 0.3
+    ga, be = 1 + 0.1 * _rand((8,), 8), 0.1 * _rand((8,), 9)
+    rm, rv = 0.1 * _rand((8,), 10), 1 + 0.2 * _rand((8,), 11).abs()
+    gy = _rand(shape, 12)
+    xg, gg, bg = (t.to(dev).requires_grad_() for t in (x, ga, be))
+    rmg, rvg = rm.to(dev), rv.to(dev)
+    y = ops.batch_norm_relu(xg, gg, bg, rmg, rvg, training)
+    y.backward(gy.to(dev))
+    xr, gr, br = (t.clone().requires_grad_() for t in (x, ga, be))
+    rm2, rv2 = rm.clone(), rv.clone()
+    yr = F.relu(F.batch_norm(xr, rm2, rv2, gr, br, training, 0.1, 1e-5))
+    yr.backward(gy)
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 5e-5
+    if training:
+        assert rel_err(gg.grad.cpu(), gr.grad) < 5e-5 and rel_err(bg.grad.cpu(), br.grad) < 5e-5
+        assert rel_err(rmg.cpu(), rm2) < 1e-5 and rel_err(rvg.cpu(), rv2) < 1e-5
+
+
+def test_maxpool_ties(dev):
+    from icl_amd import ops
+    x = torch.relu(_rand((2, 16, 24, 24, 24), 13))
+    xg = x.to(dev).requires_grad_()
+    y = ops.max_pool3d_2(xg)
+    gy = _rand(tuple(y.shape), 14)
+    y.backward(gy.to(dev))
+    xr = x.clone().requires_grad_()
+    yr = F.max_pool3d(xr, 2)
+    yr.backward(gy)
+    assert torch.equal(y.detach().cpu(), yr.detach())
+    assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("ins,outs,c", [((3, 4, 5), (6, 8, 10), 3), ((6, 6, 6), (96, 96, 96), 2), ((12, 12, 12), (96, 96, 96), 2),
+                                        ((24, 24, 24), (96, 96, 96), 2), ((24, 24, 24), (48, 48, 48), 16)])
+def test_trilinear(dev, ins, outs, c):
+    from icl_amd import ops
+    x = _rand((1, c) + ins, 15)
+    xg = x.to(dev).requires_grad_()
+    y = ops.trilinear_resize(xg, outs)
+    gy = _rand(tuple(y.shape), 16)
+    y.backward(gy.to(dev))
+    xr = x.clone().requires_grad_()
+    yr = F.interpolate(xr, size=list(outs), mode="trilinear", align_corners=False)
+    yr.backward(gy)
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-6
+    assert rel_err(xg.grad.cpu(), xr.grad) < 2e-5
+
+
+def test_upsample_concat_and_depthwise_and_dropout(dev):
+    from icl_amd import ops
+    skip, deep = _rand((2, 16, 12, 12, 12), 17), _rand((2, 32, 6, 6, 6), 18)
+    sg, dg = skip.to(dev).requires_grad_(), deep.to(dev).requires_grad_()
+    y = ops.upsample2x_concat(sg, dg)
+    gy = _rand(tuple(y.shape), 19)
+    y.backward(gy.to(dev))
+    sr, dr = skip.clone().requires_grad_(), deep.clone().requires_grad_()
+    yr = torch.cat([sr, F.interpolate(dr, scale_factor=(2, 2, 2), mode="trilinear")], 1)
+    yr.backward(gy)
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-6
+    assert rel_err(sg.grad.cpu(), sr.grad) < 1e-6 and rel_err(dg.grad.cpu(), dr.grad) < 2e-5
+    # depthwise
+    x, w = _rand((6, 4, 12, 12, 12), 20), _rand((4, 1, 3, 3, 3), 21) * 0.3
+    xg, wg = x.to(dev).requires_grad_(), w.to(dev).requires_grad_()
+    y = ops.depthwise_conv3d(xg, wg)
+    gy = _rand(tuple(y.shape), 22)
+    y.backward(gy.to(dev))
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = F.conv3d(xr, wr, None, padding=1, groups=4)
+    yr.backward(gy)
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-5 and rel_err(wg.grad.cpu(), wr.grad) < 1e-4
+    # dropout: mask statistics, scaling, and backward uses the same mask
+    x = torch.ones(1 << 20, device=dev, requires_grad=True)
+    y = ops.dropout(x, 0.3, seed=123)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.7) < 5e-3
+    assert torch.allclose(y[y != 0], torch.full_like(y[y != 0], 1 / 0.7))
+    y.sum().backward()
+    assert torch.equal(x.grad != 0, y.detach() != 0)
+
+
+def test_plain_unet3d_matches_reference_golden(dev):
+    from icl_amd.networks.unet_3D import unet_3D
+    g = load_golden("unit.npz")
+    m = unet_3D(n_classes=3, in_channels=2, device=dev)
+    assert list(m.state_dict().keys()) == list(g["unet32_keys"])
+    fill_like_reference_init(list(m.named_parameters()))
+    m.eval()
+    x = synthetic_volume((1, 2, 32, 32, 32), 16).to(dev).requires_grad_()
+    y = m(x)
+    y.backward(synthetic_volume(tuple(y.shape), 17).to(dev))
+    assert rel_err(y.detach().cpu(), g["unet32_y"]) < 1e-3
+    for k, p in m.named_parameters():
+        if k.endswith("bias") and k != "final.bias":
+            continue
+        ref = float(g["unet32_gn." + k])
+        got = float(p.grad.double().norm())
+        assert abs(got - ref) <= 5e-3 * max(ref, 1e-6), k
+    assert rel_err(m.final.weight.grad.cpu(), g["unet32_g.final.weight"]) < 1e-3
+
+
+def _parity_mode(model):
+    from icl_amd.networks.aligner import DropPath
+    from icl_amd.networks.layers import Dropout3
+    for mod in model.modules():
+        if isinstance(mod, Dropout3):
+            mod.p = 0.0
+        if isinstance(mod, DropPath):
+            mod.drop_prob = 0.0
+
+
+@pytest.mark.parametrize("nc", [2, 16])
+def test_full_icl_step_matches_reference_golden(dev, nc):
+    """BASELINE configs[1] (nc=2) and configs[4] (nc=16) shapes: 96^3, batch 1+1, the whole ICL step."""
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    g = load_golden(f"model_unet3d_icl_nc{nc}.npz")
+    model = unet_3D_icl(n_classes=nc, in_channels=1, device=dev)
+    assert list(model.state_dict().keys()) == list(g["keys"])
+    assert [k for k, _ in model.named_parameters()] == list(g["param_keys"])
+    fill_like_reference_init(list(model.named_parameters()))
+    _parity_mode(model)
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, nc).to(dev)
+    model.eval()
+    with torch.no_grad():
+        y = model(vol[:1], inference=True)
+    assert rel_err(y[:, :, ::8, ::8, ::8].cpu(), g["inf_logits_sub"]) < 1e-3
+    assert rel_err(y[:, :, 40:44, 40:56, 40:56].cpu(), g["inf_logits_slab"]) < 1e-3
+    l2 = y.double().pow(2).sum(dim=(0, 2, 3, 4)).sqrt().cpu().numpy()
+    assert np.allclose(l2, g["inf_logits_l2"], rtol=1e-4)
+    model.train()
+    cfg = ICLConfig(num_classes=nc, labeled_bs=1, w_pse=0.1 if nc == 16 else 1.0)
+    tr = ICLTrainer(model, cfg)
+    outs = model(vol[:1], vol[1:])
+    assert rel_err(outs[0].detach()[:, :, ::8, ::8, ::8].cpu(), g["final_lab_sub"]) < 1e-3
+    assert rel_err(outs[1].detach()[:, :, ::8, ::8, ::8].cpu(), g["final_unlab_sub"]) < 1e-3
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            assert rel_err(t.detach().cpu(), g[f"{name}{i}"]) < 1e-3, (name, i)
+    loss, parts = tr.compute_loss(outs, lab)
+    got = [float(parts[k]) for k in ("dice", "ce", "aux", "pse", "con")] + [float(loss)]
+    assert np.allclose(got, g["losses"], rtol=0, atol=1e-4), (got, g["losses"])
+    soft = torch.softmax(outs[0].detach(), 1)
+    for c in range(nc):
+        t = (lab == c).float()
+        p = soft[:, c]
+        sd = float((2 * (p * t).sum() + 1e-5) / ((p * p).sum() + (t * t).sum() + 1e-5))
+        assert abs(sd - float(g["soft_dice"][c])) < 1e-4
+    tr.optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    none = [k for k, p in model.named_parameters() if p.grad is None]
+    assert none == list(g["grad_none"])
+    ref = dict(zip(g["grad_norm_keys"], g["grad_norms"]))
+    bad = []
+    for k, p in model.named_parameters():
+        if p.grad is None or (k.endswith(".0.bias")):
+            continue
+        got_n = float(p.grad.double().norm())
+        if abs(got_n - ref[k]) > 1e-2 * max(ref[k], 1e-7) + 1e-9:
+            bad.append((k, got_n, ref[k]))
+    assert not bad, bad[:10]
+    assert rel_err(model.final.weight.grad.cpu(), g["grad.final.weight"]) < 1e-3
+    assert rel_err(model.sspa.guided_Q.grad.cpu(), g["grad.sspa.guided_Q"]) < 5e-3
+    tr.optimizer.step()
+    post = np.array([float(p.detach().double().norm()) for _, p in model.named_parameters()])
+    assert np.allclose(post, g["post_sgd_norms"], rtol=1e-5)
+    assert rel_err(model.final.weight.detach().cpu(), g["post_sgd.final.weight"]) < 1e-5
