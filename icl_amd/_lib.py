@@ -38,6 +38,8 @@ _SIGNATURES = {
     "icl_dwconv3_fwd": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "icl_dwconv3_wgrad": (c_int, [P, P, P, I, I, I, I, I, P]),
     "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P]),
+    "icl_loss_fwd": (c_int, [P, P, P, P, P, P, I, I, L, I, I, P]),
+    "icl_loss_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, L, I, I, P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

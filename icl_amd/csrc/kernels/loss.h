@@ -1,0 +1,195 @@
+// loss.h — fused softmax + Dice / cross-entropy / soft-Dice / MSE reductions and their gradients.
+//
+// Reference ops (/root/reference/code/utils/losses.py): DiceLoss :200-231 (+ CrossEntropyLoss at
+// train_inherent_consistent_unet_3D_BraTS.py:107 and inside AuxLoss3D :268), softmax_dice_loss/dice_loss1
+// :22-59 (PseudoSoftLoss3D), softmax_mse_loss :68-90.  The reference materialises softmax, one-hot targets
+// and per-class products as full tensors (nc passes over [B,nc,S]); here one pass reads the logits (and the
+// labels or the second logit tensor) and reduces every per-class sum at once; the backward is one more pass.
+// HBM-bound: forward 4*nc*S (+8*S labels | +4*nc*S) bytes, backward the same + 4*nc*S written.
+//
+// mode 0/1 (hard target = labels): stats = [I_c = sum p_c[y==c] | Z_c = sum p_c^2 | Y_c = count(y==c) | CE = sum(lse - a_y)]
+// mode 2/3 (soft target = softmax(b)): stats = [I_c = sum p_c q_c | A_c = sum p_c | Bq_c = sum q_c | MSE = sum (p-q)^2]
+// out[0] = CE mean (mode 1) | MSE mean (mode 3) | 0 ;  out[1] = mean_c w_c (1 - (2I+eps)/(den+eps)), den = Z+Y | A+Bq.
+#pragma once
+
+namespace icl {
+
+constexpr float kDiceEps = 1e-5f;
+
+template <int NCMAX>
+__device__ __forceinline__ void softmax_vec(float* v, int nc, float& lse) {
+  float m = v[0];
+#pragma unroll
+  for (int c = 1; c < NCMAX; ++c)
+    if (c < nc) m = fmaxf(m, v[c]);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCMAX; ++c)
+    if (c < nc) { v[c] = expf(v[c] - m); s += v[c]; }
+  const float inv = 1.0f / s;
+#pragma unroll
+  for (int c = 0; c < NCMAX; ++c)
+    if (c < nc) v[c] *= inv;
+  lse = m + logf(s);
+}
+
+// grid-stride over the B*S voxels; stats (3*nc+1 floats, pre-zeroed) accumulated with one atomic per block per slot
+template <int NCMAX>
+__global__ __launch_bounds__(256) void loss_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const long long* __restrict__ labels, float* __restrict__ stats,
+                                                         int B, int nc, long S, int a_is_prob) {
+  float s0[NCMAX], s1[NCMAX], s2[NCMAX];
+  float sx = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCMAX; ++c) { s0[c] = 0.f; s1[c] = 0.f; s2[c] = 0.f; }
+  const long total = (long)B * S;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long bi = e / S, s = e - bi * S;
+    const float* ap = a + bi * nc * S + s;
+    float p[NCMAX];
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) p[c] = c < nc ? ap[(long)c * S] : 0.f;
+    float lse = 0.f;
+    if (labels) {
+      const int y = (int)labels[e];
+      float ay = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c)
+        if (c == y) ay = p[c];
+      if (!a_is_prob) { softmax_vec<NCMAX>(p, nc, lse); sx += lse - ay; }
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c) {
+        if (c < nc) {
+          const float t = (c == y) ? 1.f : 0.f;
+          s0[c] += p[c] * t;
+          s1[c] += p[c] * p[c];
+          s2[c] += t;
+        }
+      }
+    } else {
+      const float* bp = b + bi * nc * S + s;
+      float q[NCMAX];
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c) q[c] = c < nc ? bp[(long)c * S] : 0.f;
+      float l2;
+      if (!a_is_prob) softmax_vec<NCMAX>(p, nc, lse);
+      softmax_vec<NCMAX>(q, nc, l2);
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c) {
+        if (c < nc) {
+          s0[c] += p[c] * q[c];
+          s1[c] += p[c];
+          s2[c] += q[c];
+          const float d = p[c] - q[c];
+          sx += d * d;
+        }
+      }
+    }
+  }
+  __shared__ float red[4][3 * NCMAX + 1];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < NCMAX; ++c) {
+    const float r0 = wave_sum(s0[c]), r1 = wave_sum(s1[c]), r2 = wave_sum(s2[c]);
+    if (lane == 0) { red[wid][c] = r0; red[wid][NCMAX + c] = r1; red[wid][2 * NCMAX + c] = r2; }
+  }
+  {
+    const float rx = wave_sum(sx);
+    if (lane == 0) red[wid][3 * NCMAX] = rx;
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < 3 * NCMAX + 1) {
+    const int grp = t / NCMAX, c = t - grp * NCMAX;
+    if (t == 3 * NCMAX || c < nc) {
+      const float v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+      const int slot = (t == 3 * NCMAX) ? 3 * nc : grp * nc + c;
+      atomicAdd(stats + slot, v);
+    }
+  }
+}
+
+// out[0], out[1] from stats (one thread).  weight may be NULL.
+__global__ void loss_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ weight, float* __restrict__ out,
+                                     int nc, float inv_vox, float inv_elems, int mode) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  float dice = 0.f;
+  for (int c = 0; c < nc; ++c) {
+    const float num = 2.f * stats[c] + kDiceEps;
+    const float den = stats[nc + c] + stats[2 * nc + c] + kDiceEps;
+    dice += (weight ? weight[c] : 1.f) * (1.f - num / den);
+  }
+  out[1] = (mode == 3) ? 0.f : dice / (float)nc;
+  out[0] = (mode == 1) ? stats[3 * nc] * inv_vox : (mode == 3 ? stats[3 * nc] * inv_elems : 0.f);
+}
+
+// coef = [alpha_c | beta_c | gamma_c | kappa]:  dL/dp_c(v) = alpha_c*T_c(v) + beta_c*p_c(v) + gamma_c, T = one-hot | q;
+// kappa scales the cross-entropy logit gradient (p - t).  g = upstream grads of (out[0], out[1]).
+__global__ void loss_coef_kernel(const float* __restrict__ stats, const float* __restrict__ weight, const float* __restrict__ g,
+                                 float* __restrict__ coef, int nc, float inv_vox, float inv_elems, int mode) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const float g0 = g[0], g1 = g[1];
+  for (int c = 0; c < nc; ++c) {
+    const float num = 2.f * stats[c] + kDiceEps;
+    const float den = stats[nc + c] + stats[2 * nc + c] + kDiceEps;
+    const float w = (weight ? weight[c] : 1.f) * g1 / (float)nc;
+    float al = 0.f, be = 0.f, ga = 0.f;
+    if (mode == 0 || mode == 1) { al = -2.f * w / den; be = 2.f * w * num / (den * den); }
+    else if (mode == 2) { al = -2.f * w / den; ga = w * num / (den * den); }
+    else { al = -2.f * g0 * inv_elems; be = 2.f * g0 * inv_elems; }
+    coef[c] = al; coef[nc + c] = be; coef[2 * nc + c] = ga;
+  }
+  coef[3 * nc] = (mode == 1) ? g0 * inv_vox : 0.f;
+}
+
+template <int NCMAX>
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const long long* __restrict__ labels, const float* __restrict__ coef,
+                                                        float* __restrict__ ga, int B, int nc, long S, int a_is_prob) {
+  float al[NCMAX], be[NCMAX], gm[NCMAX];
+#pragma unroll
+  for (int c = 0; c < NCMAX; ++c) {
+    al[c] = c < nc ? coef[c] : 0.f;
+    be[c] = c < nc ? coef[nc + c] : 0.f;
+    gm[c] = c < nc ? coef[2 * nc + c] : 0.f;
+  }
+  const float kappa = coef[3 * nc];
+  const long total = (long)B * S;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long bi = e / S, s = e - bi * S;
+    const float* ap = a + bi * nc * S + s;
+    float* gp = ga + bi * nc * S + s;
+    float p[NCMAX], T[NCMAX];
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) p[c] = c < nc ? ap[(long)c * S] : 0.f;
+    float lse;
+    if (!a_is_prob) softmax_vec<NCMAX>(p, nc, lse);
+    if (labels) {
+      const int y = (int)labels[e];
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c) T[c] = (c == y) ? 1.f : 0.f;
+    } else {
+      const float* bp = b + bi * nc * S + s;
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c) T[c] = c < nc ? bp[(long)c * S] : 0.f;
+      softmax_vec<NCMAX>(T, nc, lse);
+    }
+    float d[NCMAX];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) {
+      d[c] = c < nc ? al[c] * T[c] + be[c] * p[c] + gm[c] : 0.f;
+      dot += d[c] * p[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) {
+      if (c < nc) {
+        float gv = a_is_prob ? d[c] : p[c] * (d[c] - dot);
+        if (labels) gv += kappa * (p[c] - T[c]);
+        gp[(long)c * S] = gv;
+      }
+    }
+  }
+}
+
+}  // namespace icl

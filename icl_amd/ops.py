@@ -448,42 +448,80 @@ def prototype_attention(qh: torch.Tensor, kv: torch.Tensor, heads: int, scale: f
 
 
 # --------------------------------------------------------------------------------------
-# Loss reductions (utils/losses.py L1-L5).  STOP-GAP torch expressions on the device until the fused
-# softmax+Dice/CE/MSE reduction kernels land.
+# Loss reductions (utils/losses.py L1-L5): one fused HIP pass per loss term, one more for its gradient
 # --------------------------------------------------------------------------------------
+
+class _FusedLoss(torch.autograd.Function):
+    """out = [term0, term1] per icl_loss_fwd's mode table (include/icl_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, a, target, weight, mode, a_is_prob):
+        _require(a, target, weight)
+        L = _lib.lib()
+        a = a.contiguous()
+        target = target.contiguous()
+        B, nc = a.shape[0], a.shape[1]
+        S = a.numel() // (B * nc)
+        hard = mode <= 1
+        if hard:
+            assert target.dtype == torch.int64 and target.numel() == B * S, "labels must be int64 [B, ...]"
+        else:
+            assert target.shape == a.shape and target.dtype == torch.float32
+        stats = torch.empty(3 * nc + 1, dtype=torch.float32, device=a.device)
+        out = torch.empty(2, dtype=torch.float32, device=a.device)
+        _lib.check(L.icl_loss_fwd(_ptr(a), None if hard else _ptr(target), _ptr(target) if hard else None, _ptr(weight),
+                                  _ptr(stats), _ptr(out), B, nc, S, mode, int(a_is_prob), _stream(a)), "loss_fwd")
+        ctx.save_for_backward(a, target, stats, weight)
+        ctx.cfg = (mode, int(a_is_prob))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, target, stats, weight = ctx.saved_tensors
+        mode, aip = ctx.cfg
+        L = _lib.lib()
+        B, nc = a.shape[0], a.shape[1]
+        S = a.numel() // (B * nc)
+        hard = mode <= 1
+        gout = gout.contiguous()
+        coef = torch.empty(3 * nc + 1, dtype=torch.float32, device=a.device)
+        ga = torch.empty_like(a)
+        _lib.check(L.icl_loss_bwd(_ptr(a), None if hard else _ptr(target), _ptr(target) if hard else None, _ptr(weight),
+                                  _ptr(stats), _ptr(gout), _ptr(coef), _ptr(ga), B, nc, S, mode, aip, _stream(a)), "loss_bwd")
+        return ga, None, None, None, None
+
+
+def _weight_tensor(weight, like):
+    if weight is None:
+        return None
+    return torch.as_tensor(weight, dtype=torch.float32, device=like.device)
+
 
 def dice_loss(inputs: torch.Tensor, labels: torch.Tensor, n_classes: int, softmax: bool = False, weight=None):
     """DiceLoss.forward (losses.py:218-231); labels [B, ...] integer class ids."""
-    p = torch.softmax(inputs, dim=1) if softmax else inputs
-    B = p.shape[0]
-    pf = p.reshape(B, n_classes, -1)
-    lab = labels.reshape(B, 1, -1)
-    cls = torch.arange(n_classes, device=p.device, dtype=lab.dtype).view(1, n_classes, 1)
-    t = (lab == cls).to(p.dtype)
-    inter = (pf * t).sum(dim=(0, 2))
-    z = (pf * pf).sum(dim=(0, 2))
-    y = t.sum(dim=(0, 2))
-    dice = 1 - (2 * inter + 1e-5) / (z + y + 1e-5)
-    if weight is not None:
-        dice = dice * torch.as_tensor(weight, device=p.device, dtype=p.dtype)
-    return dice.sum() / n_classes
+    assert inputs.shape[1] == n_classes
+    return _FusedLoss.apply(inputs, labels.long(), _weight_tensor(weight, inputs), 0, not softmax)[1]
+
+
+def cross_entropy_dice_parts(logits: torch.Tensor, labels: torch.Tensor, n_classes: int):
+    """(CrossEntropyLoss()(logits, labels), DiceLoss(softmax=True)(logits, labels)) from ONE pass over the logits."""
+    assert logits.shape[1] == n_classes
+    out = _FusedLoss.apply(logits, labels.long(), None, 1, False)
+    return out[0], out[1]
 
 
 def cross_entropy_dice(logits: torch.Tensor, labels: torch.Tensor, n_classes: int):
-    """CE(logits, labels) + DiceLoss(softmax=True)(logits, labels) — one AuxLoss3D term (losses.py:268-269)."""
-    return torch.nn.functional.cross_entropy(logits, labels) + dice_loss(logits, labels, n_classes, softmax=True)
+    """CE + Dice(softmax=True) — one AuxLoss3D term (losses.py:268-269)."""
+    ce, dc = cross_entropy_dice_parts(logits, labels, n_classes)
+    return ce + dc
 
 
 def soft_dice_loss(a: torch.Tensor, b: torch.Tensor):
-    """softmax_dice_loss (losses.py:42-59): per class 1-(2*sum(sa*sb)+eps)/(sum(sa)+sum(sb)+eps), mean over classes."""
-    n = a.shape[1]
-    sa = torch.softmax(a, dim=1).transpose(0, 1).reshape(n, -1)
-    sb = torch.softmax(b, dim=1).transpose(0, 1).reshape(n, -1)
-    inter = (sa * sb).sum(dim=1)
-    d = 1 - (2 * inter + 1e-5) / (sa.sum(dim=1) + sb.sum(dim=1) + 1e-5)
-    return d.sum() / n
+    """softmax_dice_loss (losses.py:42-59): per class 1-(2*sum(sa*sb)+eps)/(sum(sa)+sum(sb)+eps), mean over classes.
+    Gradient flows to ``a`` only (the reference detaches the target, losses.py:294)."""
+    return _FusedLoss.apply(a, b.detach(), None, 2, False)[1]
 
 
 def softmax_mse(a: torch.Tensor, b: torch.Tensor):
-    """mean((softmax(a,1) - softmax(b,1))^2) — one scale of softmax_mse_loss (losses.py:82-87)."""
-    return torch.mean((torch.softmax(a, dim=1) - torch.softmax(b, dim=1)) ** 2)
+    """mean((softmax(a,1) - softmax(b,1))^2) — one scale of softmax_mse_loss (losses.py:82-87); target detached."""
+    return _FusedLoss.apply(a, b.detach(), None, 3, False)[0]

@@ -18,6 +18,7 @@ from typing import Dict, Optional
 import torch
 from torch.nn.modules.loss import CrossEntropyLoss
 
+from . import ops
 from .utils import losses as L
 
 
@@ -48,9 +49,8 @@ class ICLTrainer:
     def compute_loss(self, outputs, label_batch):
         cfg = self.cfg
         lab = label_batch[:cfg.labeled_bs]
-        outputs_soft = torch.softmax(outputs[0], dim=1)
-        loss_ce = self.ce_loss(outputs[0], lab)
-        loss_dice = self.dice_loss(outputs_soft, lab.unsqueeze(1))
+        # CrossEntropyLoss()(out0, y) and DiceLoss(softmax(out0), y) (…BraTS.py:105-108) from one fused pass
+        loss_ce, loss_dice = ops.cross_entropy_dice_parts(outputs[0], lab, cfg.num_classes)
         loss_aux = self.aux_loss(outputs[2], lab)
         loss_pse = self.pse_loss(outputs[3], outputs[1])
         loss_con = L.softmax_mse_loss(outputs[3], outputs[4])

@@ -74,6 +74,19 @@ int icl_dwconv3_wgrad(const float* x, const float* gy, float* gw, int n, int c, 
  * mask keyed by (seed, element index); calling it again with the same seed on dY is the backward. */
 int icl_dropout(const float* x, float* y, int64_t n, uint32_t seed, float p, void* stream);
 
+/* ---- fused softmax + Dice / CE / soft-Dice / MSE reductions (utils/losses.py:22-59,68-90,200-231 and the
+ * CrossEntropyLoss at train_inherent_consistent_unet_3D_BraTS.py:107).  a is [B,nc,S] logits (or probabilities when
+ * a_is_prob); the target is int64 labels [B,S] (modes 0,1) or a second logit tensor b [B,nc,S] (modes 2,3):
+ *   mode 0 hard Dice        out = {0, dice}          mode 1 CE + hard Dice   out = {ce, dice}
+ *   mode 2 soft Dice        out = {0, dice}          mode 3 softmax MSE      out = {mse, 0}
+ * stats: 3*nc+1 floats (kept for backward); coef: 3*nc+1 floats scratch; gout: upstream grads of out[0], out[1];
+ * ga: gradient w.r.t. a.  weight (per-class Dice weights) may be NULL.  nc <= 16. */
+int icl_loss_fwd(const float* a, const float* b, const int64_t* labels, const float* weight, float* stats, float* out,
+                 int batch, int nc, int64_t s, int mode, int a_is_prob, void* stream);
+int icl_loss_bwd(const float* a, const float* b, const int64_t* labels, const float* weight, const float* stats,
+                 const float* gout, float* coef, float* ga, int batch, int nc, int64_t s, int mode, int a_is_prob,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

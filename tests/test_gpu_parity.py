@@ -224,7 +224,9 @@ def test_full_icl_step_matches_reference_golden(dev, nc):
     ref = dict(zip(g["grad_norm_keys"], g["grad_norms"]))
     bad = []
     for k, p in model.named_parameters():
-        if p.grad is None or (k.endswith(".0.bias")):
+        # conv biases that feed an InstanceNorm (".0.bias") or a softmax over classes (attn_convs1.*.bias)
+        # have an exactly-zero true gradient: both sides hold rounding noise only
+        if p.grad is None or k.endswith(".0.bias") or ("attn_convs1" in k and k.endswith("bias")):
             continue
         got_n = float(p.grad.double().norm())
         if abs(got_n - ref[k]) > 1e-2 * max(ref[k], 1e-7) + 1e-9:

@@ -129,3 +129,71 @@ def test_upsample_concat():
     assert rel_err(y.detach(), yr.detach()) < 1e-6
     assert rel_err(skip.grad, sr.grad) < 1e-6
     assert rel_err(deep.grad, dr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("nc", [2, 3, 16])
+def test_fused_losses(nc):
+    from icl_amd.utils.hashfill import synthetic_labels
+    B, S = 2, (6, 5, 7)
+    lab = synthetic_labels((B,) + S, 31, nc)
+    a = (_rand((B, nc) + S, 32) * 2).requires_grad_()
+    ar = a.detach().clone().requires_grad_()
+    # CE + hard dice from logits
+    ce, dc = ops.cross_entropy_dice_parts(a, lab, nc)
+    (1.3 * ce + 0.7 * dc).backward()
+    pr = torch.softmax(ar, 1)
+    dr = 0
+    for c in range(nc):
+        t = (lab == c).float()
+        dr = dr + (1 - (2 * (pr[:, c] * t).sum() + 1e-5) / ((pr[:, c] ** 2).sum() + t.sum() + 1e-5))
+    dr = dr / nc
+    cr = F.cross_entropy(ar, lab)
+    (1.3 * cr + 0.7 * dr).backward()
+    assert abs(float(ce) - float(cr)) < 1e-5 and abs(float(dc) - float(dr)) < 1e-5
+    assert rel_err(a.grad, ar.grad) < 1e-4
+    # hard dice on probabilities with class weights
+    w = [0.5 + 0.1 * i for i in range(nc)]
+    p = torch.softmax(_rand((B, nc) + S, 33), 1).requires_grad_()
+    prr = p.detach().clone().requires_grad_()
+    d = ops.dice_loss(p, lab, nc, softmax=False, weight=w)
+    d.backward()
+    drr = 0
+    for c in range(nc):
+        t = (lab == c).float()
+        drr = drr + w[c] * (1 - (2 * (prr[:, c] * t).sum() + 1e-5) / ((prr[:, c] ** 2).sum() + t.sum() + 1e-5))
+    drr = drr / nc
+    drr.backward()
+    assert abs(float(d) - float(drr)) < 1e-5 and rel_err(p.grad, prr.grad) < 1e-4
+    # soft dice and softmax-MSE against a second logit tensor
+    b = _rand((B, nc) + S, 34) * 2
+    a2 = (_rand((B, nc) + S, 35) * 2).requires_grad_()
+    a2r = a2.detach().clone().requires_grad_()
+    sd, ms = ops.soft_dice_loss(a2, b), ops.softmax_mse(a2, b)
+    (sd + 10 * ms).backward()
+    sa, sb = torch.softmax(a2r, 1), torch.softmax(b, 1)
+    sdr = 0
+    for c in range(nc):
+        sdr = sdr + (1 - (2 * (sa[:, c] * sb[:, c]).sum() + 1e-5) / (sa[:, c].sum() + sb[:, c].sum() + 1e-5))
+    sdr = sdr / nc
+    msr = ((sa - sb) ** 2).mean()
+    (sdr + 10 * msr).backward()
+    assert abs(float(sd) - float(sdr)) < 1e-5 and abs(float(ms) - float(msr)) < 1e-6
+    assert rel_err(a2.grad, a2r.grad) < 1e-4
+
+
+def test_depthwise_and_dropout():
+    x = _rand((3, 4, 5, 6, 7), 41, True)
+    w = (_rand((4, 1, 3, 3, 3), 42) * 0.3).requires_grad_()
+    y = ops.depthwise_conv3d(x, w)
+    gy = _rand(tuple(y.shape), 43)
+    y.backward(gy)
+    xr, wr = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    yr = F.conv3d(xr, wr, None, padding=1, groups=4)
+    yr.backward(gy)
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    assert rel_err(x.grad, xr.grad) < 1e-5 and rel_err(w.grad, wr.grad) < 1e-5
+    xo = torch.ones(1 << 14, requires_grad=True)
+    yo = ops.dropout(xo, 0.3, seed=7)
+    assert abs((yo != 0).float().mean().item() - 0.7) < 0.03
+    yo.sum().backward()
+    assert torch.equal(xo.grad != 0, yo.detach() != 0)
