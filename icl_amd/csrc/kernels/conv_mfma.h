@@ -10,14 +10,19 @@
 // pack_weights_kernel into Wp[tap][CinP][CoutP] (CinP % 4 == 0, CoutP % 16 == 0, zero padded):
 //   forward : Wp[tap][ci][co]       = W[co][ci][tap]
 //   dgrad   : Wp[T-1-tap][co][ci]   = W[co][ci][tap]   (dX = conv(dY, flipped/transposed W): same kernel)
-// so weight staging is a coalesced row copy and the MFMA B operand is bank-conflict free.
+// so weight staging is a coalesced 16-B row copy and the MFMA B operand is bank-conflict free.
 //
-// forward / dgrad kernel (one workgroup = one TZxTYxTX output tile x NB output channels):
+// forward / dgrad kernel (one workgroup = one TZxTYxTX output tile x NB output channels x a Cin split):
 //   GEMM view  M = voxels (16 consecutive tile voxels per MFMA), N = Cout (16 per MFMA),
 //              K = taps x Cin, walked tap-major in steps of 4 input channels.
 //   A[v][k]  = Xs[cin plane k][voxel v + tap offset]   (input halo tile staged in LDS, zero filled)
 //   B[k][n]  = Ws[tap*KC + k][n]
 //   LDS plane stride PS == 16 (mod 32): lanes 0-15 (voxels) and 16-31 (next cin plane) hit disjoint banks.
+//   Staging: with W % 4 == 0 every LDS row holds the 16-B aligned span [x0-4, x0+TX+4) so global loads and
+//   LDS stores are 16 B per lane; each thread's (global offset, LDS offset) pairs are computed once and reused
+//   for every Cin chunk, and the loads of chunk i+1 are issued into registers before the MFMAs of chunk i.
+//   ksplit > 1 spreads the Cin chunks of one output tile over several workgroups (fp32 atomics into a zeroed
+//   output): the 6^3..24^3 layers have too few tiles to fill 256 CUs otherwise.
 // wgrad kernel (one workgroup = 16 output channels x 16 input channels x all taps, loops over tiles):
 //   GEMM view  M = Cout (16), N = Cin (16) per tap, K = voxels in steps of 4 consecutive x.
 //   A[co][v] = Gs[co][v] (dY tile, zero where outside the volume), B[v][ci] = Xs[ci][v + tap offset]
@@ -34,8 +39,12 @@ struct ConvGeom {
   int D, H, W;
   int TZ, TY, TX;  // output tile
   int ntz, nty, ntx;
-  int KC;  // input channels per LDS chunk (multiple of 4)
-  int PS;  // LDS plane stride in floats
+  int KC;      // input channels per LDS chunk (multiple of 4, divides CinP)
+  int PS;      // LDS plane stride in floats
+  int PXL;     // LDS row pitch in floats
+  int HX;      // x halo staged on each side of a row (4 for vector staging of a 3^3 conv, else PAD)
+  int CPP;     // channels covered by one staging pass of the workgroup
+  int ksplit;  // Cin-chunk split across workgroups
   long x_bstride, y_bstride;  // batch strides in elements (channel stride is D*H*W)
 };
 
@@ -70,41 +79,142 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
   }
 }
 
-// Stage the zero-filled input halo tile of channels [c0, c0+KC) into Xs[c][PS]; rows are (c,pz,py), 32 lanes per row.
-template <int KS, int NT>
-__device__ __forceinline__ void stage_halo(float* Xs, const float* __restrict__ xb, int c0, const ConvGeom& g, int z0, int y0, int x0) {
-  constexpr int PAD = KS / 2;
-  const int PZ = g.TZ + KS - 1, PY = g.TY + KS - 1, PX = g.TX + KS - 1;
-  const int rows = g.KC * PZ * PY;
-  const int px = threadIdx.x & 31;
-  const int gx = x0 - PAD + px;
-  const bool xok = (px < PX) && gx >= 0 && gx < g.W;
-  const long HW = (long)g.H * g.W;
-  for (int rr = threadIdx.x >> 5; rr < rows; rr += NT / 32) {
-    const int c = rr / (PZ * PY);
-    const int rem = rr - c * (PZ * PY);
-    const int pz = rem / PY, py = rem - pz * PY;
-    const int gz = z0 - PAD + pz, gy = y0 - PAD + py;
-    float v = 0.f;
-    if (xok && (c0 + c) < g.Cin && gz >= 0 && gz < g.D && gy >= 0 && gy < g.H)
-      v = xb[(long)(c0 + c) * g.D * HW + gz * HW + (long)gy * g.W + gx];
-    if (px < PX) Xs[c * g.PS + (pz * PY + py) * PX + px] = v;
+// ---------------------------------------------------------------------------------------------------------
+// Input halo staging.  One "pass" of the workgroup covers CPP channels x PZ x PY rows x Q items per row
+// (Q = PXL/4 float4 when VEC, PXL scalars otherwise).  A thread owns up to JXMAX items of a pass; their
+// (global offset, LDS offset, channel, in-bounds) are pass-invariant and computed once per tile.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kJX = 4;   // max items per thread per pass
+constexpr int kNP = 4;   // max passes per chunk (KC / CPP)
+
+template <int KS, int NT, bool VEC>
+struct HaloStager {
+  int goff[kJX];   // element offset inside the chunk's first channel group; -1 = out of the volume / no item
+  int loff[kJX];
+  int chan[kJX];
+
+  __device__ __forceinline__ void setup(const ConvGeom& g, int z0, int y0, int x0) {
+    constexpr int PAD = KS / 2;
+    constexpr int E = VEC ? 4 : 1;
+    const int PZ = g.TZ + KS - 1, PY = g.TY + KS - 1;
+    const int Q = g.PXL / E;
+    const int IP = g.CPP * PZ * PY * Q;
+    const long HW = (long)g.H * g.W;
+#pragma unroll
+    for (int j = 0; j < kJX; ++j) {
+      const int it = threadIdx.x + j * NT;
+      goff[j] = -1; loff[j] = -1; chan[j] = 0;
+      if (it < IP) {
+        const int q = it % Q;
+        int r = it / Q;
+        const int py = r % PY;
+        r /= PY;
+        const int pz = r % PZ;
+        const int c = r / PZ;
+        const int gx = x0 - g.HX + q * E, gy = y0 - PAD + py, gz = z0 - PAD + pz;
+        chan[j] = c;
+        loff[j] = c * g.PS + (pz * PY + py) * g.PXL + q * E;
+        const bool ok = gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx + (E - 1) < g.W;
+        if (ok) goff[j] = (int)((long)c * g.D * HW + gz * HW + (long)gy * g.W + gx);
+      }
+    }
+  }
+};
+
+template <bool VEC> struct StageVal { float v[VEC ? 4 : 1]; };
+
+template <int KS, int NT, bool VEC>
+__device__ __forceinline__ void halo_load(const HaloStager<KS, NT, VEC>& st, StageVal<VEC> (&val)[kNP][kJX],
+                                          const float* __restrict__ xb, int c0, const ConvGeom& g) {
+  const long DHW = (long)g.D * g.H * g.W;
+  const int np = g.KC / g.CPP;
+#pragma unroll
+  for (int p = 0; p < kNP; ++p) {
+#pragma unroll
+    for (int j = 0; j < kJX; ++j) {
+      if (VEC) { val[p][j].v[0] = 0.f; val[p][j].v[1] = 0.f; val[p][j].v[2] = 0.f; val[p][j].v[3] = 0.f; }
+      else val[p][j].v[0] = 0.f;
+      if (p < np && st.goff[j] >= 0 && (c0 + p * g.CPP + st.chan[j]) < g.Cin) {
+        const float* src = xb + (long)(c0 + p * g.CPP) * DHW + st.goff[j];
+        if (VEC) {
+          const float4 t = *reinterpret_cast<const float4*>(src);
+          val[p][j].v[0] = t.x; val[p][j].v[1] = t.y; val[p][j].v[2] = t.z; val[p][j].v[3] = t.w;
+        } else {
+          val[p][j].v[0] = *src;
+        }
+      }
+    }
   }
 }
 
-template <int KS, int NBT, int MV, int WAVES>
+template <int KS, int NT, bool VEC>
+__device__ __forceinline__ void halo_store(const HaloStager<KS, NT, VEC>& st, const StageVal<VEC> (&val)[kNP][kJX], float* Xs,
+                                           const ConvGeom& g) {
+  const int np = g.KC / g.CPP;
+#pragma unroll
+  for (int p = 0; p < kNP; ++p) {
+#pragma unroll
+    for (int j = 0; j < kJX; ++j) {
+      if (p < np && st.loff[j] >= 0) {
+        float* dst = Xs + p * g.CPP * g.PS + st.loff[j];
+        if (VEC) *reinterpret_cast<float4*>(dst) = make_float4(val[p][j].v[0], val[p][j].v[1], val[p][j].v[2], val[p][j].v[3]);
+        else *dst = val[p][j].v[0];
+      }
+    }
+  }
+}
+
+// Packed-weight staging: rows (tap, c) of NB floats, 16 B per item.
+constexpr int kWX = 7;  // max float4 items per thread per chunk
+
+template <int T, int NB, int NBP, int NT>
+struct WeightStager {
+  int goff[kWX];
+  int loff[kWX];
+  __device__ __forceinline__ void setup(const ConvGeom& g, int n0) {
+    const int total = T * g.KC * (NB / 4);
+#pragma unroll
+    for (int i = 0; i < kWX; ++i) {
+      const int it = threadIdx.x + i * NT;
+      goff[i] = -1; loff[i] = -1;
+      if (it < total) {
+        const int n4 = it % (NB / 4), row = it / (NB / 4);
+        const int tap = row / g.KC, c = row - tap * g.KC;
+        loff[i] = row * NBP + n4 * 4;
+        if (n0 + n4 * 4 < g.CoutP) goff[i] = (tap * g.CinP + c) * g.CoutP + n0 + n4 * 4;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(float4 (&val)[kWX], const float* __restrict__ wp, int c0, const ConvGeom& g) const {
+#pragma unroll
+    for (int i = 0; i < kWX; ++i) {
+      val[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (goff[i] >= 0) val[i] = *reinterpret_cast<const float4*>(wp + (long)c0 * g.CoutP + goff[i]);
+    }
+  }
+  __device__ __forceinline__ void store(const float4 (&val)[kWX], float* Ws) const {
+#pragma unroll
+    for (int i = 0; i < kWX; ++i)
+      if (loff[i] >= 0) *reinterpret_cast<float4*>(Ws + loff[i]) = val[i];
+  }
+};
+
+template <int KS, int NBT, int MV, int WAVES, bool VEC>
 __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                      const float* __restrict__ bias, float* __restrict__ y,
                                                                      ConvGeom g) {
   constexpr int T = KS * KS * KS;
+  constexpr int PAD = KS / 2;
   constexpr int NB = NBT * 16;
-  constexpr int NBP = NB + (NB > 16 ? 16 : 0);
+  constexpr int NBP = NB + (NB == 32 ? 16 : 0) + (NB == 48 ? 32 : 0);  // 16, 48, 80: == 16 (mod 32)
   constexpr int NT = WAVES * 64;
   ICL_DYN_LDS(float, lds);
   float* Xs = lds;
   float* Ws = lds + g.KC * g.PS;
-  const int PY = g.TY + KS - 1, PX = g.TX + KS - 1;
-  const int bt = blockIdx.x;
+  const int PY = g.TY + KS - 1;
+  const int ntiles = g.ntx * g.nty * g.ntz;
+  const int bt = blockIdx.x % ntiles;
+  const int ks = blockIdx.x / ntiles;
   const int x0 = (bt % g.ntx) * g.TX;
   const int y0 = ((bt / g.ntx) % g.nty) * g.TY;
   const int z0 = (bt / (g.ntx * g.nty)) * g.TZ;
@@ -123,7 +233,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_fwd_kernel(const float
     if (vt >= MT) vt = MT - 1;
     const int tx = vt % g.TX, t2 = vt / g.TX;
     const int ty = t2 % g.TY, tz = t2 / g.TY;
-    vbase[m] = (tz * PY + ty) * PX + tx + lq * g.PS;
+    vbase[m] = (tz * PY + ty) * g.PXL + tx + (g.HX - PAD) + lq * g.PS;
   }
   f32x4 acc[MV][NBT];
 #pragma unroll
@@ -131,23 +241,31 @@ __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_fwd_kernel(const float
 #pragma unroll
     for (int j = 0; j < NBT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int c0 = 0; c0 < g.CinP; c0 += g.KC) {
+  HaloStager<KS, NT, VEC> hs;
+  hs.setup(g, z0, y0, x0);
+  WeightStager<T, NB, NBP, NT> wst;
+  wst.setup(g, n0);
+  StageVal<VEC> xv[kNP][kJX];
+  float4 wv[kWX];
+
+  const int nchunks = g.CinP / g.KC;
+  int ci = ks;
+  if (ci < nchunks) {
+    halo_load<KS, NT, VEC>(hs, xv, xb, ci * g.KC, g);
+    wst.load(wv, wp, ci * g.KC, g);
+  }
+  for (; ci < nchunks; ci += g.ksplit) {
+    __syncthreads();  // every wave is done reading the previous chunk
+    halo_store<KS, NT, VEC>(hs, xv, Xs, g);
+    wst.store(wv, Ws);
     __syncthreads();
-    stage_halo<KS, NT>(Xs, xb, c0, g, z0, y0, x0);
-    {
-      const int total = T * g.KC * NB;
-      for (int e = threadIdx.x; e < total; e += NT) {
-        const int n = e % NB, row = e / NB;
-        const int tap = row / g.KC, c = row - tap * g.KC;
-        float v = 0.f;
-        if (n0 + n < g.CoutP && c0 + c < g.CinP) v = wp[((long)tap * g.CinP + c0 + c) * g.CoutP + n0 + n];
-        Ws[row * NBP + n] = v;
-      }
+    if (ci + g.ksplit < nchunks) {  // prefetch the next chunk into registers; it lands while the MFMAs run
+      halo_load<KS, NT, VEC>(hs, xv, xb, (ci + g.ksplit) * g.KC, g);
+      wst.load(wv, wp, (ci + g.ksplit) * g.KC, g);
     }
-    __syncthreads();
     for (int tap = 0; tap < T; ++tap) {
       const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-      const int tapoff = (dz * PY + dy) * PX + dx;
+      const int tapoff = (dz * PY + dy) * g.PXL + dx;
       for (int cc = 0; cc < g.KC; cc += 4) {
         const int krow = tap * g.KC + cc + lq;
         float b[NBT];
@@ -164,12 +282,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_fwd_kernel(const float
   }
 
   // epilogue: lane holds, per (m, j), rows vt = group*16 + lq*4 + r (r = 0..3) of column co = n0 + j*16 + lr
-  const bool vec = ((g.TX & 3) == 0) && ((g.W & 3) == 0);
+  const bool vec = ((g.TX & 3) == 0) && ((g.W & 3) == 0) && g.ksplit == 1;
+  const bool atomic = g.ksplit > 1;
 #pragma unroll
   for (int j = 0; j < NBT; ++j) {
     const int co = n0 + j * 16 + lr;
     if (co >= g.Cout) continue;
-    const float bv = bias ? bias[co] : 0.f;
+    const float bv = (bias && ks == 0) ? bias[co] : 0.f;
     float* yc = yb + (long)co * DHW;
 #pragma unroll
     for (int m = 0; m < MV; ++m) {
@@ -191,7 +310,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_fwd_kernel(const float
           const int tx = vt % g.TX, t2 = vt / g.TX;
           const int ty = t2 % g.TY, tz = t2 / g.TY;
           const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
-          if (gz < g.D && gy < g.H && gx < g.W) yc[gz * HW + (long)gy * g.W + gx] = acc[m][j][r] + bv;
+          if (gz < g.D && gy < g.H && gx < g.W) {
+            float* dst = yc + gz * HW + (long)gy * g.W + gx;
+            if (atomic) atomicAdd(dst, acc[m][j][r] + bv);
+            else *dst = acc[m][j][r] + bv;
+          }
         }
       }
     }
@@ -199,16 +322,18 @@ __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_fwd_kernel(const float
 }
 
 // dW partials: grid.x = spatial split, grid.y = (CoutP/16) * ceil(CinP/16), grid.z = batch.
-// Requires TX % 4 == 0 and KC == 16.  Gs pitch MTP and plane stride PS are == 2 (mod 32).
-template <int KS, int NTW, int WAVES>
+// Requires TX % 4 == 0 and KC == 16.  Gs pitch MTP and plane stride PS are == 2 (mod 32) in the scalar layout;
+// with VEC staging PS is a multiple of 4 with PS/2 odd... see host: PS == 4*odd keeps 2-way conflicts at most.
+template <int KS, int NTW, int WAVES, bool VEC>
 __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                        float* __restrict__ gwp, ConvGeom g, int MTP) {
   constexpr int T = KS * KS * KS;
+  constexpr int PAD = KS / 2;
   constexpr int NT = WAVES * 64;
   ICL_DYN_LDS(float, lds);
   float* Xs = lds;                // [16][PS]
   float* Gs = lds + 16 * g.PS;    // [16][MTP]
-  const int PY = g.TY + KS - 1, PX = g.TX + KS - 1;
+  const int PY = g.TY + KS - 1;
   const int ncin = (g.CinP + 15) / 16;
   const int co0 = (blockIdx.y / ncin) * 16;
   const int c0 = (blockIdx.y % ncin) * 16;
@@ -223,41 +348,87 @@ __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_wgrad_kernel(const flo
   int tapoff[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
-    const int tap = wid + t * WAVES;
+    const int tap = (T >= WAVES) ? wid + t * WAVES : 0;
     const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-    tapoff[t] = (dz * PY + dy) * PX + dx;
+    tapoff[t] = (dz * PY + dy) * g.PXL + dx + (g.HX - PAD);
   }
   f32x4 acc[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  HaloStager<KS, NT, VEC> hs;
+  StageVal<VEC> xv[kNP][kJX];
+  // dY tile items: 16 channels x MT/E elements; up to 4 per thread (MT <= 256 when VEC, checked on the host)
+  constexpr int E = VEC ? 4 : 1;
+  constexpr int kGX = VEC ? 4 : 16;
+
   for (int bt = blockIdx.x; bt < ntiles; bt += gridDim.x) {
     const int x0 = (bt % g.ntx) * g.TX;
     const int y0 = ((bt / g.ntx) % g.nty) * g.TY;
     const int z0 = (bt / (g.ntx * g.nty)) * g.TZ;
-    __syncthreads();
-    stage_halo<KS, NT>(Xs, xb, c0, g, z0, y0, x0);
-    for (int e = threadIdx.x; e < 16 * MT; e += NT) {
-      const int vt = e % MT, co = e / MT;
-      const int tx = vt % g.TX, t2 = vt / g.TX;
-      const int ty = t2 % g.TY, tz = t2 / g.TY;
-      const int gz = z0 + tz, gyy = y0 + ty, gx = x0 + tx;
-      float v = 0.f;
-      if (co0 + co < g.Cout && gz < g.D && gyy < g.H && gx < g.W) v = gb[(long)(co0 + co) * DHW + gz * HW + (long)gyy * g.W + gx];
-      Gs[co * MTP + vt] = v;
+    hs.setup(g, z0, y0, x0);
+    halo_load<KS, NT, VEC>(hs, xv, xb, c0, g);
+    StageVal<VEC> gv[kGX];
+    int gl[kGX];
+#pragma unroll
+    for (int i = 0; i < kGX; ++i) {
+      const int it = threadIdx.x + i * NT;
+      gl[i] = -1;
+      if (VEC) { gv[i].v[0] = 0.f; gv[i].v[1] = 0.f; gv[i].v[2] = 0.f; gv[i].v[3] = 0.f; }
+      else gv[i].v[0] = 0.f;
+      if (it < 16 * (MT / E)) {
+        const int vt = (it % (MT / E)) * E, co = it / (MT / E);
+        const int tx = vt % g.TX, t2 = vt / g.TX;
+        const int ty = t2 % g.TY, tz = t2 / g.TY;
+        const int gz = z0 + tz, gyy = y0 + ty, gx = x0 + tx;
+        gl[i] = co * MTP + vt;
+        if (co0 + co < g.Cout && gz < g.D && gyy < g.H && gx + (E - 1) < g.W) {
+          const float* src = gb + (long)(co0 + co) * DHW + gz * HW + (long)gyy * g.W + gx;
+          if (VEC) {
+            const float4 t4 = *reinterpret_cast<const float4*>(src);
+            gv[i].v[0] = t4.x; gv[i].v[1] = t4.y; gv[i].v[2] = t4.z; gv[i].v[3] = t4.w;
+          } else {
+            gv[i].v[0] = *src;
+          }
+        }
+      }
+    }
+    __syncthreads();  // previous tile fully consumed
+    halo_store<KS, NT, VEC>(hs, xv, Xs, g);
+#pragma unroll
+    for (int i = 0; i < kGX; ++i) {
+      if (gl[i] >= 0) {
+        if (VEC) {  // MTP is even, not a multiple of 4: two 8-byte stores
+          *reinterpret_cast<float2*>(Gs + gl[i]) = make_float2(gv[i].v[0], gv[i].v[1]);
+          *reinterpret_cast<float2*>(Gs + gl[i] + 2) = make_float2(gv[i].v[2], gv[i].v[3]);
+        } else {
+          Gs[gl[i]] = gv[i].v[0];
+        }
+      }
     }
     __syncthreads();
-    for (int k0 = 0; k0 < MT; k0 += 4) {
-      const int tx = k0 % g.TX, t2 = k0 / g.TX;
-      const int ty = t2 % g.TY, tz = t2 / g.TY;
-      const int vb = (tz * PY + ty) * PX + tx + lq + lr * g.PS;
-      const float a = Gs[lr * MTP + k0 + lq];
+    if (T >= WAVES) {
+      for (int k0 = 0; k0 < MT; k0 += 4) {
+        const int tx = k0 % g.TX, t2 = k0 / g.TX;
+        const int ty = t2 % g.TY, tz = t2 / g.TY;
+        const int vb = (tz * PY + ty) * g.PXL + tx + lq + lr * g.PS;
+        const float a = Gs[lr * MTP + k0 + lq];
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        if (wid + t * WAVES < T) {
-          const float b = Xs[vb + tapoff[t]];
-          acc[t] = icl_mfma_16x16x4(a, b, acc[t]);
+        for (int t = 0; t < NTW; ++t) {
+          if (wid + t * WAVES < T) {
+            const float b = Xs[vb + tapoff[t]];
+            acc[t] = icl_mfma_16x16x4(a, b, acc[t]);
+          }
         }
+      }
+    } else {  // fewer taps than waves (1x1x1): the waves split the voxels instead
+      for (int k0 = wid * 4; k0 < MT; k0 += 4 * WAVES) {
+        const int tx = k0 % g.TX, t2 = k0 / g.TX;
+        const int ty = t2 % g.TY, tz = t2 / g.TY;
+        const int vb = (tz * PY + ty) * g.PXL + tx + lq + lr * g.PS;
+        const float a = Gs[lr * MTP + k0 + lq];
+        const float b = Xs[vb + tapoff[0]];
+        acc[0] = icl_mfma_16x16x4(a, b, acc[0]);
       }
     }
   }
@@ -266,7 +437,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_wgrad_kernel(const flo
   if (ci < g.CinP) {
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-      const int tap = wid + t * WAVES;
+      const int tap = (T >= WAVES) ? wid + t * WAVES : 0;
       if (tap >= T) continue;
       float* dst = gwp + ((long)tap * g.CinP + ci) * g.CoutP + co0 + lq * 4;
 #pragma unroll

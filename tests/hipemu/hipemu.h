@@ -306,3 +306,4 @@ static inline f32x16 icl_mfma_32x32x2(float a, float b, f32x16 c) {
 #define ICL_MEMSET_ASYNC(ptr, val, bytes, stream) ((void)memset((ptr), (val), (bytes)))
 #define ICL_LAST_LAUNCH_ERROR() 0
 #define ICL_ERROR_STRING(e) "hipemu"
+#define ICL_SET_MAX_DYN_LDS(kern, bytes) ((void)0)
