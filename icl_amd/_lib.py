@@ -33,12 +33,15 @@ _SIGNATURES = {
     "icl_maxpool2_fwd": (c_int, [P, P, P, L, I, I, I, P]),
     "icl_maxpool2_bwd": (c_int, [P, P, P, L, I, I, I, P]),
     "icl_trilinear_fwd": (c_int, [P, P, I, I, I, I, I, I, I, I, L, P]),
-    "icl_trilinear_bwd": (c_int, [P, P, I, I, I, I, I, I, I, I, L, P]),
+    "icl_trilinear_bwd_ws_bytes": (c_int64, [I, I, I, I, I, I, I, I]),
+    "icl_trilinear_bwd": (c_int, [P, P, P, I, I, I, I, I, I, I, I, L, P]),
     "icl_copy_rows": (c_int, [P, P, L, L, L, L, P]),
     "icl_dwconv3_fwd": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "icl_dwconv3_wgrad": (c_int, [P, P, P, I, I, I, I, I, P]),
     "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P]),
     "icl_loss_fwd": (c_int, [P, P, P, P, P, P, I, I, L, I, I, P]),
+    "icl_sgd_step": (c_int, [P, P, P, L, F, F, F, I, P]),
+    "icl_sgd_step_multi": (c_int, [P, P, P, P, I, F, F, F, I, P]),
     "icl_loss_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, L, I, I, P]),
 }
 

@@ -167,6 +167,11 @@ __device__ __forceinline__ void halo_store(const HaloStager<KS, NT, VEC>& st, co
 // Packed-weight staging: rows (tap, c) of NB floats, 16 B per item.
 constexpr int kWX = 7;  // max float4 items per thread per chunk
 
+// column swizzle for 32-float rows: odd rows swap their 16-column halves, so the four k-rows an MFMA B-read touches
+// (lanes 0-15 / 16-31 read rows k, k+1) fall on disjoint LDS banks without padding the row to 48 floats.
+template <int NB>
+__device__ __forceinline__ int wswz(int row, int col) { return NB == 32 ? (col ^ ((row & 1) << 4)) : col; }
+
 template <int T, int NB, int NBP, int NT>
 struct WeightStager {
   int goff[kWX];
@@ -180,7 +185,7 @@ struct WeightStager {
       if (it < total) {
         const int n4 = it % (NB / 4), row = it / (NB / 4);
         const int tap = row / g.KC, c = row - tap * g.KC;
-        loff[i] = row * NBP + n4 * 4;
+        loff[i] = row * NBP + wswz<NB>(row, n4 * 4);
         if (n0 + n4 * 4 < g.CoutP) goff[i] = (tap * g.CinP + c) * g.CoutP + n0 + n4 * 4;
       }
     }
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_fwd_kernel(const float
   constexpr int T = KS * KS * KS;
   constexpr int PAD = KS / 2;
   constexpr int NB = NBT * 16;
-  constexpr int NBP = NB + (NB == 32 ? 16 : 0) + (NB == 48 ? 32 : 0);  // 16, 48, 80: == 16 (mod 32)
+  constexpr int NBP = NB;  // row pitch 16 / 48 is == 16 (mod 32); the 32-wide rows are XOR-swizzled (wswz) instead of padded
   constexpr int NT = WAVES * 64;
   ICL_DYN_LDS(float, lds);
   float* Xs = lds;
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_fwd_kernel(const float
         const int krow = tap * g.KC + cc + lq;
         float b[NBT];
 #pragma unroll
-        for (int j = 0; j < NBT; ++j) b[j] = Ws[krow * NBP + j * 16 + lr];
+        for (int j = 0; j < NBT; ++j) b[j] = Ws[krow * NBP + wswz<NB>(krow, j * 16 + lr)];
 #pragma unroll
         for (int m = 0; m < MV; ++m) {
           const float a = Xs[vbase[m] + tapoff + cc * g.PS];

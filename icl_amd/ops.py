@@ -290,7 +290,8 @@ class _Trilinear(torch.autograd.Function):
         n, c, di, hi, wi = ctx.in_shape
         do, ho, wo = gy.shape[2:]
         gx = torch.empty(ctx.in_shape, dtype=torch.float32, device=gy.device)
-        _lib.check(L.icl_trilinear_bwd(_ptr(gy), _ptr(gx), n, c, di, hi, wi, do, ho, wo, c * do * ho * wo, _stream(gy)),
+        ws = _ws(L.icl_trilinear_bwd_ws_bytes(n, c, di, hi, wi, do, ho, wo), gy)
+        _lib.check(L.icl_trilinear_bwd(_ptr(gy), _ptr(gx), _ptr(ws), n, c, di, hi, wi, do, ho, wo, c * do * ho * wo, _stream(gy)),
                    "trilinear_bwd")
         return gx, None
 
@@ -335,7 +336,8 @@ class _UpCat(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gdeep = torch.empty((n, cd, d // 2, h // 2, w // 2), dtype=torch.float32, device=g.device)
             gv = g[:, cs:]
-            _lib.check(L.icl_trilinear_bwd(_vp(gv.data_ptr()), _ptr(gdeep), n, cd, d // 2, h // 2, w // 2, d, h, w,
+            ws = _ws(L.icl_trilinear_bwd_ws_bytes(n, cd, d // 2, h // 2, w // 2, d, h, w), g)
+            _lib.check(L.icl_trilinear_bwd(_vp(gv.data_ptr()), _ptr(gdeep), _ptr(ws), n, cd, d // 2, h // 2, w // 2, d, h, w,
                                            (cs + cd) * s, _stream(g)), "trilinear_bwd")
         return gskip, gdeep
 

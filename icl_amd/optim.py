@@ -1,0 +1,67 @@
+"""FusedSGD — torch.optim.SGD(momentum, weight_decay) semantics on one HIP pass per parameter.
+
+Counterpart of ``optim.SGD(model.parameters(), lr, momentum=0.9, weight_decay=1e-4)`` in the reference trainers
+(/root/reference/code/train_inherent_consistent_unet_3D_BraTS.py:85-86).  It is a ``torch.optim.Optimizer`` so the
+trainers' ``for g in optimizer.param_groups: g['lr'] = lr_`` schedule (:117-119) keeps working.  Parameters whose
+``.grad`` is None are skipped entirely — no weight decay, no momentum — exactly like torch.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+_BIG = 1 << 20
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=0.01, momentum=0.9, weight_decay=0.0):
+        if momentum <= 0:
+            raise ValueError("FusedSGD implements the momentum form used by the ICL trainers")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        L = _lib.lib()
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            lr, mom, wd = float(group["lr"]), float(group["momentum"]), float(group["weight_decay"])
+            small = {0: [], 1: []}
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32):
+                    raise RuntimeError("FusedSGD needs contiguous fp32 parameters and gradients")
+                if not p.is_cuda and not _lib.host_pointers_ok():
+                    raise RuntimeError("FusedSGD needs device tensors (no CPU fallback)")
+                st = self.state[p]
+                first = 0
+                if "momentum_buffer" not in st:
+                    st["momentum_buffer"] = torch.empty_like(p)
+                    first = 1
+                m = st["momentum_buffer"]
+                if p.numel() >= _BIG:
+                    stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream) if p.is_cuda else None
+                    _lib.check(L.icl_sgd_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), p.numel(), lr, mom, wd, first, stream),
+                               "sgd_step")
+                else:
+                    small[first].append((p, g, m))
+            for first, items in small.items():
+                if not items:
+                    continue
+                n = len(items)
+                arr = ctypes.c_void_p * n
+                P_ = arr(*[it[0].data_ptr() for it in items])
+                G_ = arr(*[it[1].data_ptr() for it in items])
+                M_ = arr(*[it[2].data_ptr() for it in items])
+                N_ = (ctypes.c_int64 * n)(*[it[0].numel() for it in items])
+                p0 = items[0][0]
+                stream = ctypes.c_void_p(torch.cuda.current_stream(p0.device).cuda_stream) if p0.is_cuda else None
+                _lib.check(L.icl_sgd_step_multi(P_, G_, M_, N_, n, lr, mom, wd, first, stream), "sgd_step_multi")
+        return loss

@@ -19,6 +19,7 @@ import torch
 from torch.nn.modules.loss import CrossEntropyLoss
 
 from . import ops
+from .optim import FusedSGD
 from .utils import losses as L
 
 
@@ -38,8 +39,8 @@ class ICLConfig:
 class ICLTrainer:
     def __init__(self, model: torch.nn.Module, cfg: ICLConfig, ddp=None):
         self.model, self.cfg, self.ddp = model, cfg, ddp
-        self.optimizer = torch.optim.SGD(model.parameters(), lr=cfg.base_lr, momentum=cfg.momentum,
-                                         weight_decay=cfg.weight_decay)
+        self.optimizer = FusedSGD(model.parameters(), lr=cfg.base_lr, momentum=cfg.momentum,
+                                  weight_decay=cfg.weight_decay)
         self.ce_loss = CrossEntropyLoss()
         self.dice_loss = L.DiceLoss(cfg.num_classes)
         self.aux_loss = L.AuxLoss3D(cfg.num_classes, cfg.patch_size)

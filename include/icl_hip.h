@@ -58,7 +58,9 @@ int icl_maxpool2_bwd(const float* gy, const uint8_t* idx, float* gx, int64_t nc,
  * Source index scale per axis = in/out (what ATen uses for size= and for scale_factor=2). */
 int icl_trilinear_fwd(const float* x, float* y, int n, int c, int di, int hi, int wi, int dout, int hout, int wout,
                       int64_t y_bstride, void* stream);
-int icl_trilinear_bwd(const float* gy, float* gx, int n, int c, int di, int hi, int wi, int dout, int hout, int wout,
+/* backward = three separable one-axis gathers (x, y, z); ws >= icl_trilinear_bwd_ws_bytes(...) */
+int64_t icl_trilinear_bwd_ws_bytes(int n, int c, int di, int hi, int wi, int dout, int hout, int wout);
+int icl_trilinear_bwd(const float* gy, float* gx, void* ws, int n, int c, int di, int hi, int wi, int dout, int hout, int wout,
                       int64_t gy_bstride, void* stream);
 
 /* ---- strided row copy (torch.cat([skip, up], 1), networks/utils.py:276) */
@@ -86,6 +88,13 @@ int icl_loss_fwd(const float* a, const float* b, const int64_t* labels, const fl
 int icl_loss_bwd(const float* a, const float* b, const int64_t* labels, const float* weight, const float* stats,
                  const float* gout, float* coef, float* ga, int batch, int nc, int64_t s, int mode, int a_is_prob,
                  void* stream);
+
+/* ---- fused SGD(momentum, weight decay) step, torch.optim.SGD semantics (train_inherent_consistent_unet_3D_BraTS.py:85-86,115):
+ * d = g + wd*p; m = first ? d : momentum*m + d; p -= lr*m.  The multi form takes HOST arrays of device pointers. */
+int icl_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float weight_decay, int first,
+                 void* stream);
+int icl_sgd_step_multi(void* const* p, const void* const* g, void* const* m, const int64_t* n, int count, float lr,
+                       float momentum, float weight_decay, int first, void* stream);
 
 #ifdef __cplusplus
 }

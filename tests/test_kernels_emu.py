@@ -197,3 +197,28 @@ def test_depthwise_and_dropout():
     assert abs((yo != 0).float().mean().item() - 0.7) < 0.03
     yo.sum().backward()
     assert torch.equal(xo.grad != 0, yo.detach() != 0)
+
+
+def test_fused_sgd_matches_torch():
+    from icl_amd.optim import FusedSGD
+    torch.manual_seed(0)
+    shapes = [(5, 7), (33,), (1 << 20,), (3, 3, 3, 2, 2), (1,)]
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    skip = torch.nn.Parameter(torch.randn(4))  # never receives a gradient
+    skip_ref = skip.detach().clone()
+    a = FusedSGD(ps + [skip], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    b = torch.optim.SGD(qs, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    for it in range(3):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        a.step()
+        b.step()
+        for grp in a.param_groups:
+            grp["lr"] = 0.01 * (1 - it / 10) ** 0.9
+        for grp in b.param_groups:
+            grp["lr"] = 0.01 * (1 - it / 10) ** 0.9
+    for p, q in zip(ps, qs):
+        assert rel_err(p.detach(), q.detach()) < 1e-6
+    assert torch.equal(skip.detach(), skip_ref)
