@@ -39,8 +39,20 @@ def _rand(shape, seed, grad=False):
     (1, 20, 48, 6, 6, 12, 3),   # partial cin chunk + partial cout tile
     (2, 8, 2, 4, 4, 8, 1),      # 1x1x1 (final conv class)
     (1, 32, 16, 2, 8, 32, 3),   # wide row: several x tiles
+    (1, 8, 48, 5, 12, 12, 3),   # static 4x4x16 tile, masked x/z borders, NB = 48
+    (2, 4, 16, 3, 16, 24, 3),   # static 2x8x16 tile, CinP = 4 chunks, partial x tile
 ])
 def test_conv3d_fwd_bwd(n, cin, cout, d, h, w, ks):
+    _conv_check(n, cin, cout, d, h, w, ks)
+
+
+def test_conv3d_forced_big_tile(monkeypatch):
+    monkeypatch.setenv("ICL_CONV_FORCE_TILE", "48")
+    _conv_check(1, 16, 16, 6, 8, 16, 3)
+    _conv_check(1, 8, 32, 4, 16, 16, 3)
+
+
+def _conv_check(n, cin, cout, d, h, w, ks):
     x = _rand((n, cin, d, h, w), 1, True)
     wt = (_rand((cout, cin, ks, ks, ks), 2) * 0.2).requires_grad_()
     b = (_rand((cout,), 3) * 0.1).requires_grad_()
