@@ -17,9 +17,10 @@ from .. import ops
 class Conv3d(nn.Module):
     """nn.Conv3d(cin, cout, k, stride 1, padding k//2) parameters; forward = MFMA implicit-GEMM kernel."""
 
-    def __init__(self, cin, cout, ks=3, bias=True, groups=1, device=None, kaiming_normal=False):
+    def __init__(self, cin, cout, ks=3, bias=True, groups=1, device=None, kaiming_normal=False, feeds_instance_norm=False):
         super().__init__()
         self.cin, self.cout, self.ks, self.groups = cin, cout, ks, groups
+        self.feeds_instance_norm = feeds_instance_norm
         self.weight = nn.Parameter(torch.empty(cout, cin // groups, ks, ks, ks, device=device))
         self.bias = nn.Parameter(torch.empty(cout, device=device)) if bias else None
         fan_in = (cin // groups) * ks ** 3
@@ -34,7 +35,7 @@ class Conv3d(nn.Module):
     def forward(self, x):
         if self.groups != 1:
             return ops.depthwise_conv3d(x, self.weight)
-        return ops.conv3d(x, self.weight, self.bias)
+        return ops.conv3d(x, self.weight, self.bias, self.feeds_instance_norm)
 
 
 class InstanceNormReLU(nn.Module):
@@ -54,7 +55,8 @@ class ConvBlock(nn.Sequential):
     Index 1 fuses norm+ReLU; index 2 is kept as a no-op so the child layout matches the reference."""
 
     def __init__(self, cin, cout, device=None):
-        super().__init__(Conv3d(cin, cout, 3, device=device, kaiming_normal=True), InstanceNormReLU(), _Identity())
+        super().__init__(Conv3d(cin, cout, 3, device=device, kaiming_normal=True, feeds_instance_norm=True),
+                         InstanceNormReLU(), _Identity())
 
 
 class UnetConv3(nn.Module):

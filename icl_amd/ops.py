@@ -126,10 +126,11 @@ def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_b
 
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, zero_bias_grad=False):
         _require(x, weight, bias)
         x = x.contiguous()
         weight = weight.contiguous()
+        ctx.zero_bias_grad = zero_bias_grad
         n, cin, d, h, w = x.shape
         cout, ks = weight.shape[0], weight.shape[2]
         assert weight.shape[1] == cin and weight.shape[2] == weight.shape[3] == weight.shape[4]
@@ -157,18 +158,26 @@ class _Conv3d(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw = torch.empty_like(weight)
             gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            gb_arg = gb
+            if ctx.has_bias and ctx.zero_bias_grad:
+                # the conv feeds an InstanceNorm: its output is invariant to the bias, so dL/dbias == 0 exactly
+                # (the reference holds ~1e-8 rounding noise there); skip the reduction pass over dY.
+                gb.zero_()
+                gb_arg = None
             ws = _ws(L.icl_conv3d_packed_elems(cout, cin, ks, 0) * 4, x)
             flops = 2.0 * ks ** 3 * cin * cout * s * n
             nbytes = 4.0 * (n * s * (cin + cout) + 2 * ks ** 3 * cin * cout)
             with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):
-                _lib.check(L.icl_conv3d_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(ws), n, cin, cout, d, h, w, ks,
+                _lib.check(L.icl_conv3d_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin, cout, d, h, w, ks,
                                               cin * s, cout * s, _stream(x)), "conv3d_wgrad")
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def conv3d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Conv3d, kernel 3 (pad 1) or 1 (pad 0), stride 1."""
-    return _Conv3d.apply(x, weight, bias)
+def conv3d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           zero_bias_grad: bool = False) -> torch.Tensor:
+    """Conv3d, kernel 3 (pad 1) or 1 (pad 0), stride 1.  ``zero_bias_grad``: the caller guarantees the output goes
+    straight into a mean-removing normalisation, so the bias gradient is identically zero."""
+    return _Conv3d.apply(x, weight, bias, zero_bias_grad)
 
 
 # --------------------------------------------------------------------------------------
