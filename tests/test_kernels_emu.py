@@ -41,6 +41,9 @@ def _rand(shape, seed, grad=False):
     (1, 32, 16, 2, 8, 32, 3),   # wide row: several x tiles
     (1, 8, 48, 5, 12, 12, 3),   # static 4x4x16 tile, masked x/z borders, NB = 48
     (2, 4, 16, 3, 16, 24, 3),   # static 2x8x16 tile, CinP = 4 chunks, partial x tile
+    (1, 16, 32, 3, 8, 24, 3),   # flat 2x8x24 tile (NB 32), z border
+    (1, 8, 96, 4, 8, 12, 3),    # flat 4x4x12 tile, NB 48
+    (2, 16, 64, 6, 6, 6, 3),    # flat 6x6x6 tile, scalar staging, padded row groups
 ])
 def test_conv3d_fwd_bwd(n, cin, cout, d, h, w, ks):
     _conv_check(n, cin, cout, d, h, w, ks)
