@@ -25,6 +25,7 @@ _SIGNATURES = {
     "icl_conv3d_packed_elems": (c_int64, [I, I, I, I]),
     "icl_conv3d_pack_weights": (c_int, [P, P, I, I, I, I, P]),
     "icl_conv3d_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, I, L, L, P]),
+    "icl_conv3d_wgrad_ws_bytes": (c_int64, [I, I, I, I]),
     "icl_conv3d_wgrad": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, L, L, P]),
     "icl_norm_ws_bytes": (c_int64, [I, I, L]),
     "icl_norm_fwd": (c_int, [P, P, P, P, P, P, P, P, I, I, L, I, I, I, F, F, P, P]),

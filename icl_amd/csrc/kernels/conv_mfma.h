@@ -26,7 +26,7 @@
 // wgrad kernel (one workgroup = 16 output channels x 16 input channels x all taps, loops over tiles):
 //   GEMM view  M = Cout (16), N = Cin (16) per tap, K = voxels in steps of 4 consecutive x.
 //   A[co][v] = Gs[co][v] (dY tile, zero where outside the volume), B[v][ci] = Xs[ci][v + tap offset]
-//   taps are dealt round-robin to the waves; partial dW is atomically added into packed gWp.
+//   taps are dealt round-robin to the waves; partial dW of each (split, batch) workgroup goes to its own packed slab, reduced by reduce_unpack_wgrad_kernel.
 //
 // Algorithmic HBM bytes: fwd 4*(I+O+W), dgrad 4*(O+I+W), wgrad 4*(O+I+W).
 #pragma once
@@ -66,16 +66,30 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
   }
 }
 
-// gW[co][ci][tap] = gWp[tap][ci][co]
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ gwp, float* __restrict__ gw, int Cout, int Cin,
-                                                           int T, int CinP, int CoutP) {
-  const long total = (long)Cout * Cin * T;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int tap = (int)(e % T);
-    const long t = e / T;
-    const int ci = (int)(t % Cin);
-    const int co = (int)(t / Cin);
-    gw[e] = gwp[((long)tap * CinP + ci) * CoutP + co];
+// gW[co][ci][tap] = sum over slabs s of gWp[s][tap][ci][co]  (fixed summation order -> reproducible).
+// A workgroup owns 64 consecutive packed elements; its 4 waves take slabs s = wave, wave+4, ... so every slab
+// read is a coalesced 256-byte row, then the four partial sums are combined through LDS in wave order.
+__global__ __launch_bounds__(256) void reduce_unpack_wgrad_kernel(const float* __restrict__ gwp, float* __restrict__ gw, int Cout, int Cin,
+                                                                  int T, int CinP, int CoutP, int nslabs) {
+  const long pe = (long)T * CinP * CoutP;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __shared__ float part[4][64];
+  for (long base = (long)blockIdx.x * 64; base < pe; base += (long)gridDim.x * 64) {
+    const long idx = base + lane;
+    float acc = 0.f;
+    if (idx < pe)
+      for (int s = wid; s < nslabs; s += 4) acc += gwp[s * pe + idx];
+    __syncthreads();
+    part[wid][lane] = acc;
+    __syncthreads();
+    if (wid == 0 && idx < pe) {
+      const float v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+      const int co = (int)(idx % CoutP);
+      const long t = idx / CoutP;
+      const int ci = (int)(t % CinP);
+      const int tap = (int)(t / CinP);
+      if (co < Cout && ci < Cin) gw[((long)co * Cin + ci) * T + tap] = v;
+    }
   }
 }
 
@@ -444,9 +458,12 @@ __global__ __launch_bounds__(WAVES * 64) void conv3d_mfma_wgrad_kernel(const flo
     for (int t = 0; t < NTW; ++t) {
       const int tap = (T >= WAVES) ? wid + t * WAVES : 0;
       if (tap >= T) continue;
-      float* dst = gwp + ((long)tap * g.CinP + ci) * g.CoutP + co0 + lq * 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[t][r]);
+      // every (split, batch) workgroup owns one slab of packed partial sums: plain 16-byte stores, no atomics;
+      // reduce_unpack_wgrad_kernel adds the slabs in a fixed order (bitwise reproducible gradients)
+      // (with fewer taps than waves the waves hold partial sums of the SAME tap: one slab per wave)
+      const long slab = ((long)blockIdx.z * gridDim.x + blockIdx.x) * (T >= WAVES ? 1 : WAVES) + (T >= WAVES ? 0 : wid);
+      float* dst = gwp + slab * ((long)T * g.CinP * g.CoutP) + ((long)tap * g.CinP + ci) * g.CoutP + co0 + lq * 4;
+      *reinterpret_cast<float4*>(dst) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
     }
   }
 }

@@ -194,8 +194,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma_fwd_static_kernel(const float
 // ---------------------------------------------------------------------------------------------------------
 // wgrad, tile 2 x 8 x 16 voxels, 16 output x 16 input channels x 27 taps per workgroup (taps round-robin over waves).
 // ---------------------------------------------------------------------------------------------------------
-struct WgradTile {
-  static constexpr int TZ = 2, TY = 8, TX = 16, KC = 16;
+template <int TZ_, int TY_>
+struct WgradTileT {
+  static constexpr int TZ = TZ_, TY = TY_, TX = 16, KC = 16;
   static constexpr int HX = 4, PXL = TX + 2 * HX, PZ = TZ + 2, PY = TY + 2, Q = PXL / 4;
   static constexpr int PER_CH = PZ * PY * Q;
   static constexpr int PS = pad_to_mod(PZ * PY * PXL, 2, 32);   // B reads: lanes lr -> planes, conflict-free
@@ -205,9 +206,10 @@ struct WgradTile {
   static constexpr int GX = 16 * (MT / 4) / NT;  // dY float4 items per thread
 };
 
+template <class TC>
 __global__ __launch_bounds__(256) void conv3d_mfma_wgrad_static_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                        float* __restrict__ gwp, ConvGeom g) {
-  using TC = WgradTile;
+  
   constexpr int T = 27, NTW = 7, WAVES = 4, NT = 256;
   constexpr int PS = TC::PS, PXL = TC::PXL, PY = TC::PY, PZ = TC::PZ, MT = TC::MT, MTP = TC::MTP;
   constexpr int NP = TC::NP, JX = TC::JX, CPP = TC::CPP, Q = TC::Q, GX = TC::GX;
@@ -331,9 +333,11 @@ __global__ __launch_bounds__(256) void conv3d_mfma_wgrad_static_kernel(const flo
     for (int t = 0; t < NTW; ++t) {
       const int tap = wid + t * WAVES;
       if (tap >= T) continue;
-      float* dst = gwp + ((long)tap * g.CinP + ci) * g.CoutP + co0 + lq * 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[t][r]);
+      // every (split, batch) workgroup owns one slab of packed partial sums: plain 16-byte stores, no atomics;
+      // reduce_unpack_wgrad_kernel adds the slabs in a fixed order (bitwise reproducible gradients)
+      const long slab = (long)blockIdx.z * gridDim.x + blockIdx.x;
+      float* dst = gwp + slab * ((long)T * g.CinP * g.CoutP) + ((long)tap * g.CinP + ci) * g.CoutP + co0 + lq * 4;
+      *reinterpret_cast<float4*>(dst) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
     }
   }
 }

@@ -164,7 +164,7 @@ class _Conv3d(torch.autograd.Function):
                 # (the reference holds ~1e-8 rounding noise there); skip the reduction pass over dY.
                 gb.zero_()
                 gb_arg = None
-            ws = _ws(L.icl_conv3d_packed_elems(cout, cin, ks, 0) * 4, x)
+            ws = _ws(L.icl_conv3d_wgrad_ws_bytes(n, cin, cout, ks), x)
             flops = 2.0 * ks ** 3 * cin * cout * s * n
             nbytes = 4.0 * (n * s * (cin + cout) + 2 * ks ** 3 * cin * cout)
             with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):

@@ -32,8 +32,9 @@ int icl_conv3d_pack_weights(const float* w, float* wp, int cout, int cin, int ks
  * x = dY, cin/cout swapped, bias NULL.  Batch strides in elements; channel stride is D*H*W. */
 int icl_conv3d_fwd(const float* x, const float* wp, const float* bias, float* y, int n, int cin, int cout, int d, int h,
                    int w, int ks, int64_t x_bstride, int64_t y_bstride, void* stream);
-/* gw[cout][cin][taps] = sum over batch and voxels; ws >= icl_conv3d_packed_elems(cout,cin,ks,0)*4 bytes.
- * gbias (may be NULL) [cout] = sum of gy. */
+/* gw[cout][cin][taps] = sum over batch and voxels; ws >= icl_conv3d_wgrad_ws_bytes(n,cin,cout,ks) bytes (one packed
+ * partial-sum slab per workgroup row, reduced in a fixed order: bitwise reproducible).  gbias (may be NULL) [cout] = sum of gy. */
+int64_t icl_conv3d_wgrad_ws_bytes(int n, int cin, int cout, int ks);
 int icl_conv3d_wgrad(const float* x, const float* gy, float* gw, float* gbias, void* ws, int n, int cin, int cout, int d,
                      int h, int w, int ks, int64_t x_bstride, int64_t gy_bstride, void* stream);
 

@@ -41,7 +41,7 @@ def main():
         gb = torch.empty_like(b)
         wp, wpt = ops.pack_weights(w, 0), ops.pack_weights(w, 1)
         S = s ** 3
-        ws = torch.empty(L.icl_conv3d_packed_elems(cout, cin, 3, 0), device=dev)
+        ws = torch.empty(L.icl_conv3d_wgrad_ws_bytes(1, cin, cout, 3) // 4, device=dev)
         fl = 2.0 * 27 * cin * cout * S
         t_f = timeit(lambda: ops.conv3d_forward_raw(x, wp, b, 1, cin, cout, s, s, s, 3, cin * S, y, cout * S))
         t_d = timeit(lambda: ops.conv3d_forward_raw(gy, wpt, None, 1, cout, cin, s, s, s, 3, cout * S, gx, cin * S)) if cin > 1 else 0.0

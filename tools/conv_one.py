@@ -19,7 +19,7 @@ gy = torch.randn(1, cout, s, s, s, device=dev)
 y, gx, gw, gb = torch.empty_like(gy), torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
 wp, wpt = ops.pack_weights(w, 0), ops.pack_weights(w, 1)
 S = s ** 3
-ws = torch.empty(L.icl_conv3d_packed_elems(cout, cin, 3, 0), device=dev)
+ws = torch.empty(L.icl_conv3d_wgrad_ws_bytes(1, cin, cout, 3) // 4, device=dev)
 for _ in range(iters):
     if what == "fwd":
         ops.conv3d_forward_raw(x, wp, b, 1, cin, cout, s, s, s, 3, cin * S, y, cout * S)
