@@ -1,0 +1,76 @@
+"""World-size-2 checks of the data-parallel gradient reducer on the gloo backend (CPU).
+
+SURVEY.md §8e: W ranks == W independent reference steps with averaged gradients; parameters whose grad is None
+are skipped, never zero-filled (torch SGD skips them too, so weight decay must not touch them)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(7, 5)
+        self.unused = torch.nn.Linear(3, 3)       # never used in forward: grad stays None
+        self.big = torch.nn.Parameter(torch.randn(300, 40))
+        self.b = torch.nn.Linear(5, 2)
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x))) + (self.big.sum() * 1e-3)
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from icl_amd.ddp import GradientReducer
+    torch.manual_seed(100 + rank)          # different initial weights per rank: broadcast must fix that
+    model = Tiny()
+    red = GradientReducer(model, world, bucket_bytes=4096)   # small buckets: multi-tensor and single-tensor paths
+    red.broadcast_parameters()
+    torch.manual_seed(7)
+    data = torch.randn(world, 4, 7)        # every rank knows all shards so it can build the reference result
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+    model(data[rank]).pow(2).mean().backward()
+    red.reduce_gradients()
+    assert model.unused.weight.grad is None and model.unused.bias.grad is None
+    got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    unused_before = model.unused.weight.detach().clone()
+    opt.step()
+    assert torch.equal(model.unused.weight.detach(), unused_before)   # skipped: no weight decay applied
+    # reference: same weights, mean over ranks of the per-shard gradients
+    if rank == 0:
+        torch.save({k: v for k, v in got.items()}, os.path.join(tmp, "g0.pt"))
+    dist.barrier()
+    g0 = torch.load(os.path.join(tmp, "g0.pt"))
+    for k in got:
+        assert torch.allclose(got[k], g0[k], rtol=0, atol=0), k   # all ranks hold identical averaged grads
+    # independent recomputation on one process
+    torch.manual_seed(100)                 # rank 0's initial weights are what was broadcast
+    single = Tiny()
+    acc = None
+    for r in range(world):
+        single.zero_grad(set_to_none=True)
+        single(data[r]).pow(2).mean().backward()
+        gs = {k: p.grad.clone() for k, p in single.named_parameters() if p.grad is not None}
+        acc = gs if acc is None else {k: acc[k] + gs[k] for k in gs}
+    for k in got:
+        assert torch.allclose(got[k], acc[k] / world, rtol=1e-5, atol=1e-6), k
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradient_reducer_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
