@@ -1,0 +1,248 @@
+// token.h — aligner token operators: LayerNorm, GELU(erf) and the prototype cross-attention
+// (/root/reference/code/networks/unet_3D_icl.py: Class_Decoder :244-268, Query_Attention :270-297, MLP :299-315).
+// All of them are tiny next to the convolutions and the 13,824^2 mlp2 GEMMs: HBM/latency-bound, fp32 VALU.
+// (The QK^T contraction is nc x 16 per token, <= 28 MFLOP per call — SURVEY.md §0.4 — far too small to feed MFMA.)
+#pragma once
+
+namespace icl {
+
+// ---------------------------------------------------------------- LayerNorm over the last axis, one wave per row
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + r * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float m = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = xr[c] - m; q += d * d; }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  float* yr = y + r * C;
+  for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - m) * rs * gamma[c] + beta[c];
+  if (lane == 0) { mean[r] = m; rstd[r] = rs; }
+}
+
+// gx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = gy*gamma
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ gx, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + r * C;
+  const float* gr = gy + r * C;
+  const float m = mean[r], rs = rstd[r];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float g = gr[c] * gamma[c];
+    s1 += g;
+    s2 += g * (xr[c] - m) * rs;
+  }
+  s1 = wave_sum(s1) / (float)C;
+  s2 = wave_sum(s2) / (float)C;
+  float* o = gx + r * C;
+  for (int c = lane; c < C; c += 64) o[c] = rs * (gr[c] * gamma[c] - s1 - (xr[c] - m) * rs * s2);
+}
+
+// dgamma[c] += sum_rows gy*xhat, dbeta[c] += sum_rows gy  (pre-zeroed; grid (ceil(C/256), row chunks))
+__global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C,
+                                                              long rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float a = 0.f, b = 0.f;
+  for (long r = r0; r < r1; ++r) {
+    const float g = gy[r * C + c];
+    a += g * (x[r * C + c] - mean[r]) * rstd[r];
+    b += g;
+  }
+  atomicAdd(dgamma + c, a);
+  atomicAdd(dbeta + c, b);
+}
+
+// ---------------------------------------------------------------- GELU (exact erf form, nn.GELU default)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+  }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * expf(-0.5f * v * v);
+    gx[i] = gy[i] * (cdf + v * pdf);
+  }
+}
+
+// ---------------------------------------------------------------- prototype cross-attention
+// q    [B,h,nc,D]   (the reference's reshape-quirk layout of fc_q's output, unet_3D_icl.py:287)
+// kv   [B,N,2,h,D]  (fc_kv output: k | v, head, d)
+// logits[B,h,nc,N] = scale * q.k   — returned as the "attention" map (pre-softmax, :290,296)
+// out  [B,h,nc,D]   = softmax_N(logits) @ v;  stats[B,h,nc,2] = (row max, sum of exp) for the backward.
+constexpr int kAttnMaxNc = 16;
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restrict__ q, const float* __restrict__ kv, float* __restrict__ logits,
+                                                          int B, int H, int nc, int N, float scale) {
+  __shared__ float qs[kAttnMaxNc * D];
+  const int bh = blockIdx.y;  // b*H + h
+  const int b = bh / H, h = bh % H;
+  for (int i = threadIdx.x; i < nc * D; i += 256) qs[i] = q[(long)bh * nc * D + i];
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float* kp = kv + (((long)b * N + n) * 2 + 0) * H * D + h * D;
+  float k[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) k[d] = kp[d];
+  for (int c = 0; c < nc; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) s += qs[c * D + d] * k[d];
+    logits[((long)bh * nc + c) * N + n] = s * scale;
+  }
+}
+
+// one workgroup per (b,h,c): softmax statistics and out = P @ V
+template <int D>
+__global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const float* __restrict__ logits, const float* __restrict__ kv,
+                                                              float* __restrict__ out, float* __restrict__ stats, int B, int H, int nc, int N) {
+  __shared__ float red[4 * (D + 1)];
+  const int row = blockIdx.x;  // (b*H + h)*nc + c
+  const int bh = row / nc;
+  const int b = bh / H, h = bh % H;
+  const float* l = logits + (long)row * N;
+  float m = -3.0e38f;
+  for (int n = threadIdx.x; n < N; n += 256) m = fmaxf(m, l[n]);
+  m = wave_max(m);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) red[wid] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f, o[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) o[d] = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float p = expf(l[n] - m);
+    s += p;
+    const float* vp = kv + (((long)b * N + n) * 2 + 1) * H * D + h * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[d] += p * vp[d];
+  }
+  s = wave_sum(s);
+#pragma unroll
+  for (int d = 0; d < D; ++d) o[d] = wave_sum(o[d]);
+  if (lane == 0) {
+    red[wid * (D + 1)] = s;
+#pragma unroll
+    for (int d = 0; d < D; ++d) red[wid * (D + 1) + 1 + d] = o[d];
+  }
+  __syncthreads();
+  if (threadIdx.x < D + 1) {
+    const int i = threadIdx.x;
+    const float v = red[i] + red[(D + 1) + i] + red[2 * (D + 1) + i] + red[3 * (D + 1) + i];
+    red[i] = v;
+  }
+  __syncthreads();
+  const float tot = red[0];
+  if (threadIdx.x < D) out[(long)row * D + threadIdx.x] = red[1 + threadIdx.x] / tot;
+  if (threadIdx.x == 0) { stats[(long)row * 2] = m; stats[(long)row * 2 + 1] = tot; }
+}
+
+// dlogit[c][n] = ga[c][n] + p*(dO[c].V[n] - out[c].dO[c]);   thread per (b,h,n): dK[n], dV[n] (no reduction needed)
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ logits,
+                                                          const float* __restrict__ stats, const float* __restrict__ out,
+                                                          const float* __restrict__ gout, const float* __restrict__ glog,
+                                                          float* __restrict__ gkv, int B, int H, int nc, int N, float scale) {
+  __shared__ float qs[kAttnMaxNc * D], gos[kAttnMaxNc * D], dl[kAttnMaxNc], ms[kAttnMaxNc * 2];
+  const int bh = blockIdx.y;
+  const int b = bh / H, h = bh % H;
+  for (int i = threadIdx.x; i < nc * D; i += 256) {
+    qs[i] = q[(long)bh * nc * D + i];
+    gos[i] = gout ? gout[(long)bh * nc * D + i] : 0.f;
+  }
+  for (int i = threadIdx.x; i < nc * 2; i += 256) ms[i] = stats[(long)bh * nc * 2 + i];
+  __syncthreads();
+  if (threadIdx.x < nc) {
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += out[((long)bh * nc + threadIdx.x) * D + d] * gos[threadIdx.x * D + d];
+    dl[threadIdx.x] = s;  // delta_c
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const long base = ((long)b * N + n) * 2 * H * D + h * D;
+  float v[D], dk[D], dv[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) { v[d] = kv[base + (long)H * D + d]; dk[d] = 0.f; dv[d] = 0.f; }
+  for (int c = 0; c < nc; ++c) {
+    const float p = expf(logits[((long)bh * nc + c) * N + n] - ms[c * 2]) / ms[c * 2 + 1];
+    float dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) dp += gos[c * D + d] * v[d];
+    const float g = (glog ? glog[((long)bh * nc + c) * N + n] : 0.f) + p * (dp - dl[c]);
+#pragma unroll
+    for (int d = 0; d < D; ++d) { dk[d] += scale * g * qs[c * D + d]; dv[d] += p * gos[c * D + d]; }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) { gkv[base + d] = dk[d]; gkv[base + (long)H * D + d] = dv[d]; }
+}
+
+// one workgroup per (b,h,c): dQ[c] = scale * sum_n dlogit[c][n] * K[n]
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ kv, const float* __restrict__ logits, const float* __restrict__ stats,
+                                                         const float* __restrict__ out, const float* __restrict__ gout,
+                                                         const float* __restrict__ glog, float* __restrict__ gq, int B, int H, int nc,
+                                                         int N, float scale) {
+  __shared__ float red[4 * D];
+  __shared__ float go[D];
+  __shared__ float delta_s;
+  const int row = blockIdx.x;
+  const int bh = row / nc;
+  const int b = bh / H, h = bh % H;
+  if (threadIdx.x < D) go[threadIdx.x] = gout ? gout[(long)row * D + threadIdx.x] : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += out[(long)row * D + d] * go[d];
+    delta_s = s;
+  }
+  __syncthreads();
+  const float m = stats[(long)row * 2], tot = stats[(long)row * 2 + 1], delta = delta_s;
+  float acc[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const long base = ((long)b * N + n) * 2 * H * D + h * D;
+    const float p = expf(logits[(long)row * N + n] - m) / tot;
+    float dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) dp += go[d] * kv[base + (long)H * D + d];
+    const float g = (glog ? glog[(long)row * N + n] : 0.f) + p * (dp - delta);
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] += g * kv[base + d];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float v = wave_sum(acc[d]);
+    if (lane == 0) red[wid * D + d] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    const int d = threadIdx.x;
+    gq[(long)row * D + d] = scale * (red[d] + red[D + d] + red[2 * D + d] + red[3 * D + d]);
+  }
+}
+
+}  // namespace icl

@@ -198,6 +198,33 @@ class InherentConsistent(nn.Module):
             self.query_convs.append(Conv1d(c, c // 2, device))
         self.guided_Q = nn.Parameter(torch.zeros(1, num_classes, in_chans[0], device=device))
 
+    def forward_labeled_pair(self, feats_a, feats_b):
+        """``self(feats_a, 'labeled')`` and ``self(feats_b, 'labeled')`` in lock step (the two ``sspa`` calls of
+        unet_3D_icl.py:144-145 share their weights).  Everything up to the attention maps is per-sample, so both inputs
+        go through the token projection / Class_Decoder as ONE batch: the 13,824^2 ``mlp2`` weights (1.5 GB per call)
+        are streamed twice per step instead of three times and their gradient is produced by one GEMM instead of two
+        plus an accumulation.  The BatchNorm layers of ``attn_convs0`` (batch statistics) and the per-call batch means
+        ``updated_Qs`` are still evaluated per input, in the reference order (a, then b)."""
+        ba = feats_a[0].shape[0]
+        bs = ba + feats_b[0].shape[0]
+        maps_a, maps_b, qs_a, qs_b = [], [], [], []
+        nxt = self.guided_Q.expand(bs, -1, -1)
+        for i in range(len(self.depth)):
+            f = torch.cat([feats_a[i], feats_b[i]], 0)
+            tok = self.norm_layers[i](self.proj_layers[i](f).flatten(2).transpose(1, 2))
+            q_out, attn = self.class_decoders[i](nxt, tok)
+            b, nc, h, n = attn.shape
+            r = self.resolutions[i]
+            a = attn.contiguous().view(b, nc, h, r, r, r)
+            for part, maps, qs in ((a[:ba], maps_a, qs_a), (a[ba:], maps_b, qs_b)):
+                pb = part.shape[0]
+                m = self.attn_convs1[i](self.attn_convs0[i](part.reshape(pb * nc, h, r, r, r)))
+                maps.append(m.reshape(pb, nc, r, r, r))
+            nxt = self.query_convs[i](q_out)
+            qs_a.append(q_out[:ba].mean(dim=0, keepdim=True))
+            qs_b.append(q_out[ba:].mean(dim=0, keepdim=True))
+        return (maps_a, qs_a), (maps_b, qs_b)
+
     def forward(self, feats, guided_Q=None, modal="labeled"):
         bs = feats[0].shape[0]
         feat_maps, updated_qs = [], []

@@ -36,8 +36,7 @@ class unet_3D_icl(UNet3DBackbone):  # noqa: N801 — reference class name
         final_lab, final_unlab = final[:bl], final[bl:]
         feats_lab = [f[:bl] for f in feats]
         feats_unlab = [f[bl:] for f in feats]
-        feat_maps_lab, updated_qs_lab = self.sspa(feats_lab, "labeled")
-        feat_maps_consis, _ = self.sspa(feats_unlab, "labeled")
+        (feat_maps_lab, updated_qs_lab), (feat_maps_consis, _) = self.sspa.forward_labeled_pair(feats_lab, feats_unlab)
         feat_maps_unlab, _ = self.uscl(feats_unlab, updated_qs_lab, "unlabeled")
         return final_lab, final_unlab, feat_maps_lab, feat_maps_unlab, feat_maps_consis
 

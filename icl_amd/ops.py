@@ -429,33 +429,112 @@ def dropout(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Tens
 
 
 # --------------------------------------------------------------------------------------
-# Aligner token ops (Linear / LayerNorm / GELU / prototype attention), unet_3D_icl.py:244-315.
-# STOP-GAP: these four still dispatch to ATen/rocBLAS on the device; DESIGN.md tracks their
-# replacement by HIP kernels (skinny weight-streaming GEMM for mlp2, fused LN, fused attention).
+# Aligner token ops (unet_3D_icl.py:244-315): LayerNorm, GELU and the prototype attention are HIP kernels
+# (csrc/kernels/token.h); the Linear layers (incl. the 13,824^2 mlp2) are plain library GEMMs on rocBLAS, which
+# measure 5.8 TB/s on the weight stream of the skinny mlp2 products (profiles/) — already at the HBM roofline.
 # --------------------------------------------------------------------------------------
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     return torch.nn.functional.linear(x, weight, bias)
 
 
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _require(x, weight, bias)
+        L = _lib.lib()
+        x = x.contiguous()
+        c = x.shape[-1]
+        rows = x.numel() // c
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _lib.check(L.icl_layernorm_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(mean), _ptr(rstd), rows, c, eps, _stream(x)),
+                   "layernorm_fwd")
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        L = _lib.lib()
+        gy = gy.contiguous()
+        c = x.shape[-1]
+        rows = x.numel() // c
+        gx = torch.empty_like(x)
+        dg = torch.empty_like(weight)
+        db = torch.empty_like(weight)
+        _lib.check(L.icl_layernorm_bwd(_ptr(gy), _ptr(x), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dg), _ptr(db), rows, c,
+                                       _stream(x)), "layernorm_bwd")
+        return gx, dg, db, None
+
+
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    return torch.nn.functional.layer_norm(x, (weight.shape[0],), weight, bias, eps)
+    return _LayerNorm.apply(x, weight, bias, eps)
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require(x)
+        L = _lib.lib()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(L.icl_gelu_fwd(_ptr(x), _ptr(y), x.numel(), _stream(x)), "gelu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        L = _lib.lib()
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        _lib.check(L.icl_gelu_bwd(_ptr(gy), _ptr(x), _ptr(gx), x.numel(), _stream(x)), "gelu_bwd")
+        return gx
 
 
 def gelu(x: torch.Tensor) -> torch.Tensor:
-    return torch.nn.functional.gelu(x)
+    return _Gelu.apply(x)
+
+
+class _ProtoAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qh, kv, heads, scale):
+        _require(qh, kv)
+        L = _lib.lib()
+        qh = qh.contiguous()
+        kv = kv.contiguous()
+        B, h, nc, d = qh.shape
+        N = kv.shape[1]
+        assert h == heads and kv.shape[2] == 2 * h * d
+        logits = torch.empty((B, h, nc, N), dtype=torch.float32, device=qh.device)
+        out = torch.empty((B, h, nc, d), dtype=torch.float32, device=qh.device)
+        stats = torch.empty((B, h, nc, 2), dtype=torch.float32, device=qh.device)
+        _lib.check(L.icl_attn_fwd(_ptr(qh), _ptr(kv), _ptr(logits), _ptr(out), _ptr(stats), B, h, nc, N, d, scale, _stream(qh)), "attn_fwd")
+        ctx.save_for_backward(qh, kv, logits, stats, out)
+        ctx.scale = scale
+        return out, logits
+
+    @staticmethod
+    def backward(ctx, gout, glog):
+        qh, kv, logits, stats, out = ctx.saved_tensors
+        L = _lib.lib()
+        B, h, nc, d = qh.shape
+        N = kv.shape[1]
+        gout = gout.contiguous() if gout is not None else None
+        glog = glog.contiguous() if glog is not None else None
+        gq = torch.empty_like(qh)
+        gkv = torch.empty_like(kv)
+        _lib.check(L.icl_attn_bwd(_ptr(qh), _ptr(kv), _ptr(logits), _ptr(stats), _ptr(out), _ptr(gout), _ptr(glog), _ptr(gq), _ptr(gkv),
+                                  B, h, nc, N, d, ctx.scale, _stream(qh)), "attn_bwd")
+        return gq, gkv, None, None
 
 
 def prototype_attention(qh: torch.Tensor, kv: torch.Tensor, heads: int, scale: float):
     """qh [B,h,nc,d]; kv [B,N,2*h*d] laid out (k|v, head, d).  Returns (softmax(QK^T*scale) V  [B,h,nc,d],
     scaled pre-softmax logits [B,h,nc,N])."""
-    B, N, C2 = kv.shape
-    d = C2 // (2 * heads)
-    kvp = kv.reshape(B, N, 2, heads, d).permute(2, 0, 3, 1, 4)
-    k, v = kvp[0], kvp[1]
-    logits = (qh @ k.transpose(-2, -1)) * scale
-    out = logits.softmax(dim=-1) @ v
-    return out, logits
+    return _ProtoAttention.apply(qh, kv, heads, float(scale))
 
 
 # --------------------------------------------------------------------------------------

@@ -90,6 +90,24 @@ int icl_loss_bwd(const float* a, const float* b, const int64_t* labels, const fl
                  const float* gout, float* coef, float* ga, int batch, int nc, int64_t s, int mode, int a_is_prob,
                  void* stream);
 
+/* ---- aligner token operators (networks/unet_3D_icl.py:244-315)
+ * LayerNorm over the last axis c of [rows, c] (nn.LayerNorm, eps 1e-5); mean/rstd [rows] are saved for the backward;
+ * dgamma/dbeta (may both be NULL) are overwritten.  GELU is the exact erf form (nn.GELU default). */
+int icl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows,
+                      int c, float eps, void* stream);
+int icl_layernorm_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* rstd, float* gx,
+                      float* dgamma, float* dbeta, int64_t rows, int c, void* stream);
+int icl_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int icl_gelu_bwd(const float* gy, const float* x, float* gx, int64_t n, void* stream);
+/* Prototype cross-attention of Query_Attention.forward (:283-297): q [B,h,nc,d] (reshape-quirk layout of fc_q's output),
+ * kv [B,N,2,h,d] (fc_kv output).  logits [B,h,nc,N] = scale*q.k (the pre-softmax map the reference returns),
+ * out [B,h,nc,d] = softmax_N(logits) @ v, stats [B,h,nc,2] = (row max, sum exp).  d in {8,16}, nc <= 16.
+ * Backward: gout / glog (either may be NULL) are the upstream gradients of out / logits. */
+int icl_attn_fwd(const float* q, const float* kv, float* logits, float* out, float* stats, int b, int h, int nc, int n, int d,
+                 float scale, void* stream);
+int icl_attn_bwd(const float* q, const float* kv, const float* logits, const float* stats, const float* out, const float* gout,
+                 const float* glog, float* gq, float* gkv, int b, int h, int nc, int n, int d, float scale, void* stream);
+
 /* ---- fused SGD(momentum, weight decay) step, torch.optim.SGD semantics (train_inherent_consistent_unet_3D_BraTS.py:85-86,115):
  * d = g + wd*p; m = first ? d : momentum*m + d; p -= lr*m.  The multi form takes HOST arrays of device pointers. */
 int icl_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float weight_decay, int first,

@@ -149,6 +149,75 @@ def test_upsample_concat_and_depthwise_and_dropout(dev):
     assert torch.equal(x.grad != 0, y.detach() != 0)
 
 
+def test_token_ops_and_losses_and_sgd(dev):
+    """LayerNorm / GELU / prototype attention / fused losses / FusedSGD against torch-CPU expressions of the oracle."""
+    from icl_amd import ops
+    from icl_amd.optim import FusedSGD
+    # LayerNorm + GELU, short rows and the 13,824-long token rows of norm3
+    for shape in [(2, 1728, 128), (16, 13824)]:
+        c = shape[-1]
+        x, w, b, gy = _rand(shape, 61) * 2 + 0.3, 1 + 0.1 * _rand((c,), 62), 0.1 * _rand((c,), 63), _rand(shape, 64)
+        xg, wg, bg = (t.to(dev).requires_grad_() for t in (x, w, b))
+        y = ops.gelu(ops.layer_norm(xg, wg, bg))
+        y.backward(gy.to(dev))
+        xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+        yr = F.gelu(F.layer_norm(xr, (c,), wr, br, 1e-5))
+        yr.backward(gy)
+        assert rel_err(y.detach().cpu(), yr.detach()) < 1e-5
+        assert rel_err(xg.grad.cpu(), xr.grad) < 1e-4 and rel_err(wg.grad.cpu(), wr.grad) < 1e-4 and rel_err(bg.grad.cpu(), br.grad) < 1e-4
+    # prototype attention at the three aligner scales (nc = 2 and 16)
+    for B, h, nc, d, N in [(2, 16, 2, 16, 216), (1, 8, 16, 16, 1728), (2, 4, 2, 16, 13824)]:
+        C = h * d
+        qh, kv = _rand((B, h, nc, d), 71), _rand((B, N, 2 * C), 72)
+        go, gl = _rand((B, h, nc, d), 73), _rand((B, h, nc, N), 74)
+        qg, kg = qh.to(dev).requires_grad_(), kv.to(dev).requires_grad_()
+        out, logits = ops.prototype_attention(qg, kg, h, d ** -0.5)
+        ((out * go.to(dev)).sum() + (logits * gl.to(dev)).sum()).backward()
+        qr, kr = qh.clone().requires_grad_(), kv.clone().requires_grad_()
+        kvp = kr.reshape(B, N, 2, h, d).permute(2, 0, 3, 1, 4)
+        lr = (qr @ kvp[0].transpose(-2, -1)) * d ** -0.5
+        orf = lr.softmax(dim=-1) @ kvp[1]
+        ((orf * go).sum() + (lr * gl).sum()).backward()
+        assert rel_err(out.detach().cpu(), orf.detach()) < 1e-5 and rel_err(logits.detach().cpu(), lr.detach()) < 1e-5
+        assert rel_err(qg.grad.cpu(), qr.grad) < 1e-4 and rel_err(kg.grad.cpu(), kr.grad) < 1e-4
+    # fused losses at 96^3, nc = 2 and 16 (oracle functions are the expected values)
+    from oracle import icl_oracle as O
+    for nc in (2, 16):
+        lab = synthetic_labels((1, 96, 96, 96), 61, nc)
+        a, b2 = _rand((1, nc, 96, 96, 96), 62), _rand((1, nc, 96, 96, 96), 63)
+        ag = a.to(dev).requires_grad_()
+        ce, dc = ops.cross_entropy_dice_parts(ag, lab.to(dev), nc)
+        sd, ms = ops.soft_dice_loss(ag, b2.to(dev)), ops.softmax_mse(ag, b2.to(dev))
+        (ce + dc + sd + 10 * ms).backward()
+        ar = a.clone().requires_grad_()
+        cer = F.cross_entropy(ar, lab)
+        dcr = O.dice_loss(ar, lab.unsqueeze(1), nc, softmax=True)
+        sdr = O.softmax_dice_loss(ar, b2)
+        msr = torch.mean((F.softmax(ar, 1) - F.softmax(b2, 1)) ** 2)
+        (cer + dcr + sdr + 10 * msr).backward()
+        for got, ref in ((ce, cer), (dc, dcr), (sd, sdr), (ms, msr)):
+            assert abs(float(got) - float(ref)) < 1e-5
+        assert rel_err(ag.grad.cpu(), ar.grad) < 1e-4
+    # FusedSGD == torch.optim.SGD over three steps, including a parameter that never gets a gradient
+    torch.manual_seed(0)
+    shapes = [(5, 7), (33,), (3 << 20,), (3, 3, 3, 2, 2), (1,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    skip = torch.nn.Parameter(torch.randn(4, device=dev))
+    skip0 = skip.detach().clone()
+    fa = FusedSGD(ps + [skip], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    fb = torch.optim.SGD(qs, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    for it in range(3):
+        for p, q in zip(ps, qs):
+            g = torch.randn(q.shape)
+            p.grad, q.grad = g.to(dev), g.clone()
+        fa.step()
+        fb.step()
+    for p, q in zip(ps, qs):
+        assert rel_err(p.detach().cpu(), q.detach()) < 1e-6
+    assert torch.equal(skip.detach(), skip0)
+
+
 def test_plain_unet3d_matches_reference_golden(dev):
     from icl_amd.networks.unet_3D import unet_3D
     g = load_golden("unit.npz")

@@ -237,3 +237,35 @@ def test_fused_sgd_matches_torch():
     for p, q in zip(ps, qs):
         assert rel_err(p.detach(), q.detach()) < 1e-6
     assert torch.equal(skip.detach(), skip_ref)
+
+
+def test_layernorm_gelu():
+    x = (_rand((3, 5, 37), 61) * 2 + 0.3).requires_grad_()
+    w = (1 + 0.1 * _rand((37,), 62)).requires_grad_()
+    b = (0.1 * _rand((37,), 63)).requires_grad_()
+    gy = _rand((3, 5, 37), 64)
+    y = ops.gelu(ops.layer_norm(x, w, b))
+    y.backward(gy)
+    xr, wr, br = (t.detach().clone().requires_grad_() for t in (x, w, b))
+    yr = F.gelu(F.layer_norm(xr, (37,), wr, br, 1e-5))
+    yr.backward(gy)
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    assert rel_err(x.grad, xr.grad) < 1e-4 and rel_err(w.grad, wr.grad) < 1e-4 and rel_err(b.grad, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,h,nc,d,N", [(2, 2, 3, 8, 70), (1, 4, 2, 16, 300), (1, 1, 16, 16, 64)])
+def test_prototype_attention(B, h, nc, d, N):
+    C = h * d
+    qh = _rand((B, h, nc, d), 71, True)
+    kv = _rand((B, N, 2 * C), 72, True)
+    go, gl = _rand((B, h, nc, d), 73), _rand((B, h, nc, N), 74)
+    scale = d ** -0.5
+    out, logits = ops.prototype_attention(qh, kv, h, scale)
+    ((out * go).sum() + (logits * gl).sum()).backward()
+    qr, kr = qh.detach().clone().requires_grad_(), kv.detach().clone().requires_grad_()
+    kvp = kr.reshape(B, N, 2, h, d).permute(2, 0, 3, 1, 4)
+    lr = (qr @ kvp[0].transpose(-2, -1)) * scale
+    orf = lr.softmax(dim=-1) @ kvp[1]
+    ((orf * go).sum() + (lr * gl).sum()).backward()
+    assert rel_err(out.detach(), orf.detach()) < 1e-5 and rel_err(logits.detach(), lr.detach()) < 1e-5
+    assert rel_err(qh.grad, qr.grad) < 1e-4 and rel_err(kv.grad, kr.grad) < 1e-4
