@@ -61,20 +61,30 @@ __global__ __launch_bounds__(kNormThreads) void rowstats_partial_kernel(
   }
 }
 
-// One thread per group: merge chunk summaries of every row in the group.
-// groups = R (instance) or C (batch).  Optionally updates BatchNorm running stats.
-__global__ void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean,
-                                      float* __restrict__ rstd, int R, int C, int nchunks, int batch_mode,
-                                      float eps, float* running_mean, float* running_var, float momentum) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+// One WAVE per group: lanes merge the chunk summaries of every row in the group, then a shuffle tree.
+// groups = R (instance) or C (batch).  Optionally updates BatchNorm running stats.  grid = ceil(groups/4), block 256.
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int R, int C, int nchunks, int batch_mode,
+                                                             float eps, float* running_mean, float* running_var, float momentum) {
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   const int groups = batch_mode ? C : R;
   if (g >= groups) return;
   float n = 0.f, m = 0.f, q = 0.f;
   const int step = batch_mode ? C : R;
-  for (int r = g; r < R; r += step) {
-    const float* p = part + (long)r * nchunks * 3;
-    for (int ch = 0; ch < nchunks; ++ch) welford_merge(n, m, q, p[ch * 3], p[ch * 3 + 1], p[ch * 3 + 2]);
+  const int nrows = (R - g + step - 1) / step;
+  const long items = (long)nrows * nchunks;
+  for (long it = lane; it < items; it += 64) {
+    const int r = g + (int)(it / nchunks) * step;
+    const float* p = part + ((long)r * nchunks + it % nchunks) * 3;
+    welford_merge(n, m, q, p[0], p[1], p[2]);
   }
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) {
+    const float nb = __shfl_xor(n, sh, 64), mb = __shfl_xor(m, sh, 64), qb = __shfl_xor(q, sh, 64);
+    welford_merge(n, m, q, nb, mb, qb);
+  }
+  if (lane != 0) return;
   const float var = q / n;  // biased, as the normalisation uses
   mean[g] = m;
   rstd[g] = 1.0f / sqrtf(var + eps);

@@ -6,58 +6,74 @@
 
 namespace icl {
 
-// ---------------------------------------------------------------- LayerNorm over the last axis, one wave per row
+// ---------------------------------------------------------------- LayerNorm over the last axis
+// BLOCKROW = false: one wave per row (token rows, C = 64..256); true: one workgroup per row (the 13,824-long rows of norm3)
+template <bool BLOCKROW>
+__device__ __forceinline__ float team_sum(float v, float* red) {
+  if (BLOCKROW) return block_sum<256>(v, red);
+  return wave_sum(v);
+}
+
+template <bool BLOCKROW>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, long rows, int C, float eps) {
-  const int lane = threadIdx.x & 63;
-  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ float red[4];
+  const int lane = BLOCKROW ? threadIdx.x : (threadIdx.x & 63);
+  const int stride = BLOCKROW ? 256 : 64;
+  const long r = BLOCKROW ? (long)blockIdx.x : (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const float* xr = x + r * C;
   float s = 0.f;
-  for (int c = lane; c < C; c += 64) s += xr[c];
-  const float m = wave_sum(s) / (float)C;
+  for (int c = lane; c < C; c += stride) s += xr[c];
+  const float m = team_sum<BLOCKROW>(s, red) / (float)C;
   float q = 0.f;
-  for (int c = lane; c < C; c += 64) { const float d = xr[c] - m; q += d * d; }
-  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  for (int c = lane; c < C; c += stride) { const float d = xr[c] - m; q += d * d; }
+  const float rs = 1.0f / sqrtf(team_sum<BLOCKROW>(q, red) / (float)C + eps);
   float* yr = y + r * C;
-  for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - m) * rs * gamma[c] + beta[c];
+  for (int c = lane; c < C; c += stride) yr[c] = (xr[c] - m) * rs * gamma[c] + beta[c];
   if (lane == 0) { mean[r] = m; rstd[r] = rs; }
 }
 
 // gx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = gy*gamma
+template <bool BLOCKROW>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ gx, long rows, int C) {
-  const int lane = threadIdx.x & 63;
-  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ float red[4];
+  const int lane = BLOCKROW ? threadIdx.x : (threadIdx.x & 63);
+  const int stride = BLOCKROW ? 256 : 64;
+  const long r = BLOCKROW ? (long)blockIdx.x : (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const float* xr = x + r * C;
   const float* gr = gy + r * C;
   const float m = mean[r], rs = rstd[r];
   float s1 = 0.f, s2 = 0.f;
-  for (int c = lane; c < C; c += 64) {
+  for (int c = lane; c < C; c += stride) {
     const float g = gr[c] * gamma[c];
     s1 += g;
     s2 += g * (xr[c] - m) * rs;
   }
-  s1 = wave_sum(s1) / (float)C;
-  s2 = wave_sum(s2) / (float)C;
+  s1 = team_sum<BLOCKROW>(s1, red) / (float)C;
+  s2 = team_sum<BLOCKROW>(s2, red) / (float)C;
   float* o = gx + r * C;
-  for (int c = lane; c < C; c += 64) o[c] = rs * (gr[c] * gamma[c] - s1 - (xr[c] - m) * rs * s2);
+  for (int c = lane; c < C; c += stride) o[c] = rs * (gr[c] * gamma[c] - s1 - (xr[c] - m) * rs * s2);
 }
 
-// dgamma[c] += sum_rows gy*xhat, dbeta[c] += sum_rows gy  (pre-zeroed; grid (ceil(C/256), row chunks))
+// dgamma[c] += sum_rows gy*xhat, dbeta[c] += sum_rows gy  (pre-zeroed).  A workgroup covers `cols` = min(C,256)
+// columns x (256/cols) row lanes so that short rows still read full 256-byte lines; grid (ceil(C/cols), row chunks).
 __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C,
-                                                              long rows_per_block) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+                                                              long rows_per_block, int cols) {
+  const int lanes = 256 / cols;
+  const int c = blockIdx.x * cols + threadIdx.x % cols;
+  const int rl = threadIdx.x / cols;
+  if (c >= C || rl >= lanes) return;
   const long r0 = (long)blockIdx.y * rows_per_block;
   const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float a = 0.f, b = 0.f;
-  for (long r = r0; r < r1; ++r) {
+  for (long r = r0 + rl; r < r1; r += lanes) {
     const float g = gy[r * C + c];
     a += g * (x[r * C + c] - mean[r]) * rstd[r];
     b += g;
