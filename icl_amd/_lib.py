@@ -22,6 +22,7 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 _SIGNATURES = {
     "icl_abi_version": (c_int, []),
     "icl_last_error": (c_char_p, []),
+    "icl_last_kernel_name": (c_char_p, []),
     "icl_conv3d_packed_elems": (c_int64, [I, I, I, I]),
     "icl_conv3d_pack_weights": (c_int, [P, P, I, I, I, I, P]),
     "icl_conv3d_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, I, L, L, P]),

@@ -75,7 +75,12 @@ class _TimedRegion:
 
     def __exit__(self, *a):
         self.e1.record(torch.cuda.current_stream(self.like.device))
-        self.kt.records.append((self.name, self.e0, self.e1, self.flops, self.nbytes))
+        name = self.name
+        if name.startswith("conv3d"):  # the launcher reports which template instantiation it picked
+            kn = _lib.lib().icl_last_kernel_name()
+            if kn:
+                name = kn.decode()
+        self.kt.records.append((name, self.e0, self.e1, self.flops, self.nbytes))
 
 
 class _NullRegion:

@@ -22,6 +22,8 @@ extern "C" {
 
 int icl_abi_version(void);
 const char* icl_last_error(void);
+/* name of the convolution kernel instantiation picked by the most recent icl_conv3d_* call on this thread (profiling aid) */
+const char* icl_last_kernel_name(void);
 
 /* ---- Conv3d k=3 pad=1 / k=1, stride 1 (networks/utils.py:104,107; networks/unet_3D_icl.py:65,178,196,327).
  * Weights are used in packed form Wp[taps][KP][NP]: mode 0 (forward) K=Cin,N=Cout; mode 1 (dgrad) K=Cout,N=Cin
