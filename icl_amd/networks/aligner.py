@@ -198,6 +198,12 @@ class InherentConsistent(nn.Module):
             self.query_convs.append(Conv1d(c, c // 2, device))
         self.guided_Q = nn.Parameter(torch.zeros(1, num_classes, in_chans[0], device=device))
 
+    def _tokens(self, i, feat):
+        """``proj_layers[i](feat).flatten(2).transpose(1, 2)`` (:212): a 1x1x1 convolution followed by the token transpose is
+        one GEMM on the channel axis, ``feat^T W^T + b`` -> [B, N, C] — a plain library GEMM (rocBLAS), no transpose copy."""
+        p = self.proj_layers[i]
+        return ops.linear(feat.flatten(2).transpose(1, 2), p.weight.flatten(1), p.bias)
+
     def forward_labeled_pair(self, feats_a, feats_b):
         """``self(feats_a, 'labeled')`` and ``self(feats_b, 'labeled')`` in lock step (the two ``sspa`` calls of
         unet_3D_icl.py:144-145 share their weights).  Everything up to the attention maps is per-sample, so both inputs
@@ -211,7 +217,7 @@ class InherentConsistent(nn.Module):
         nxt = self.guided_Q.expand(bs, -1, -1)
         for i in range(len(self.depth)):
             f = torch.cat([feats_a[i], feats_b[i]], 0)
-            tok = self.norm_layers[i](self.proj_layers[i](f).flatten(2).transpose(1, 2))
+            tok = self.norm_layers[i](self._tokens(i, f))
             q_out, attn = self.class_decoders[i](nxt, tok)
             b, nc, h, n = attn.shape
             r = self.resolutions[i]
@@ -230,7 +236,7 @@ class InherentConsistent(nn.Module):
         feat_maps, updated_qs = [], []
         nxt = self.guided_Q.expand(bs, -1, -1) if modal == "labeled" else None
         for i in range(len(self.depth)):
-            tok = self.proj_layers[i](feats[i]).flatten(2).transpose(1, 2)
+            tok = self._tokens(i, feats[i])
             tok = self.norm_layers[i](tok)
             q_in = nxt if modal == "labeled" else guided_Q[i].expand(bs, -1, -1)
             q_out, attn = self.class_decoders[i](q_in, tok)
