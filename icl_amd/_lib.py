@@ -32,11 +32,11 @@ _SIGNATURES = {
     "icl_norm_fwd": (c_int, [P, P, P, P, P, P, P, P, I, I, L, I, I, I, F, F, P, P]),
     "icl_norm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, L, I, I, I, P, P]),
     "icl_rstd_from_var": (c_int, [P, P, I, F, P]),
-    "icl_maxpool2_fwd": (c_int, [P, P, P, L, I, I, I, P]),
-    "icl_maxpool2_bwd": (c_int, [P, P, P, L, I, I, I, P]),
-    "icl_trilinear_fwd": (c_int, [P, P, I, I, I, I, I, I, I, I, L, P]),
+    "icl_maxpool2_fwd": (c_int, [P, P, P, L, I, I, I, I, P]),
+    "icl_maxpool2_bwd": (c_int, [P, P, P, L, I, I, I, I, P]),
+    "icl_trilinear_fwd": (c_int, [P, P, I, I, I, I, I, I, I, I, L, I, P]),
     "icl_trilinear_bwd_ws_bytes": (c_int64, [I, I, I, I, I, I, I, I]),
-    "icl_trilinear_bwd": (c_int, [P, P, P, I, I, I, I, I, I, I, I, L, P]),
+    "icl_trilinear_bwd": (c_int, [P, P, P, I, I, I, I, I, I, I, I, L, I, P]),
     "icl_copy_rows": (c_int, [P, P, L, L, L, L, P]),
     "icl_dwconv3_fwd": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "icl_dwconv3_wgrad": (c_int, [P, P, P, I, I, I, I, I, P]),

@@ -101,7 +101,7 @@ __global__ void rstd_from_var_kernel(const float* __restrict__ var, float* __res
   if (c < C) rstd[c] = 1.0f / sqrtf(var[c] + eps);
 }
 
-// y = act(((x-mean[g])*rstd[g]) * gamma[c] + beta[c]); act 0 = identity, 1 = ReLU.
+// y = act(((x-mean[g])*rstd[g]) * gamma[c] + beta[c]); act 0 = identity, 1 = ReLU, 2 = LeakyReLU(0.01) (nn.LeakyReLU default).
 // grid (nchunks, R)
 __global__ __launch_bounds__(kNormThreads) void norm_act_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
@@ -123,13 +123,14 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_fwd_kernel(
     for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += kNormThreads) {
       float4 v = x4[i];
       v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
-      if (act) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      else if (act == 2) { v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y; v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w; }
       y4[i] = v;
     }
   } else {
     for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
       float v = xr[i] * sc + sh;
-      yr[i] = act ? fmaxf(v, 0.f) : v;
+      yr[i] = act == 1 ? fmaxf(v, 0.f) : (act == 2 && v < 0.f ? 0.01f * v : v);
     }
   }
 }
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_partial_kernel(
   for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
     const float xh = (xr[i] - m) * rs;
     float h = gr[i];
-    if (act && !(xh * ga + be > 0.f)) h = 0.f;
+    if (act && !(xh * ga + be > 0.f)) h = (act == 2) ? 0.01f * h : 0.f;
     p1 += h;
     p2 += h * xh;
   }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_apply_kernel(
   for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
     const float xh = (xr[i] - m) * rs;
     float h = gr[i];
-    if (act && !(xh * ga + be > 0.f)) h = 0.f;
+    if (act && !(xh * ga + be > 0.f)) h = (act == 2) ? 0.01f * h : 0.f;
     o[i] = k * (h - a1 - xh * a2);
   }
 }

@@ -1,19 +1,21 @@
-// pool_resize.h — MaxPool3d(2), trilinear resize (align_corners=False) and strided row copy.
+// pool_resize.h — MaxPool3d(2) / MaxPool2d(2), (tri/bi)linear resize and strided row copy.
 //
-// Reference ops: nn.MaxPool3d(kernel_size=2) (/root/reference/code/networks/unet_3D_icl.py:41-53),
-// nn.Upsample(scale_factor=2, mode='trilinear') in UnetUp3_CT (networks/utils.py:264) and
-// F.interpolate(size=[96,96,96], mode='trilinear') in the losses (utils/losses.py:263,292).
-// All HBM-bound; x is the fastest index everywhere so loads/stores coalesce.
+// Reference ops: nn.MaxPool3d(kernel_size=2) (/root/reference/code/networks/unet_3D_icl.py:41-53), nn.MaxPool2d(2)
+// (networks/unet_icl.py:64), nn.Upsample(scale_factor=2, mode='trilinear') in UnetUp3_CT (networks/utils.py:264),
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) in the 2D UpBlock (networks/unet_icl.py:84-85)
+// and F.interpolate(size=..., mode='trilinear'|'bilinear') in the losses (utils/losses.py:245,263,281,292).
+// 2-D tensors are handled as D = 1 volumes.  All HBM-bound; x is the fastest index so loads/stores coalesce.
 #pragma once
 
 namespace icl {
 
-// ---- MaxPool3d 2x2x2, stride 2 (even extents).  idx = argmax in (dz,dy,dx) scan order with
-// strict '>' so the first maximum wins, as ATen's max_pool3d does.
+// ---- max pooling, window pd x 2 x 2 (pd = 2: MaxPool3d(2); pd = 1: MaxPool2d(2) on a D=1 volume), stride = window.
+// idx = argmax in (dz,dy,dx) scan order with strict '>' so the first maximum wins, as ATen's max_pool does.
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                           unsigned char* __restrict__ idx, long NC, int Do, int Ho, int Wo) {
+                                                           unsigned char* __restrict__ idx, long NC, int Do, int Ho, int Wo, int pd) {
   const long total = NC * Do * Ho * Wo;
   const int H = Ho * 2, W = Wo * 2;
+  const int nk = 4 * pd;
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
     const int ox = (int)(o % Wo);
     long t = o / Wo;
@@ -21,11 +23,10 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
     t /= Ho;
     const int oz = (int)(t % Do);
     const long nc = t / Do;
-    const float* p = x + ((nc * (Do * 2) + oz * 2) * H + oy * 2) * (long)W + ox * 2;
+    const float* p = x + ((nc * (Do * pd) + oz * pd) * H + oy * 2) * (long)W + ox * 2;
     float best = p[0];
     int bi = 0;
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
+    for (int k = 1; k < nk; ++k) {
       const float v = p[((k >> 2) * H + ((k >> 1) & 1)) * (long)W + (k & 1)];
       if (v > best) { best = v; bi = k; }
     }
@@ -35,9 +36,10 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ idx,
-                                                           float* __restrict__ gx, long NC, int Do, int Ho, int Wo) {
+                                                           float* __restrict__ gx, long NC, int Do, int Ho, int Wo, int pd) {
   const long total = NC * Do * Ho * Wo;
   const int H = Ho * 2, W = Wo * 2;
+  const int nk = 4 * pd;
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
     const int ox = (int)(o % Wo);
     long t = o / Wo;
@@ -45,22 +47,23 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
     t /= Ho;
     const int oz = (int)(t % Do);
     const long nc = t / Do;
-    float* p = gx + ((nc * (Do * 2) + oz * 2) * H + oy * 2) * (long)W + ox * 2;
+    float* p = gx + ((nc * (Do * pd) + oz * pd) * H + oy * 2) * (long)W + ox * 2;
     const float g = gy[o];
     const int bi = idx[o];
-#pragma unroll
-    for (int k = 0; k < 8; k += 2) {
+    for (int k = 0; k < nk; k += 2) {
       float2 v = make_float2(bi == k ? g : 0.f, bi == k + 1 ? g : 0.f);
       *reinterpret_cast<float2*>(p + ((k >> 2) * H + ((k >> 1) & 1)) * (long)W) = v;
     }
   }
 }
 
-// ---- trilinear, align_corners=False: ATen's area_pixel_compute_source_index
-//   src = rscale*(dst+0.5)-0.5, clamped at 0;  i0 = floor(src), i1 = i0 + (i0 < in-1), l1 = src-i0, l0 = 1-l1
+// ---- linear interpolation taps along one axis, ATen's area_pixel_compute_source_index:
+//   align_corners=False: src = rscale*(dst+0.5)-0.5 clamped at 0, rscale = in/out
+//   align_corners=True : src = rscale*dst,                         rscale = (in-1)/(out-1)  (0 when out == 1)
+//   i0 = floor(src), i1 = i0 + (i0 < in-1), l1 = src-i0, l0 = 1-l1
 struct LinTap { int i0, i1; float l0, l1; };
-__device__ __forceinline__ LinTap lin_tap(int dst, float rscale, int in_size) {
-  float src = rscale * ((float)dst + 0.5f) - 0.5f;
+__device__ __forceinline__ LinTap lin_tap(int dst, float rscale, int in_size, int align) {
+  float src = align ? rscale * (float)dst : rscale * ((float)dst + 0.5f) - 0.5f;
   if (src < 0.f) src = 0.f;
   LinTap t;
   t.i0 = (int)src;
@@ -75,7 +78,7 @@ __device__ __forceinline__ LinTap lin_tap(int dst, float rscale, int in_size) {
 // channel slice of a concat buffer).  x is dense [N][C][Di][Hi][Wi].
 __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C,
                                                             int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-                                                            float rz, float ry, float rx, long y_bstride) {
+                                                            float rz, float ry, float rx, long y_bstride, int align) {
   const long per_n = (long)C * Do * Ho * Wo;
   const long total = (long)N * per_n;
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restr
     t /= Do;
     const int c = (int)(t % C);
     const int n = (int)(t / C);
-    const LinTap tz = lin_tap(oz, rz, Di), ty = lin_tap(oy, ry, Hi), tx = lin_tap(ox, rx, Wi);
+    const LinTap tz = lin_tap(oz, rz, Di, align), ty = lin_tap(oy, ry, Hi, align), tx = lin_tap(ox, rx, Wi, align);
     const float* p = x + ((long)n * C + c) * Di * Hi * Wi;
     const long z0 = (long)tz.i0 * Hi * Wi, z1 = (long)tz.i1 * Hi * Wi;
     const long y0 = (long)ty.i0 * Wi, y1 = (long)ty.i1 * Wi;
@@ -101,16 +104,22 @@ __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restr
 }
 
 // weight with which output index o contributes to input index i along one axis (exact transpose of lin_tap)
-__device__ __forceinline__ float lin_w(int o, int i, float rscale, int in_size) {
-  const LinTap t = lin_tap(o, rscale, in_size);
+__device__ __forceinline__ float lin_w(int o, int i, float rscale, int in_size, int align) {
+  const LinTap t = lin_tap(o, rscale, in_size, align);
   return (t.i0 == i ? t.l0 : 0.f) + (t.i1 == i ? t.l1 : 0.f);
 }
 
 // conservative [lo, hi] range of output indices that can touch input index i
-__device__ __forceinline__ void lin_range(int i, float rscale, int out_size, int& lo, int& hi) {
+__device__ __forceinline__ void lin_range(int i, float rscale, int out_size, int align, int& lo, int& hi) {
+  if (rscale <= 0.f) { lo = 0; hi = out_size - 1; return; }
   const float inv = 1.0f / rscale;
-  lo = (int)floorf(((float)i - 1.0f + 0.5f) * inv - 0.5f) - 1;
-  hi = (int)ceilf(((float)i + 1.0f + 0.5f) * inv - 0.5f) + 1;
+  if (align) {
+    lo = (int)floorf(((float)i - 1.0f) * inv) - 1;
+    hi = (int)ceilf(((float)i + 1.0f) * inv) + 1;
+  } else {
+    lo = (int)floorf(((float)i - 1.0f + 0.5f) * inv - 0.5f) - 1;
+    hi = (int)ceilf(((float)i + 1.0f + 0.5f) * inv - 0.5f) + 1;
+  }
   if (lo < 0) lo = 0;
   if (hi > out_size - 1) hi = out_size - 1;
 }
@@ -122,7 +131,7 @@ __device__ __forceinline__ void lin_range(int i, float rscale, int out_size, int
 // on tensors that are already 1/scale and 1/scale^2 of it: HBM traffic ~ (1 + 2/s + 2/s^2 + 1/s^3) reads
 // of dY instead of one gather per input voxel.  One thread per dst element, t fastest.
 __global__ __launch_bounds__(256) void resize_bwd_axis_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, long rows,
-                                                              int Li, int Lo, long inner, float rscale, long src_bstride) {
+                                                              int Li, int Lo, long inner, float rscale, long src_bstride, int align) {
   const long per_b = rows * Li * inner;
   const long total = (long)B * per_b;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -133,18 +142,18 @@ __global__ __launch_bounds__(256) void resize_bwd_axis_kernel(const float* __res
     const int i = (int)(r % Li);
     const long row = r / Li;
     int lo, hi;
-    lin_range(i, rscale, Lo, lo, hi);
+    lin_range(i, rscale, Lo, align, lo, hi);
     const float* p = src + b * src_bstride + (row * Lo) * inner + t;
     float acc = 0.f;
     for (int o = lo; o <= hi; ++o) {
-      const float w = lin_w(o, i, rscale, Li);
+      const float w = lin_w(o, i, rscale, Li, align);
       if (w != 0.f) acc += w * p[(long)o * inner];
     }
     dst[e] = acc;
   }
 }
 
-// dst[r*dst_stride + i] = src[r*src_stride + i], i < row_elems (row_elems % 4 == 0 fast path)
+// dst[r*dst_stride + i] = src[r*src_stride + i], i < row_elems
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows,
                                                         long row_elems, long src_stride, long dst_stride) {
   const long total = rows * row_elems;

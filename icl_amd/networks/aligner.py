@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .layers import Conv3d
+from .layers import Conv2d, Conv3d
 
 
 class Linear(nn.Module):
@@ -133,11 +133,12 @@ class Class_Decoder(nn.Module):  # noqa: N801
 class _SepBlock(nn.Module):
     """The ``block`` Sequential of SeparableConv3d(relu_first=False) (unet_3D_icl.py:336-343)."""
 
-    def __init__(self, planes, device=None):
+    def __init__(self, planes, device=None, dims=3):
         super().__init__()
-        self.depthwise = Conv3d(planes, planes, 3, bias=False, groups=planes, device=device)
+        conv = Conv3d if dims == 3 else Conv2d   # 2-D: SeparableConv2d, networks/unet_icl.py:98-126
+        self.depthwise = conv(planes, planes, 3, bias=False, groups=planes, device=device)
         self.bn_depth = BatchNorm3d(planes, device)
-        self.pointwise = Conv3d(planes, planes, 1, bias=False, device=device)
+        self.pointwise = conv(planes, planes, 1, bias=False, device=device)
         self.bn_point = BatchNorm3d(planes, device)
 
     def forward(self, x):
@@ -146,9 +147,9 @@ class _SepBlock(nn.Module):
 
 
 class SeparableConv3d(nn.Module):
-    def __init__(self, planes, device=None):
+    def __init__(self, planes, device=None, dims=3):
         super().__init__()
-        self.block = _SepBlock(planes, device)
+        self.block = _SepBlock(planes, device, dims)
 
     def forward(self, x):
         return self.block(x)
@@ -181,6 +182,8 @@ class InherentConsistent(nn.Module):
         super().__init__()
         self.in_chans, self.depth = tuple(in_chans), tuple(depths)
         self.resolutions = tuple(input_resolution)
+        self.dims = spatial_dims   # 3: unet_3D_icl.py:155-242; 2: unet_icl.py:253-340 (r^2 tokens, Conv2d/BatchNorm2d)
+        conv = Conv3d if spatial_dims == 3 else Conv2d
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
         self.proj_layers = nn.ModuleList()
         self.norm_layers = nn.ModuleList()
@@ -190,11 +193,11 @@ class InherentConsistent(nn.Module):
         self.query_convs = nn.ModuleList()
         for i in range(len(depths)):
             c, r, h = in_chans[i], input_resolution[i], num_heads[i]
-            self.proj_layers.append(Conv3d(c, c, 1, device=device))
+            self.proj_layers.append(conv(c, c, 1, device=device))
             self.norm_layers.append(LayerNorm(c, device))
             self.class_decoders.append(Class_Decoder(c, r ** spatial_dims, h, drop_path=dpr[1], device=device))
-            self.attn_convs0.append(SeparableConv3d(h, device))
-            self.attn_convs1.append(Conv3d(h, 1, 1, device=device))
+            self.attn_convs0.append(SeparableConv3d(h, device, spatial_dims))
+            self.attn_convs1.append(conv(h, 1, 1, device=device))
             self.query_convs.append(Conv1d(c, c // 2, device))
         self.guided_Q = nn.Parameter(torch.zeros(1, num_classes, in_chans[0], device=device))
 
@@ -221,11 +224,12 @@ class InherentConsistent(nn.Module):
             q_out, attn = self.class_decoders[i](nxt, tok)
             b, nc, h, n = attn.shape
             r = self.resolutions[i]
-            a = attn.contiguous().view(b, nc, h, r, r, r)
+            sp = (r,) * self.dims
+            a = attn.contiguous().view(b, nc, h, *sp)
             for part, maps, qs in ((a[:ba], maps_a, qs_a), (a[ba:], maps_b, qs_b)):
                 pb = part.shape[0]
-                m = self.attn_convs1[i](self.attn_convs0[i](part.reshape(pb * nc, h, r, r, r)))
-                maps.append(m.reshape(pb, nc, r, r, r))
+                m = self.attn_convs1[i](self.attn_convs0[i](part.reshape(pb * nc, h, *sp)))
+                maps.append(m.reshape(pb, nc, *sp))
             nxt = self.query_convs[i](q_out)
             qs_a.append(q_out[:ba].mean(dim=0, keepdim=True))
             qs_b.append(q_out[ba:].mean(dim=0, keepdim=True))
@@ -242,9 +246,10 @@ class InherentConsistent(nn.Module):
             q_out, attn = self.class_decoders[i](q_in, tok)
             b, nc, h, n = attn.shape
             r = self.resolutions[i]
-            a = attn.contiguous().view(b * nc, h, r, r, r)
+            sp = (r,) * self.dims
+            a = attn.contiguous().view(b * nc, h, *sp)
             a = self.attn_convs1[i](self.attn_convs0[i](a))
-            feat_maps.append(a.reshape(b, nc, r, r, r))
+            feat_maps.append(a.reshape(b, nc, *sp))
             nxt = self.query_convs[i](q_out)
             updated_qs.append(q_out.mean(dim=0, keepdim=True))
         return feat_maps, updated_qs

@@ -95,3 +95,44 @@ class Dropout3(nn.Module):
         if not self.training or self.p == 0.0:
             return x
         return ops.dropout(x, self.p)
+
+
+class Conv2d(nn.Module):
+    """nn.Conv2d(cin, cout, k in {1,3}, padding k//2) parameters (networks/unet_icl.py:46-52,82,173); the forward embeds
+    the 2-D stencil in the dz = 1 plane of a 3-D kernel and runs the MFMA convolution on a D = 1 volume."""
+
+    def __init__(self, cin, cout, ks=3, bias=True, groups=1, device=None, feeds_batch_norm=False):
+        super().__init__()
+        self.cin, self.cout, self.ks, self.groups = cin, cout, ks, groups
+        self.feeds_batch_norm = feeds_batch_norm
+        self.weight = nn.Parameter(torch.empty(cout, cin // groups, ks, ks, device=device))
+        self.bias = nn.Parameter(torch.empty(cout, device=device)) if bias else None
+        fan_in = (cin // groups) * ks * ks
+        with torch.no_grad():  # torch default init (the reference never re-initialises its 2-D nets)
+            self.weight.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+            if self.bias is not None:
+                self.bias.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+
+    def forward(self, x):
+        if self.groups != 1:
+            return ops.depthwise_conv2d(x, self.weight)
+        # a batch-statistics BatchNorm removes the per-channel mean: the bias gradient is exactly zero in training
+        return ops.conv2d(x, self.weight, self.bias, self.feeds_batch_norm and self.training)
+
+
+class BatchNormAct(nn.Module):
+    """nn.BatchNorm{2,3}d parameters/buffers fused with the activation that follows (act: 0 none, 1 ReLU, 2 LeakyReLU)."""
+
+    def __init__(self, c, act, device=None):
+        super().__init__()
+        self.act = act
+        self.weight = nn.Parameter(torch.ones(c, device=device))
+        self.bias = nn.Parameter(torch.zeros(c, device=device))
+        self.register_buffer("running_mean", torch.zeros(c, device=device))
+        self.register_buffer("running_var", torch.ones(c, device=device))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long, device=device))
+
+    def forward(self, x):
+        if self.training:
+            self.num_batches_tracked += 1
+        return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.act)

@@ -246,22 +246,51 @@ def batch_norm_relu(x, gamma, beta, running_mean, running_var, training: bool, r
     return _NormAct.apply(x, gamma, beta, running_mean, running_var, 1, bool(training), int(relu), eps, momentum)
 
 
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, act: int,
+                   eps: float = 1e-5, momentum: float = 0.1) -> torch.Tensor:
+    """BatchNorm{2,3}d fused with act: 0 none, 1 ReLU, 2 LeakyReLU(0.01) (2-D ConvBlock, networks/unet_icl.py:46-54).
+    A 4-D input [N,C,H,W] is normalised over (N,H,W) exactly like a 5-D one over (N,D,H,W)."""
+    return _NormAct.apply(x, gamma, beta, running_mean, running_var, 1, bool(training), int(act), eps, momentum)
+
+
+def _embed_2d_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[Co,Ci,3,3] -> [Co,Ci,3,3,3] with the 2-D stencil in the dz = 1 plane (autograd slices the gradient back).
+    A 3x3 convolution of a D = 1 volume with this kernel and padding 1 is exactly the 2-D convolution."""
+    co, ci, kh, kw = weight.shape
+    if kh == 1:
+        return weight.unsqueeze(2)
+    w3 = weight.new_zeros((co, ci, 3, kh, kw))
+    w3[:, :, 1] = weight
+    return w3
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, zero_bias_grad: bool = False) -> torch.Tensor:
+    """nn.Conv2d k=3 pad 1 / k=1 on [N,C,H,W] (networks/unet_icl.py:46-52,82,173) through the 3-D MFMA kernels."""
+    return conv3d(x.unsqueeze(2), _embed_2d_weight(weight), bias, zero_bias_grad).squeeze(2)
+
+
+def depthwise_conv2d(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """Depthwise 3x3 (SeparableConv2d.depthwise, networks/unet_icl.py:100-103) on the 3-D stencil kernel."""
+    return depthwise_conv3d(x.unsqueeze(2), _embed_2d_weight(weight)).squeeze(2)
+
+
 # --------------------------------------------------------------------------------------
 # MaxPool3d(2) — networks/unet_3D_icl.py:41-53
 # --------------------------------------------------------------------------------------
 
 class _MaxPool2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, pd):
         _require(x)
         L = _lib.lib()
         x = x.contiguous()
         n, c, d, h, w = x.shape
-        assert d % 2 == 0 and h % 2 == 0 and w % 2 == 0, "MaxPool3d(2) kernels need even extents"
-        y = torch.empty((n, c, d // 2, h // 2, w // 2), dtype=torch.float32, device=x.device)
+        assert d % pd == 0 and h % 2 == 0 and w % 2 == 0, "max-pool kernels need even extents"
+        y = torch.empty((n, c, d // pd, h // 2, w // 2), dtype=torch.float32, device=x.device)
         idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
-        _lib.check(L.icl_maxpool2_fwd(_ptr(x), _ptr(y), _ptr(idx), n * c, d // 2, h // 2, w // 2, _stream(x)), "maxpool2_fwd")
+        _lib.check(L.icl_maxpool2_fwd(_ptr(x), _ptr(y), _ptr(idx), n * c, d // pd, h // 2, w // 2, pd, _stream(x)), "maxpool2_fwd")
         ctx.save_for_backward(idx)
+        ctx.pd = pd
         return y
 
     @staticmethod
@@ -270,13 +299,18 @@ class _MaxPool2(torch.autograd.Function):
         L = _lib.lib()
         gy = gy.contiguous()
         n, c, d, h, w = gy.shape
-        gx = torch.empty((n, c, d * 2, h * 2, w * 2), dtype=torch.float32, device=gy.device)
-        _lib.check(L.icl_maxpool2_bwd(_ptr(gy), _ptr(idx), _ptr(gx), n * c, d, h, w, _stream(gy)), "maxpool2_bwd")
-        return gx
+        gx = torch.empty((n, c, d * ctx.pd, h * 2, w * 2), dtype=torch.float32, device=gy.device)
+        _lib.check(L.icl_maxpool2_bwd(_ptr(gy), _ptr(idx), _ptr(gx), n * c, d, h, w, ctx.pd, _stream(gy)), "maxpool2_bwd")
+        return gx, None
 
 
 def max_pool3d_2(x: torch.Tensor) -> torch.Tensor:
-    return _MaxPool2.apply(x)
+    return _MaxPool2.apply(x, 2)
+
+
+def max_pool2d_2(x: torch.Tensor) -> torch.Tensor:
+    """nn.MaxPool2d(2) on [N,C,H,W] (networks/unet_icl.py:64), run as a D = 1 volume."""
+    return _MaxPool2.apply(x.unsqueeze(2), 1).squeeze(2)
 
 
 # --------------------------------------------------------------------------------------
@@ -285,16 +319,17 @@ def max_pool3d_2(x: torch.Tensor) -> torch.Tensor:
 
 class _Trilinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, size):
+    def forward(ctx, x, size, align):
         _require(x)
         L = _lib.lib()
         x = x.contiguous()
         n, c, di, hi, wi = x.shape
         do, ho, wo = size
         y = torch.empty((n, c, do, ho, wo), dtype=torch.float32, device=x.device)
-        _lib.check(L.icl_trilinear_fwd(_ptr(x), _ptr(y), n, c, di, hi, wi, do, ho, wo, c * do * ho * wo, _stream(x)),
+        _lib.check(L.icl_trilinear_fwd(_ptr(x), _ptr(y), n, c, di, hi, wi, do, ho, wo, c * do * ho * wo, align, _stream(x)),
                    "trilinear_fwd")
         ctx.in_shape = (n, c, di, hi, wi)
+        ctx.align = align
         return y
 
     @staticmethod
@@ -305,13 +340,18 @@ class _Trilinear(torch.autograd.Function):
         do, ho, wo = gy.shape[2:]
         gx = torch.empty(ctx.in_shape, dtype=torch.float32, device=gy.device)
         ws = _ws(L.icl_trilinear_bwd_ws_bytes(n, c, di, hi, wi, do, ho, wo), gy)
-        _lib.check(L.icl_trilinear_bwd(_ptr(gy), _ptr(gx), _ptr(ws), n, c, di, hi, wi, do, ho, wo, c * do * ho * wo, _stream(gy)),
-                   "trilinear_bwd")
-        return gx, None
+        _lib.check(L.icl_trilinear_bwd(_ptr(gy), _ptr(gx), _ptr(ws), n, c, di, hi, wi, do, ho, wo, c * do * ho * wo, ctx.align,
+                                       _stream(gy)), "trilinear_bwd")
+        return gx, None, None
 
 
-def trilinear_resize(x: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
-    return _Trilinear.apply(x, tuple(int(s) for s in size))
+def trilinear_resize(x: torch.Tensor, size: Sequence[int], align_corners: bool = False) -> torch.Tensor:
+    return _Trilinear.apply(x, tuple(int(s) for s in size), int(bool(align_corners)))
+
+
+def bilinear_resize(x: torch.Tensor, size: Sequence[int], align_corners: bool = False) -> torch.Tensor:
+    """F.interpolate(mode='bilinear') / nn.Upsample(bilinear) on [N,C,H,W], run as a D = 1 volume."""
+    return _Trilinear.apply(x.unsqueeze(2), (1, int(size[0]), int(size[1])), int(bool(align_corners))).squeeze(2)
 
 
 class _UpCat(torch.autograd.Function):
@@ -333,7 +373,7 @@ class _UpCat(torch.autograd.Function):
         _lib.check(L.icl_copy_rows(_ptr(skip), _ptr(out), n, cs * s, cs * s, (cs + cd) * s, _stream(skip)), "copy_rows")
         up_view = out[:, cs:]
         _lib.check(L.icl_trilinear_fwd(_ptr(deep), _vp(up_view.data_ptr()), n, cd, d // 2, h // 2, w // 2, d, h, w,
-                                       (cs + cd) * s, _stream(skip)), "trilinear_fwd")
+                                       (cs + cd) * s, 0, _stream(skip)), "trilinear_fwd")
         ctx.dims = (n, cs, cd, d, h, w)
         return out
 
@@ -352,7 +392,7 @@ class _UpCat(torch.autograd.Function):
             gv = g[:, cs:]
             ws = _ws(L.icl_trilinear_bwd_ws_bytes(n, cd, d // 2, h // 2, w // 2, d, h, w), g)
             _lib.check(L.icl_trilinear_bwd(_vp(gv.data_ptr()), _ptr(gdeep), _ptr(ws), n, cd, d // 2, h // 2, w // 2, d, h, w,
-                                           (cs + cd) * s, _stream(g)), "trilinear_bwd")
+                                           (cs + cd) * s, 0, _stream(g)), "trilinear_bwd")
         return gskip, gdeep
 
 

@@ -32,8 +32,8 @@ class ICLConfig:
     momentum: float = 0.9
     weight_decay: float = 1e-4
     w_pse: float = 1.0     # 0.1 in the AMOS trainer (train_..._AMOS22.py:230)
-    w_con: float = 10.0
-    patch_size: tuple = (96, 96, 96)
+    w_con: float = 10.0    # 50 in the 2-D trainer (train_inherent_consistent_unet_2D.py:127)
+    patch_size: tuple = (96, 96, 96)   # (256, 256) selects the 2-D losses (AuxLoss / PseudoSoftLoss)
 
 
 class ICLTrainer:
@@ -43,8 +43,12 @@ class ICLTrainer:
                                   weight_decay=cfg.weight_decay)
         self.ce_loss = CrossEntropyLoss()
         self.dice_loss = L.DiceLoss(cfg.num_classes)
-        self.aux_loss = L.AuxLoss3D(cfg.num_classes, cfg.patch_size)
-        self.pse_loss = L.PseudoSoftLoss3D(cfg.num_classes, cfg.patch_size)
+        if len(cfg.patch_size) == 3:
+            self.aux_loss = L.AuxLoss3D(cfg.num_classes, cfg.patch_size)
+            self.pse_loss = L.PseudoSoftLoss3D(cfg.num_classes, cfg.patch_size)
+        else:
+            self.aux_loss = L.AuxLoss(cfg.num_classes, cfg.patch_size)
+            self.pse_loss = L.PseudoSoftLoss(cfg.num_classes, cfg.patch_size)
         self.iter_num = 0
 
     def compute_loss(self, outputs, label_batch):

@@ -57,6 +57,42 @@ def _resize(t, size):
     return ops.trilinear_resize(t.float(), size)
 
 
+def _resize2d(t, size):
+    return ops.bilinear_resize(t.float(), size)
+
+
+class AuxLoss(nn.Module):
+    """2-D twin of AuxLoss3D (losses.py:233-251): bilinear resize to ``resize``, CE + Dice(softmax=True) per map."""
+
+    def __init__(self, n_classes, resize=(224, 224)):
+        super().__init__()
+        self.n_classes = n_classes
+        self.ce_loss = CrossEntropyLoss()
+        self.dice_loss = DiceLoss(n_classes)
+        self.resize = tuple(resize)
+
+    def forward(self, feat_maps, labels):
+        loss = 0.0
+        for fm in feat_maps:
+            loss = loss + ops.cross_entropy_dice(_resize2d(fm, self.resize), labels.long(), self.n_classes)
+        return loss / len(feat_maps)
+
+
+class PseudoSoftLoss(nn.Module):
+    """2-D twin of PseudoSoftLoss3D (losses.py:273-285)."""
+
+    def __init__(self, n_classes, resize=(224, 224)):
+        super().__init__()
+        self.resize = tuple(resize)
+
+    def forward(self, feat_maps, predicts):
+        tgt = predicts.detach()
+        loss = 0.0
+        for fm in feat_maps:
+            loss = loss + softmax_dice_loss(_resize2d(fm, self.resize), tgt)
+        return loss / len(feat_maps)
+
+
 class AuxLoss3D(nn.Module):
     """losses.py:254-271 (resize hard-coded to 96^3 there; exposed as an argument with that default)."""
 

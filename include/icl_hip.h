@@ -43,7 +43,7 @@ int icl_conv3d_wgrad(const float* x, const float* gy, float* gw, float* gbias, v
 /* ---- InstanceNorm3d(+ReLU) (networks/utils.py:105-106,108-109) and BatchNorm3d(+ReLU)
  * (networks/unet_3D_icl.py:325-340).  mode 0 = instance (group = (n,c)), 1 = batch (group = c).
  * use_batch_stats 0 = normalise with the given mean/rstd... (eval-mode BatchNorm: mean=running_mean,
- * rstd computed from running_var by icl_rstd_from_var).  act 0 none / 1 ReLU.  gamma/beta/running_* may be NULL. */
+ * rstd computed from running_var by icl_rstd_from_var).  act 0 none / 1 ReLU / 2 LeakyReLU(0.01).  gamma/beta/running_* may be NULL. */
 int64_t icl_norm_ws_bytes(int n, int c, int64_t s);
 int icl_norm_fwd(const float* x, float* y, float* mean, float* rstd, const float* gamma, const float* beta,
                  float* running_mean, float* running_var, int n, int c, int64_t s, int mode, int use_batch_stats,
@@ -53,18 +53,19 @@ int icl_norm_bwd(const float* gy, const float* x, const float* mean, const float
                  int use_batch_stats, int act, void* ws, void* stream);
 int icl_rstd_from_var(const float* var, float* rstd, int c, float eps, void* stream);
 
-/* ---- MaxPool3d(2) (networks/unet_3D_icl.py:41-53); idx = uint8 argmax within the 2x2x2 window. */
-int icl_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int64_t nc, int dout, int hout, int wout, void* stream);
-int icl_maxpool2_bwd(const float* gy, const uint8_t* idx, float* gx, int64_t nc, int dout, int hout, int wout, void* stream);
+/* ---- MaxPool3d(2) (networks/unet_3D_icl.py:41-53) and MaxPool2d(2) (networks/unet_icl.py:64, pool_depth = 1 on a
+ * D = 1 volume); idx = uint8 argmax within the pool_depth x 2 x 2 window. */
+int icl_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int64_t nc, int dout, int hout, int wout, int pool_depth, void* stream);
+int icl_maxpool2_bwd(const float* gy, const uint8_t* idx, float* gx, int64_t nc, int dout, int hout, int wout, int pool_depth, void* stream);
 
-/* ---- trilinear resize, align_corners=False (networks/utils.py:264; utils/losses.py:263,292).
- * Source index scale per axis = in/out (what ATen uses for size= and for scale_factor=2). */
+/* ---- trilinear / bilinear (D = 1) resize (networks/utils.py:264; networks/unet_icl.py:84-85; utils/losses.py:245,263,281,292).
+ * align_corners=0: source scale in/out (what ATen uses for size= and for scale_factor=2); 1: (in-1)/(out-1). */
 int icl_trilinear_fwd(const float* x, float* y, int n, int c, int di, int hi, int wi, int dout, int hout, int wout,
-                      int64_t y_bstride, void* stream);
+                      int64_t y_bstride, int align_corners, void* stream);
 /* backward = three separable one-axis gathers (x, y, z); ws >= icl_trilinear_bwd_ws_bytes(...) */
 int64_t icl_trilinear_bwd_ws_bytes(int n, int c, int di, int hi, int wi, int dout, int hout, int wout);
 int icl_trilinear_bwd(const float* gy, float* gx, void* ws, int n, int c, int di, int hi, int wi, int dout, int hout, int wout,
-                      int64_t gy_bstride, void* stream);
+                      int64_t gy_bstride, int align_corners, void* stream);
 
 /* ---- strided row copy (torch.cat([skip, up], 1), networks/utils.py:276) */
 int icl_copy_rows(const float* src, float* dst, int64_t rows, int64_t row_elems, int64_t src_stride, int64_t dst_stride,

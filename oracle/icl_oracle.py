@@ -122,19 +122,24 @@ def class_decoder(p: P, pre: str, query: torch.Tensor, feat: torch.Tensor, heads
 
 
 def _bn_train(p: P, pre: str, x: torch.Tensor, training: bool) -> torch.Tensor:
-    if training:  # batch statistics, biased variance (nn.BatchNorm3d in train mode)
-        return F.batch_norm(x, None, None, p[f"{pre}.weight"], p[f"{pre}.bias"], True, 0.1, 1e-5)
+    if training:  # batch statistics, biased variance; running stats updated in place when the buffers are present
+        return F.batch_norm(x, p.get(f"{pre}.running_mean"), p.get(f"{pre}.running_var"), p[f"{pre}.weight"],
+                            p[f"{pre}.bias"], True, 0.1, 1e-5)
     return F.batch_norm(x, p[f"{pre}.running_mean"], p[f"{pre}.running_var"],
                         p[f"{pre}.weight"], p[f"{pre}.bias"], False, 0.1, 1e-5)
 
 
+def _convnd(x, w, b=None, padding=0, groups=1):
+    return (F.conv3d if w.dim() == 5 else F.conv2d)(x, w, b, padding=padding, groups=groups)
+
+
 def separable_conv3d(p: P, pre: str, x: torch.Tensor, training: bool) -> torch.Tensor:
-    """SeparableConv3d(relu_first=False), networks/unet_3D_icl.py:317-345: depthwise 3^3
-    (groups=C, no bias) -> BN -> ReLU -> pointwise 1^3 (no bias) -> BN -> ReLU."""
+    """SeparableConv3d(relu_first=False), networks/unet_3D_icl.py:317-345 (2-D twin: unet_icl.py:98-126): depthwise 3^d
+    (groups=C, no bias) -> BN -> ReLU -> pointwise 1^d (no bias) -> BN -> ReLU."""
     c = x.shape[1]
-    x = F.conv3d(x, p[f"{pre}.block.depthwise.weight"], None, padding=1, groups=c)
+    x = _convnd(x, p[f"{pre}.block.depthwise.weight"], None, padding=1, groups=c)
     x = F.relu(_bn_train(p, f"{pre}.block.bn_depth", x, training))
-    x = F.conv3d(x, p[f"{pre}.block.pointwise.weight"], None)
+    x = _convnd(x, p[f"{pre}.block.pointwise.weight"], None)
     x = F.relu(_bn_train(p, f"{pre}.block.bn_point", x, training))
     return x
 
@@ -150,16 +155,18 @@ def inherent_consistent(p: P, pre: str, feats: Sequence[torch.Tensor], heads: Se
     maps, upd = [], []
     nxt = p[f"{pre}.guided_Q"].expand(bs, -1, -1) if modal == "labeled" else None
     for i, f in enumerate(feats):
-        tok = F.conv3d(f, p[f"{pre}.proj_layers.{i}.weight"], p[f"{pre}.proj_layers.{i}.bias"])
+        tok = _convnd(f, p[f"{pre}.proj_layers.{i}.weight"], p[f"{pre}.proj_layers.{i}.bias"])
         tok = _ln(p, f"{pre}.norm_layers.{i}", tok.flatten(2).transpose(1, 2))
         q_in = nxt if modal == "labeled" else guided_q[i].expand(bs, -1, -1)
         q_out, attn = class_decoder(p, f"{pre}.class_decoders.{i}", q_in, tok, heads[i])
         b, nc, h, n = attn.shape
-        r = int(round(n ** (1.0 / 3.0)))
-        a = attn.contiguous().view(b * nc, h, r, r, r)
+        dims = f.dim() - 2   # 3: int(np.cbrt(N)) (unet_3D_icl.py:215); 2: int(np.sqrt(N)) (unet_icl.py:311)
+        r = int(round(n ** (1.0 / dims)))
+        sp = (r,) * dims
+        a = attn.contiguous().view(b * nc, h, *sp)
         a = separable_conv3d(p, f"{pre}.attn_convs0.{i}", a, training)
-        a = F.conv3d(a, p[f"{pre}.attn_convs1.{i}.weight"], p[f"{pre}.attn_convs1.{i}.bias"])
-        maps.append(a.squeeze(1).reshape(b, nc, r, r, r))
+        a = _convnd(a, p[f"{pre}.attn_convs1.{i}.weight"], p[f"{pre}.attn_convs1.{i}.bias"])
+        maps.append(a.squeeze(1).reshape(b, nc, *sp))
         nq = F.conv1d(q_out.permute(0, 2, 1), p[f"{pre}.query_convs.{i}.weight"],
                       p[f"{pre}.query_convs.{i}.bias"])
         nxt = nq.permute(0, 2, 1)
@@ -392,3 +399,130 @@ def make_params(shapes, base_seed: int = 1337, requires_grad: bool = False, stri
         for t in p.values():
             t.requires_grad_()
     return p
+
+
+# ----------------------------------------------------------------------------
+# 2-D U-Net ICL (BASELINE config 1): networks/unet_icl.py, networks/unet.py
+# ----------------------------------------------------------------------------
+
+UNET2D_FT = (16, 32, 64, 128, 256)
+UNET2D_HEADS = (8, 4, 2)          # params['num_heads'][::-1], unet_icl.py:214
+UNET2D_RES = (32, 64, 128)        # input_resolution[1:4] for 256^2 inputs, unet_icl.py:213
+
+
+def conv_block2d(p: P, pre: str, x: torch.Tensor, training: bool) -> torch.Tensor:
+    """ConvBlock, networks/unet_icl.py:39-57: 2 x [Conv2d 3x3 -> BatchNorm2d -> LeakyReLU(0.01)], dropout prob 0."""
+    for i, j in ((0, 1), (4, 5)):
+        x = F.conv2d(x, p[f"{pre}.conv_conv.{i}.weight"], p[f"{pre}.conv_conv.{i}.bias"], padding=1)
+        x = F.leaky_relu(_bn_train(p, f"{pre}.conv_conv.{j}", x, training), 0.01)
+    return x
+
+
+def up_block2d(p: P, pre: str, x1: torch.Tensor, x2: torch.Tensor, training: bool) -> torch.Tensor:
+    """UpBlock with the default bilinear=True (Decoder never forwards the flag), unet_icl.py:75-96:
+    conv1x1 -> bilinear x2 align_corners=True -> cat([skip, up]) -> ConvBlock."""
+    x1 = F.conv2d(x1, p[f"{pre}.conv1x1.weight"], p[f"{pre}.conv1x1.bias"])
+    x1 = F.interpolate(x1, scale_factor=2, mode="bilinear", align_corners=True)
+    return conv_block2d(p, f"{pre}.conv", torch.cat([x2, x1], 1), training)
+
+
+def backbone2d(p: P, x: torch.Tensor, training: bool):
+    """Encoder + Decoder, unet_icl.py:128-193.  Returns (logits, [x_1, x_2, x_3])."""
+    x0 = conv_block2d(p, "encoder.in_conv", x, training)
+    xs = [x0]
+    for i in range(1, 5):
+        xs.append(conv_block2d(p, f"encoder.down{i}.maxpool_conv.1", F.max_pool2d(xs[-1], 2), training))
+    x_1 = up_block2d(p, "decoder.up1", xs[4], xs[3], training)
+    x_2 = up_block2d(p, "decoder.up2", x_1, xs[2], training)
+    x_3 = up_block2d(p, "decoder.up3", x_2, xs[1], training)
+    x = up_block2d(p, "decoder.up4", x_3, xs[0], training)
+    out = F.conv2d(x, p["decoder.out_conv.weight"], p["decoder.out_conv.bias"], padding=1)
+    return out, [x_1, x_2, x_3]
+
+
+def unet_icl_2d_forward(p: P, x_lab, x_unlab=None, inference=False, training=True):
+    """UNet_icl.forward, unet_icl.py:235-252: two separate backbone passes (BatchNorm sees each half on its own)."""
+    out_lab, feats_lab = backbone2d(p, x_lab, training)
+    if inference:
+        return out_lab
+    out_unlab, feats_unlab = backbone2d(p, x_unlab, training)
+    maps_lab, qs_lab = inherent_consistent(p, "sspa", feats_lab, UNET2D_HEADS, None, "labeled", training)
+    maps_con, _ = inherent_consistent(p, "sspa", feats_unlab, UNET2D_HEADS, None, "labeled", training)
+    maps_unlab, _ = inherent_consistent(p, "uscl", feats_unlab, UNET2D_HEADS, qs_lab, "unlabeled", training)
+    return out_lab, out_unlab, maps_lab, maps_unlab, maps_con
+
+
+def _resize2d(m, size):
+    return F.interpolate(m.float(), size=list(size), mode="bilinear")
+
+
+def icl_losses_2d(outputs, labels_lab: torch.Tensor, n_classes: int, size=(256, 256), w_con: float = 50.0):
+    """train_inherent_consistent_unet_2D.py:117-127: ce + dice(softmax=True) + AuxLoss + PseudoSoftLoss + 50*consistency
+    (AuxLoss / PseudoSoftLoss: utils/losses.py:233-251,273-285 with resize=patch_size)."""
+    out_lab, out_unlab, maps_lab, maps_unlab, maps_con = outputs
+    l_ce = F.cross_entropy(out_lab, labels_lab.long())
+    l_dice = dice_loss(out_lab, labels_lab.unsqueeze(1), n_classes, softmax=True)
+    l_aux = 0.0
+    for m in maps_lab:
+        r = _resize2d(m, size)
+        l_aux = l_aux + F.cross_entropy(r, labels_lab.long()) + dice_loss(r, labels_lab.unsqueeze(1), n_classes, softmax=True)
+    l_aux = l_aux / len(maps_lab)
+    tgt = out_unlab.detach()
+    l_pse = sum(softmax_dice_loss(_resize2d(m, size), tgt) for m in maps_unlab) / len(maps_unlab)
+    l_con = softmax_mse_loss(maps_unlab, maps_con)
+    total = l_ce + l_dice + l_aux + l_pse + w_con * l_con
+    return total, dict(ce=l_ce, dice=l_dice, aux=l_aux, pse=l_pse, con=l_con)
+
+
+def conv_block2d_shapes(pre, cin, cout):
+    out = []
+    for i, j, ci in ((0, 1, cin), (4, 5, cout)):
+        out += [(f"{pre}conv_conv.{i}.weight", (cout, ci, 3, 3)), (f"{pre}conv_conv.{i}.bias", (cout,)),
+                (f"{pre}conv_conv.{j}.weight", (cout,)), (f"{pre}conv_conv.{j}.bias", (cout,))]
+    return out
+
+
+def backbone2d_shapes(nc: int, in_ch: int = 1):
+    f = UNET2D_FT
+    out = conv_block2d_shapes("encoder.in_conv.", in_ch, f[0])
+    for i in range(1, 5):
+        out += conv_block2d_shapes(f"encoder.down{i}.maxpool_conv.1.", f[i - 1], f[i])
+    for i, (c1, c2) in enumerate(((f[4], f[3]), (f[3], f[2]), (f[2], f[1]), (f[1], f[0])), start=1):
+        out += [(f"decoder.up{i}.conv1x1.weight", (c2, c1, 1, 1)), (f"decoder.up{i}.conv1x1.bias", (c2,))]
+        out += conv_block2d_shapes(f"decoder.up{i}.conv.", c2 * 2, c2)
+    out += [("decoder.out_conv.weight", (nc, f[0], 3, 3)), ("decoder.out_conv.bias", (nc,))]
+    return out
+
+
+def backbone2d_buffers(in_ch: int = 1):
+    out = {}
+    for k, s in backbone2d_shapes(2, in_ch):
+        if k.endswith((".1.weight", ".5.weight")) and "conv_conv" in k:
+            b = k[: -len("weight")]
+            out[b + "running_mean"] = torch.zeros(s)
+            out[b + "running_var"] = torch.ones(s)
+    return out
+
+
+def aligner_shapes_nd(pre, in_chans, res, nc, heads, dims):
+    """aligner_shapes with conv weights of the right rank (dims = 2: unet_icl.py:253-300)."""
+    out = []
+    for k, s in aligner_shapes(pre, in_chans, [1] * len(res), nc, heads):
+        out.append((k, s))
+    fixed = []
+    n_tok = [r ** dims for r in res]
+    for k, s in out:
+        if ".norm3." in k or ".mlp2." in k:
+            i = int(k.split("class_decoders.")[1].split(".")[0])
+            s = tuple(n_tok[i] if v == 1 else v for v in s)
+        if dims == 2 and len(s) == 5:
+            s = s[:2] + s[3:]
+        fixed.append((k, s))
+    return fixed
+
+
+def unet_icl_2d_shapes(nc: int, in_ch: int = 1):
+    f = (UNET2D_FT[3], UNET2D_FT[2], UNET2D_FT[1])
+    return (backbone2d_shapes(nc, in_ch)
+            + aligner_shapes_nd("sspa.", f, UNET2D_RES, nc, UNET2D_HEADS, 2)
+            + aligner_shapes_nd("uscl.", f, UNET2D_RES, nc, UNET2D_HEADS, 2))

@@ -289,6 +289,70 @@ def gen_model(R, out, nc):
     print(f"model nc={nc}: losses", d["losses"], "grad_none", len(none))
 
 
+# ---------------------------------------------------------------- 2-D U-Net ICL (BASELINE config 1)
+def gen_model2d(R, out, nc=4):
+    from networks.unet import UNet
+    from networks.unet_icl import UNet_icl
+    L = R["losses"]
+    d = {}
+    plain = UNet(1, nc)
+    d["plain_keys"] = np.array(list(plain.state_dict().keys()))
+    model = UNet_icl(1, nc)
+    parity_mode(model)
+    fill(model)
+    d["keys"] = np.array(list(model.state_dict().keys()))
+    d["param_keys"] = np.array([k for k, _ in model.named_parameters()])
+    img = synthetic_volume((4, 1, 256, 256), 2024)
+    lab = synthetic_labels((2, 256, 256), 2025, nc)
+    model.train()
+    outs = model(img[:2], img[2:])
+    for name, t in (("out_lab", outs[0]), ("out_unlab", outs[1])):
+        d[name + "_sub"] = npy(t)[:, :, ::8, ::8]
+        d[name + "_l2"] = npy(t.double().pow(2).sum(dim=(0, 2, 3)).sqrt())
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            st = (1, 2, 4)[i]
+            d[f"{name}{i}_sub"] = npy(t)[:, :, ::st, ::st]
+            d[f"{name}{i}_l2"] = npy(t.double().pow(2).sum().sqrt())
+    l_ce = nn.CrossEntropyLoss()(outs[0], lab.long())
+    l_dice = L.DiceLoss(nc)(outs[0], lab.unsqueeze(1), softmax=True)
+    l_aux = L.AuxLoss(nc, resize=[256, 256])(outs[2], lab)
+    l_pse = L.PseudoSoftLoss(nc, resize=[256, 256])(outs[3], outs[1])
+    l_con = L.softmax_mse_loss(outs[3], outs[4])
+    loss = l_ce + l_dice + l_aux + l_pse + 50 * l_con
+    d["losses"] = np.array([float(l_ce.detach()), float(l_dice.detach()), float(l_aux.detach()), float(l_pse.detach()),
+                            float(l_con.detach()), float(loss.detach())])
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    opt.zero_grad()
+    loss.backward()
+    gn, none = {}, []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            none.append(k)
+        else:
+            gn[k] = float(p.grad.double().pow(2).sum().sqrt())
+    d["grad_none"] = np.array(none)
+    d["grad_norm_keys"] = np.array(list(gn.keys()))
+    d["grad_norms"] = np.array(list(gn.values()))
+    sd_ = dict(model.named_parameters())
+    for k in ("decoder.out_conv.weight", "encoder.in_conv.conv_conv.0.weight", "encoder.in_conv.conv_conv.1.weight",
+              "decoder.up1.conv1x1.weight", "sspa.guided_Q"):
+        d["grad." + k] = npy(sd_[k].grad)
+    opt.step()
+    d["post_sgd_norms"] = np.array([float(p.detach().double().pow(2).sum().sqrt()) for _, p in model.named_parameters()])
+    bufs = dict(model.named_buffers())
+    for k in ("encoder.in_conv.conv_conv.1.running_mean", "encoder.in_conv.conv_conv.1.running_var",
+              "decoder.up4.conv.conv_conv.5.running_var", "sspa.attn_convs0.2.block.bn_depth.running_var"):
+        d["buf." + k] = npy(bufs[k])
+    # inference branch in eval mode (uses the running statistics just updated by the train-mode pass)
+    model.eval()
+    with torch.no_grad():
+        y = model(img[:2], inference=True)
+    d["inf_logits_sub"] = npy(y)[:, :, ::8, ::8]
+    np.savez_compressed(os.path.join(out, f"model_unet2d_icl_nc{nc}.npz"), **d)
+    print("model2d: losses", d["losses"], "grad_none", len(none))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -301,3 +365,5 @@ if __name__ == "__main__":
         gen_model(R, HERE, 2)
     if a.only in ("all", "model16"):
         gen_model(R, HERE, 16)
+    if a.only in ("all", "model2d"):
+        gen_model2d(R, HERE)

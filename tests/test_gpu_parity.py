@@ -310,3 +310,57 @@ def test_full_icl_step_matches_reference_golden(dev, nc):
            if abs(post[i] - g["post_sgd_norms"][i]) > 1e-4 * g["post_sgd_norms"][i]]
     assert not off, off[:8]
     assert rel_err(model.final.weight.detach().cpu(), g["post_sgd.final.weight"]) < 1e-5
+
+
+def test_2d_unet_icl_step_matches_reference_golden(dev):
+    """BASELINE config 1 (2D U-Net ICL, 256x256, nc=4, batch 2+2) on the HIP kernels vs the reference golden."""
+    from icl_amd.networks.unet import UNet
+    from icl_amd.networks.unet_icl import UNet_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    nc = 4
+    g = load_golden("model_unet2d_icl_nc4.npz")
+    assert list(UNet(1, nc, device=dev).state_dict().keys()) == list(g["plain_keys"])
+    model = UNet_icl(1, nc, device=dev)
+    assert list(model.state_dict().keys()) == list(g["keys"])
+    assert [k for k, _ in model.named_parameters()] == list(g["param_keys"])
+    fill_like_reference_init(list(model.named_parameters()))
+    _parity_mode(model)
+    img = synthetic_volume((4, 1, 256, 256), 2024).to(dev)
+    lab = synthetic_labels((2, 256, 256), 2025, nc).to(dev)
+    model.train()
+    tr = ICLTrainer(model, ICLConfig(num_classes=nc, labeled_bs=2, w_con=50.0, patch_size=(256, 256)))
+    outs = model(img[:2], img[2:])
+    assert rel_err(outs[0].detach()[:, :, ::8, ::8].cpu(), g["out_lab_sub"]) < 1e-3
+    assert rel_err(outs[1].detach()[:, :, ::8, ::8].cpu(), g["out_unlab_sub"]) < 1e-3
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            st = (1, 2, 4)[i]
+            assert rel_err(t.detach()[:, :, ::st, ::st].cpu(), g[f"{name}{i}_sub"]) < 1e-3, (name, i)
+    loss, parts = tr.compute_loss(outs, lab)
+    got = [float(parts[k].detach()) for k in ("ce", "dice", "aux", "pse", "con")] + [float(loss.detach())]
+    assert np.allclose(got, g["losses"], rtol=0, atol=2e-4), (got, g["losses"])
+    tr.optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    none = [k for k, p in model.named_parameters() if p.grad is None]
+    assert none == list(g["grad_none"])
+    ref = dict(zip(g["grad_norm_keys"], g["grad_norms"]))
+    bad = []
+    for k, p in model.named_parameters():
+        if p.grad is None or (k.endswith("bias") and (".conv_conv.0." in k or ".conv_conv.4." in k or "attn_convs1" in k)):
+            continue
+        got_n = float(p.grad.double().norm())
+        if abs(got_n - ref[k]) > 1e-2 * max(ref[k], 1e-7) + 1e-9:
+            bad.append((k, got_n, ref[k]))
+    assert not bad, bad[:10]
+    assert rel_err(model.decoder.out_conv.weight.grad.cpu(), g["grad.decoder.out_conv.weight"]) < 1e-3
+    tr.optimizer.step()
+    post = np.array([float(p.detach().double().norm()) for _, p in model.named_parameters()])
+    assert np.allclose(post, g["post_sgd_norms"], rtol=1e-4)
+    bufs = dict(model.named_buffers())
+    for k in ("encoder.in_conv.conv_conv.1.running_mean", "encoder.in_conv.conv_conv.1.running_var",
+              "decoder.up4.conv.conv_conv.5.running_var", "sspa.attn_convs0.2.block.bn_depth.running_var"):
+        assert rel_err(bufs[k].cpu(), g["buf." + k]) < 1e-4, k
+    model.eval()
+    with torch.no_grad():
+        y = model(img[:2], inference=True)
+    assert rel_err(y[:, :, ::8, ::8].cpu(), g["inf_logits_sub"]) < 1e-3

@@ -269,3 +269,43 @@ def test_prototype_attention(B, h, nc, d, N):
     ((orf * go).sum() + (lr * gl).sum()).backward()
     assert rel_err(out.detach(), orf.detach()) < 1e-5 and rel_err(logits.detach(), lr.detach()) < 1e-5
     assert rel_err(qh.grad, qr.grad) < 1e-4 and rel_err(kv.grad, kr.grad) < 1e-4
+
+
+def test_2d_ops_through_3d_kernels():
+    """2-D U-Net ICL building blocks (config 1) run as D = 1 volumes."""
+    x = _rand((2, 4, 16, 16), 81, True)
+    w = (_rand((6, 4, 3, 3), 82) * 0.2).requires_grad_()
+    b = (_rand((6,), 83) * 0.1).requires_grad_()
+    ga, be = (1 + 0.1 * _rand((6,), 84)).requires_grad_(), (0.1 * _rand((6,), 85)).requires_grad_()
+    rm, rv = torch.zeros(6), torch.ones(6)
+    y = ops.batch_norm_act(ops.conv2d(x, w, b), ga, be, rm, rv, True, 2)
+    y = ops.bilinear_resize(ops.max_pool2d_2(y), (16, 16), align_corners=True)
+    gy = _rand(tuple(y.shape), 86)
+    y.backward(gy)
+    xr, wr, br, gr, ber = (t.detach().clone().requires_grad_() for t in (x, w, b, ga, be))
+    rm2, rv2 = torch.zeros(6), torch.ones(6)
+    yr = F.leaky_relu(F.batch_norm(F.conv2d(xr, wr, br, padding=1), rm2, rv2, gr, ber, True, 0.1, 1e-5))
+    yr = F.interpolate(F.max_pool2d(yr, 2), size=[16, 16], mode="bilinear", align_corners=True)
+    yr.backward(gy)
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    for a, r in ((x, xr), (w, wr), (ga, gr), (be, ber)):
+        assert rel_err(a.grad, r.grad) < 1e-4
+    assert rel_err(rm, rm2) < 1e-5 and rel_err(rv, rv2) < 1e-5
+    # bilinear align_corners=False (loss resize) and depthwise 3x3
+    m = _rand((2, 3, 5, 7), 87, True)
+    z = ops.bilinear_resize(m, (20, 21))
+    gz = _rand(tuple(z.shape), 88)
+    z.backward(gz)
+    mr = m.detach().clone().requires_grad_()
+    zr = F.interpolate(mr, size=[20, 21], mode="bilinear")
+    zr.backward(gz)
+    assert rel_err(z.detach(), zr.detach()) < 1e-6 and rel_err(m.grad, mr.grad) < 1e-5
+    d = _rand((3, 4, 6, 8), 89, True)
+    dw = (_rand((4, 1, 3, 3), 90) * 0.3).requires_grad_()
+    o = ops.depthwise_conv2d(d, dw)
+    go = _rand(tuple(o.shape), 91)
+    o.backward(go)
+    dr, dwr = d.detach().clone().requires_grad_(), dw.detach().clone().requires_grad_()
+    orf = F.conv2d(dr, dwr, None, padding=1, groups=4)
+    orf.backward(go)
+    assert rel_err(o.detach(), orf.detach()) < 1e-5 and rel_err(d.grad, dr.grad) < 1e-5 and rel_err(dw.grad, dwr.grad) < 1e-5

@@ -185,3 +185,40 @@ def test_full_model_step_matches_reference(nc):
     post = np.array([float(p[k].detach().double().norm()) for k, _ in shapes])
     assert np.allclose(post, g["post_sgd_norms"], rtol=1e-6)
     assert rel_err(p["final.weight"].detach(), g["post_sgd.final.weight"]) < 1e-6
+
+
+@pytest.mark.slow
+def test_2d_unet_icl_step_matches_reference():
+    """BASELINE config 1: 2D U-Net ICL, 256x256, nc=4, batch 2+2 — the reference's own CPU-runnable case."""
+    nc = 4
+    g = load_golden("model_unet2d_icl_nc4.npz")
+    shapes = O.unet_icl_2d_shapes(nc)
+    assert [k for k, _ in shapes] == list(g["param_keys"])
+    assert len([k for k in g["plain_keys"]]) == 136      # plain UNet checkpoint contract (SURVEY.md §0.8)
+    p = O.make_params(shapes, requires_grad=True)
+    p.update(O.backbone2d_buffers())
+    p.update(O.aligner_buffers("sspa.", O.UNET2D_HEADS))
+    p.update(O.aligner_buffers("uscl.", O.UNET2D_HEADS))
+    img = synthetic_volume((4, 1, 256, 256), 2024)
+    lab = synthetic_labels((2, 256, 256), 2025, nc)
+    outs = O.unet_icl_2d_forward(p, img[:2], img[2:], training=True)
+    assert rel_err(outs[0].detach()[:, :, ::8, ::8], g["out_lab_sub"]) < 1e-4
+    assert rel_err(outs[1].detach()[:, :, ::8, ::8], g["out_unlab_sub"]) < 1e-4
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            st = (1, 2, 4)[i]
+            assert rel_err(t.detach()[:, :, ::st, ::st], g[f"{name}{i}_sub"]) < 2e-4, (name, i)
+    total, parts = O.icl_losses_2d(outs, lab, nc)
+    got = [float(parts[k].detach()) for k in ("ce", "dice", "aux", "pse", "con")] + [float(total.detach())]
+    assert np.allclose(got, g["losses"], rtol=0, atol=2e-5), (got, g["losses"])
+    total.backward()
+    none = [k for k, _ in shapes if p[k].grad is None]
+    assert none == list(g["grad_none"])
+    ref = dict(zip(g["grad_norm_keys"], g["grad_norms"]))
+    for k, r in ref.items():
+        if k.endswith("bias") and (".conv_conv.0." in k or ".conv_conv.4." in k or "attn_convs1" in k):
+            continue  # conv bias in front of a batch-statistics BatchNorm / class softmax: rounding noise
+        got_n = float(p[k].grad.double().norm())
+        assert abs(got_n - r) <= 3e-3 * max(r, 1e-7) + 1e-9, (k, got_n, r)
+    assert rel_err(p["decoder.out_conv.weight"].grad, g["grad.decoder.out_conv.weight"]) < 1e-4
+    assert rel_err(p["encoder.in_conv.conv_conv.1.running_var"], g["buf.encoder.in_conv.conv_conv.1.running_var"]) < 1e-5
