@@ -364,3 +364,51 @@ def test_2d_unet_icl_step_matches_reference_golden(dev):
     with torch.no_grad():
         y = model(img[:2], inference=True)
     assert rel_err(y[:, :, ::8, ::8].cpu(), g["inf_logits_sub"]) < 1e-3
+
+
+def test_sliding_window_validation_and_checkpoint_interop(dev):
+    """Rows f1 + f3: the on-device batched sliding window reproduces the reference procedure (val_3D.py:15-83) window by
+    window; the filtered checkpoint of the ICL model loads into the plain backbone (…BraTS.py:158-162, test_3D_BraTS.py)."""
+    import math
+    from icl_amd.networks.unet_3D import unet_3D
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import backbone_state_dict
+    from icl_amd.val_3D import cal_metric, test_single_case_base
+    icl = unet_3D_icl(n_classes=2, in_channels=1, device=dev)
+    fill_like_reference_init(list(icl.named_parameters()))
+    plain = unet_3D(n_classes=2, in_channels=1, device=dev)
+    missing = plain.load_state_dict(backbone_state_dict(icl), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    icl.eval(); plain.eval()
+    x = synthetic_volume((1, 1, 96, 96, 96), 5).to(dev)
+    with torch.no_grad():
+        assert torch.equal(icl(x, inference=True), plain(x))
+    patch = (96, 96, 96)
+    for shape in [(100, 110, 120), (80, 100, 96)]:
+        image = synthetic_volume(shape, 9).numpy()
+        got = test_single_case_base(plain, "unet_3D", image, 64, 64, patch, num_classes=2)
+        # the reference procedure, one window per forward, numpy accumulation
+        w, h, d = image.shape
+        pads = [((max(p - s, 0)) // 2, max(p - s, 0) - max(p - s, 0) // 2) for s, p in zip((w, h, d), patch)]
+        img = np.pad(image, pads, mode="constant", constant_values=0)
+        ww, hh, dd = img.shape
+        sx, sy, sz = (math.ceil((n - 96) / 64) + 1 for n in (ww, hh, dd))
+        score = np.zeros((2,) + img.shape, np.float32)
+        cnt = np.zeros(img.shape, np.float32)
+        for xi in range(sx):
+            xs = min(64 * xi, ww - 96)
+            for yi in range(sy):
+                ys = min(64 * yi, hh - 96)
+                for zi in range(sz):
+                    zs = min(64 * zi, dd - 96)
+                    p = torch.from_numpy(img[xs:xs + 96, ys:ys + 96, zs:zs + 96][None, None].astype(np.float32)).to(dev)
+                    with torch.no_grad():
+                        y = torch.softmax(plain(p), dim=1).cpu().numpy()[0]
+                    score[:, xs:xs + 96, ys:ys + 96, zs:zs + 96] += y
+                    cnt[xs:xs + 96, ys:ys + 96, zs:zs + 96] += 1
+        ref = np.argmax(score / cnt[None], axis=0)
+        ref = ref[pads[0][0]:pads[0][0] + w, pads[1][0]:pads[1][0] + h, pads[2][0]:pads[2][0] + d]
+        assert got.shape == ref.shape == shape
+        assert (got != ref).mean() < 1e-4   # identical up to argmax ties of fp32 sums taken in a different order
+        dice, hd = cal_metric(ref == 1, got == 1)
+        assert dice > 0.9999

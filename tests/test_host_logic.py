@@ -1,0 +1,95 @@
+"""CPU tests of host-side logic: sampler semantics (row f2), metric conventions (row f1), C-ABI export table,
+checkpoint key filter (row f3), poly-LR schedule (T1)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_stream_sampler_matches_reference_semantics():
+    from icl_amd.dataloaders.brats2019 import TwoStreamBatchSampler
+    lab, unlab = list(range(0, 25)), list(range(25, 250))
+    np.random.seed(1337)
+    s = TwoStreamBatchSampler(lab, unlab, 4, 2)
+    batches = list(s)
+    assert len(batches) == len(s) == 12          # 25 // 2 primary batches per epoch, tail dropped
+    seen = [i for b in batches for i in b[:2]]
+    assert len(set(seen)) == 24 and all(i < 25 for i in seen)
+    assert all(len(b) == 4 and all(i >= 25 for i in b[2:]) for b in batches)
+    # the same numpy stream drives an independent restatement of the reference iteration (brats2019.py:208-217)
+    np.random.seed(1337)
+    prim = np.random.permutation(lab)
+    sec = np.random.permutation(unlab)
+    assert tuple(batches[0]) == (prim[0], prim[1], sec[0], sec[1])
+    assert tuple(batches[5]) == (prim[10], prim[11], sec[10], sec[11])
+    # rank sharding: W ranks together consume exactly the global batches
+    glob = []
+    np.random.seed(7)
+    glob = list(TwoStreamBatchSampler(lab, unlab, 8, 4))
+    shards = []
+    for r in range(2):
+        np.random.seed(7)
+        shards.append(list(TwoStreamBatchSampler(lab, unlab, 8, 4, rank=r, world_size=2)))
+    for g, a, b in zip(glob, shards[0], shards[1]):
+        assert sorted(g[:4]) == sorted(a[:2] + b[:2]) and sorted(g[4:]) == sorted(a[2:] + b[2:])
+
+
+def test_cal_metric_conventions_and_dice():
+    from icl_amd.val_3D import binary_dice, binary_hd95, cal_metric
+    z = np.zeros((8, 8, 8), bool)
+    a = z.copy(); a[2:6, 2:6, 2:6] = True
+    b = z.copy(); b[3:7, 2:6, 2:6] = True
+    assert cal_metric(z, z) == (1, 0)                       # val_3D.py:96-97
+    assert cal_metric(a, z) == (0, 373.128664) and cal_metric(z, a) == (0, 373.128664)
+    d, h = cal_metric(a, b)
+    assert abs(d - 2 * 48 / 128) < 1e-12 and abs(binary_dice(a, b) - 0.75) < 1e-12
+    assert h == binary_hd95(b, a) == 1.0                    # the two cubes are shifted by one voxel
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/icl_hip.h <-> libicl_hip.so <-> the ctypes table: no compute calls (no GPU here)."""
+    from icl_amd import _lib, build
+    header = open(os.path.join(ROOT, "include", "icl_hip.h")).read()
+    declared = set(re.findall(r"\b(icl_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = ctypes.CDLL(build.build(verbose=False))
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    lib.icl_abi_version.restype = ctypes.c_int
+    assert lib.icl_abi_version() == 1
+    # bad arguments are rejected with a message, without touching a device
+    lib.icl_last_error.restype = ctypes.c_char_p
+    lib.icl_gelu_fwd.restype = ctypes.c_int
+    assert lib.icl_gelu_fwd(None, None, ctypes.c_int64(0), None) == -1
+    assert b"gelu_fwd" in lib.icl_last_error()
+
+
+def test_product_path_fails_loudly_without_device_or_library(tmp_path, monkeypatch):
+    from icl_amd import _lib, ops
+    x = torch.zeros(1, 1, 4, 4, 4)
+    assert not _lib.host_pointers_ok()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.instance_norm_relu(x)
+    with pytest.raises(RuntimeError, match="not found"):
+        _lib._load(str(tmp_path / "missing.so"))
+    if not torch.cuda.is_available():
+        from icl_amd.networks.net_factory_3d import net_factory_3d
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            net_factory_3d("unet_3D_icl", 1, 2)
+
+
+def test_checkpoint_filter_and_lr_schedule():
+    from icl_amd.trainer import ICLConfig, backbone_state_dict
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from oracle import icl_oracle as O
+    m = unet_3D_icl(n_classes=2, in_channels=1, device="meta")
+    sd = backbone_state_dict(m)
+    assert list(sd.keys()) == [k for k, _ in O.backbone_shapes(2, 1)] and len(sd) == 38   # …BraTS.py:158-162
+    assert abs(O.poly_lr(0.01, 0, 30000) - 0.01) < 1e-15 and O.poly_lr(0.01, 30000, 30000) == 0.0
+    cfg = ICLConfig()
+    assert cfg.base_lr * (1.0 - 100 / cfg.max_iterations) ** 0.9 == O.poly_lr(cfg.base_lr, 100, cfg.max_iterations)
