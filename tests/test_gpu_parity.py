@@ -382,7 +382,8 @@ def test_sliding_window_validation_and_checkpoint_interop(dev):
     icl.eval(); plain.eval()
     x = synthetic_volume((1, 1, 96, 96, 96), 5).to(dev)
     with torch.no_grad():
-        assert torch.equal(icl(x, inference=True), plain(x))
+        # same weights, same kernels; the Cin-split layers accumulate with fp32 atomics, so compare to rounding
+        assert rel_err(icl(x, inference=True).cpu(), plain(x).cpu()) < 1e-5
     patch = (96, 96, 96)
     for shape in [(100, 110, 120), (80, 100, 96)]:
         image = synthetic_volume(shape, 9).numpy()
