@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--num-classes", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,8 +114,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    graphed = world == 1 and not args.no_graph
+    if graphed:
+        trainer.capture(vol, lab, warmup=max(args.warmup, 2))   # warm-up steps run eagerly inside capture()
         trainer.step(vol, lab)
+    else:
+        for _ in range(args.warmup):
+            trainer.step(vol, lab)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -130,6 +136,7 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_kernel_timer:
+        trainer.graph = None   # per-kernel HIP-event timing needs eager launches
         with ops.KernelTimer() as kt:
             for _ in range(3):
                 trainer.step(vol, lab)
@@ -161,7 +168,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"3D U-Net ICL BraTS-shape synthetic 96x96x96, num_classes={nc}, "
                                    f"batch=2 per GPU (1 labeled + 1 unlabeled), full ICL step incl. SGD",
-                       "global_batch": 2 * world, "parallelism": f"dp{world}"},
+                       "global_batch": 2 * world, "parallelism": f"dp{world}",
+                       "launch": "hipGraph replay" if graphed else "eager"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

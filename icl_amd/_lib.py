@@ -40,7 +40,7 @@ _SIGNATURES = {
     "icl_copy_rows": (c_int, [P, P, L, L, L, L, P]),
     "icl_dwconv3_fwd": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "icl_dwconv3_wgrad": (c_int, [P, P, P, I, I, I, I, I, P]),
-    "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P]),
+    "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P, P]),
     "icl_loss_fwd": (c_int, [P, P, P, P, P, P, I, I, L, I, I, P]),
     "icl_layernorm_fwd": (c_int, [P, P, P, P, P, P, L, I, F, P]),
     "icl_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, L, I, P]),
@@ -48,8 +48,8 @@ _SIGNATURES = {
     "icl_gelu_bwd": (c_int, [P, P, P, L, P]),
     "icl_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, F, P]),
     "icl_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
-    "icl_sgd_step": (c_int, [P, P, P, L, F, F, F, I, P]),
-    "icl_sgd_step_multi": (c_int, [P, P, P, P, I, F, F, F, I, P]),
+    "icl_sgd_step": (c_int, [P, P, P, L, F, F, F, I, P, P]),
+    "icl_sgd_step_multi": (c_int, [P, P, P, P, I, F, F, F, I, P, P]),
     "icl_loss_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, L, I, I, P]),
 }
 

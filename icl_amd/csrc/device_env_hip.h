@@ -27,6 +27,13 @@ __device__ __forceinline__ f32x16 icl_mfma_32x32x2(float a, float b, f32x16 c) {
 #define ICL_MEMSET_ASYNC(ptr, val, bytes, stream) ((void)hipMemsetAsync((ptr), (val), (bytes), (stream)))
 #define ICL_LAST_LAUNCH_ERROR() ((int)hipGetLastError())
 #define ICL_ERROR_STRING(e) hipGetErrorString((hipError_t)(e))
-// dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel (160 KiB per CU on gfx950)
-#define ICL_SET_MAX_DYN_LDS(kern, bytes) \
-  ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)))
+// dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel (160 KiB per CU on gfx950).  Done once per
+// call site (= per template instantiation): it is not a stream operation and must stay out of hipGraph capture.
+#define ICL_SET_MAX_DYN_LDS(kern, bytes)                                                                             \
+  do {                                                                                                               \
+    static bool icl_once_ = false;                                                                                   \
+    if (!icl_once_) {                                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
+      icl_once_ = true;                                                                                              \
+    }                                                                                                                \
+  } while (0)

@@ -44,8 +44,10 @@ __device__ __forceinline__ void sgd_range(float* __restrict__ p, const float* __
   }
 }
 
+// lr_dev (optional): learning rate read from device memory, so a captured hipGraph follows the host's poly-LR schedule
 __global__ __launch_bounds__(256) void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, long n,
-                                                           float lr, float mom, float wd, int first) {
+                                                           float lr, float mom, float wd, int first, const float* __restrict__ lr_dev) {
+  if (lr_dev) lr = *lr_dev;
   sgd_range(p, g, m, n, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, lr, mom, wd, first);
 }
 
@@ -58,7 +60,9 @@ struct SgdMulti {
 };
 
 // grid (chunks, tensors): every small tensor gets gridDim.x workgroups
-__global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(SgdMulti t, float lr, float mom, float wd, int first) {
+__global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(SgdMulti t, float lr, float mom, float wd, int first,
+                                                                 const float* __restrict__ lr_dev) {
+  if (lr_dev) lr = *lr_dev;
   const int k = blockIdx.y;
   sgd_range(t.p[k], t.g[k], t.m[k], t.n[k], (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, lr, mom, wd, first);
 }

@@ -442,15 +442,38 @@ def depthwise_conv3d(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
 # Dropout — nn.Dropout(p=0.3), unet_3D_icl.py:67-68
 # --------------------------------------------------------------------------------------
 
+class StepRNG:
+    """Device-resident step counter for dropout under hipGraph replay: a captured launch bakes its scalar arguments in,
+    so the per-step variation of the mask comes from this counter (incremented on the device at the end of every step)
+    and the per-call variation from a host-side call index that is identical in every replay."""
+    tensor: Optional[torch.Tensor] = None
+    calls = 0
+
+    @classmethod
+    def enable(cls, device):
+        cls.tensor = torch.zeros(1, dtype=torch.int32, device=device)
+        cls.calls = 0
+
+    @classmethod
+    def begin_step(cls):
+        cls.calls = 0
+
+    @classmethod
+    def end_step(cls):
+        if cls.tensor is not None:
+            cls.tensor += 1
+
+
 class _Dropout(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, seed):
+    def forward(ctx, x, p, seed, seed_dev):
         _require(x)
         L = _lib.lib()
         x = x.contiguous()
         y = torch.empty_like(x)
-        _lib.check(L.icl_dropout(_ptr(x), _ptr(y), x.numel(), seed, p, _stream(x)), "dropout")
+        _lib.check(L.icl_dropout(_ptr(x), _ptr(y), x.numel(), seed, p, _ptr(seed_dev), _stream(x)), "dropout")
         ctx.cfg = (p, seed)
+        ctx.seed_dev = seed_dev
         return y
 
     @staticmethod
@@ -459,18 +482,22 @@ class _Dropout(torch.autograd.Function):
         p, seed = ctx.cfg
         gy = gy.contiguous()
         gx = torch.empty_like(gy)
-        _lib.check(L.icl_dropout(_ptr(gy), _ptr(gx), gy.numel(), seed, p, _stream(gy)), "dropout_bwd")
-        return gx, None, None
-
-
-_dropout_counter = [0]
+        _lib.check(L.icl_dropout(_ptr(gy), _ptr(gx), gy.numel(), seed, p, _ptr(ctx.seed_dev), _stream(gy)), "dropout_bwd")
+        return gx, None, None, None
 
 
 def dropout(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Tensor:
-    """Training-mode dropout; the seed advances with torch's CPU generator so runs are reproducible under manual_seed."""
+    """Training-mode dropout.  Eager: the seed advances with torch's CPU generator (reproducible under manual_seed).
+    With StepRNG enabled (graph capture): seed = call index, varied per step by the device-resident counter."""
+    seed_dev = None
     if seed is None:
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-    return _Dropout.apply(x, float(p), int(seed) & 0xFFFFFFFF)
+        if StepRNG.tensor is not None and StepRNG.tensor.device == x.device:
+            seed = 0x2545F491 + 7919 * StepRNG.calls
+            StepRNG.calls += 1
+            seed_dev = StepRNG.tensor
+        else:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return _Dropout.apply(x, float(p), int(seed) & 0xFFFFFFFF, seed_dev)
 
 
 # --------------------------------------------------------------------------------------

@@ -21,6 +21,7 @@ class FusedSGD(torch.optim.Optimizer):
         if momentum <= 0:
             raise ValueError("FusedSGD implements the momentum form used by the ICL trainers")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self.lr_dev = None   # optional device scalar read by the kernels instead of group['lr'] (hipGraph replay)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -48,7 +49,8 @@ class FusedSGD(torch.optim.Optimizer):
                 m = st["momentum_buffer"]
                 if p.numel() >= _BIG:
                     stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream) if p.is_cuda else None
-                    _lib.check(L.icl_sgd_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), p.numel(), lr, mom, wd, first, stream),
+                    lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
+                    _lib.check(L.icl_sgd_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), p.numel(), lr, mom, wd, first, lrp, stream),
                                "sgd_step")
                 else:
                     small[first].append((p, g, m))
@@ -63,5 +65,6 @@ class FusedSGD(torch.optim.Optimizer):
                 N_ = (ctypes.c_int64 * n)(*[it[0].numel() for it in items])
                 p0 = items[0][0]
                 stream = ctypes.c_void_p(torch.cuda.current_stream(p0.device).cuda_stream) if p0.is_cuda else None
-                _lib.check(L.icl_sgd_step_multi(P_, G_, M_, N_, n, lr, mom, wd, first, stream), "sgd_step_multi")
+                lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
+                _lib.check(L.icl_sgd_step_multi(P_, G_, M_, N_, n, lr, mom, wd, first, lrp, stream), "sgd_step_multi")
         return loss

@@ -50,6 +50,8 @@ class ICLTrainer:
             self.aux_loss = L.AuxLoss(cfg.num_classes, cfg.patch_size)
             self.pse_loss = L.PseudoSoftLoss(cfg.num_classes, cfg.patch_size)
         self.iter_num = 0
+        self.graph = None
+        self.lr_dev = None
 
     def compute_loss(self, outputs, label_batch):
         cfg = self.cfg
@@ -62,9 +64,9 @@ class ICLTrainer:
         loss = loss_dice + loss_ce + loss_aux + cfg.w_pse * loss_pse + cfg.w_con * loss_con
         return loss, dict(dice=loss_dice, ce=loss_ce, aux=loss_aux, pse=loss_pse, con=loss_con)
 
-    def step(self, volume_batch: torch.Tensor, label_batch: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """One iteration; returns the (device-resident, un-synced) loss terms."""
+    def _step_body(self, volume_batch, label_batch):
         cfg = self.cfg
+        ops.StepRNG.begin_step()
         outputs = self.model(volume_batch[:cfg.labeled_bs], volume_batch[cfg.labeled_bs:])
         loss, parts = self.compute_loss(outputs, label_batch)
         self.optimizer.zero_grad(set_to_none=True)
@@ -72,12 +74,60 @@ class ICLTrainer:
         if self.ddp is not None:
             self.ddp.reduce_gradients()
         self.optimizer.step()
-        lr = cfg.base_lr * (1.0 - self.iter_num / cfg.max_iterations) ** 0.9
+        ops.StepRNG.end_step()
+        parts = {k: v.detach() for k, v in parts.items()}
+        parts["loss"] = loss.detach()
+        return parts
+
+    def _advance_lr(self):
+        cfg = self.cfg
+        lr = cfg.base_lr * (1.0 - self.iter_num / cfg.max_iterations) ** 0.9   # pre-increment iter, used from the next step
         for group in self.optimizer.param_groups:
             group["lr"] = lr
         self.iter_num += 1
-        parts["loss"] = loss.detach()
+
+    def step(self, volume_batch: torch.Tensor, label_batch: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """One iteration; returns the (device-resident, un-synced) loss terms.  After ``capture()`` the whole iteration
+        (forward, losses, backward, optimiser) is one hipGraph replay: ~1400 kernel launches per step otherwise cost
+        ~21 ms of host time, on par with the GPU time."""
+        if self.graph is not None:
+            if volume_batch.data_ptr() != self.static_vol.data_ptr():
+                self.static_vol.copy_(volume_batch)
+            if label_batch.data_ptr() != self.static_lab.data_ptr():
+                self.static_lab.copy_(label_batch)
+            self.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
+            self.graph.replay()
+            parts = self.static_out
+        else:
+            parts = self._step_body(volume_batch, label_batch)
+        self._advance_lr()
         return parts
+
+    def capture(self, volume_batch: torch.Tensor, label_batch: torch.Tensor, warmup: int = 3):
+        """Capture one full iteration into a hipGraph (torch.cuda.CUDAGraph).  Every per-step scalar the kernels need —
+        the learning rate and the dropout seed — lives in device memory (FusedSGD.lr_dev, ops.StepRNG) so that a replay
+        is a real training step: new masks, scheduled lr, updated weights.  Not used with DDP (the all-reduce stays eager)."""
+        assert self.ddp is None, "graph capture of the DDP step is not supported yet"
+        dev = volume_batch.device
+        self.static_vol = volume_batch.clone()
+        self.static_lab = label_batch.clone()
+        self.lr_dev = torch.full((1,), float(self.optimizer.param_groups[0]["lr"]), dtype=torch.float32, device=dev)
+        self.optimizer.lr_dev = self.lr_dev
+        ops.StepRNG.enable(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):   # allocator warm-up, momentum buffers, one-time kernel attributes
+                self.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
+                self._step_body(self.static_vol, self.static_lab)
+                self._advance_lr()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.static_out = self._step_body(self.static_vol, self.static_lab)
+        self.graph = graph
+        return self
 
 
 def backbone_state_dict(model: torch.nn.Module):

@@ -77,8 +77,9 @@ int icl_dwconv3_fwd(const float* x, const float* w, float* y, int n, int c, int 
 int icl_dwconv3_wgrad(const float* x, const float* gy, float* gw, int n, int c, int d, int h, int wd, void* stream);
 
 /* ---- nn.Dropout(p) (networks/unet_3D_icl.py:67-68,110,116): y = keep ? x/(1-p) : 0 with a counter-based
- * mask keyed by (seed, element index); calling it again with the same seed on dY is the backward. */
-int icl_dropout(const float* x, float* y, int64_t n, uint32_t seed, float p, void* stream);
+ * mask keyed by (seed, element index); calling it again with the same seed on dY is the backward.  seed_dev (may be
+ * NULL) is a device-resident counter folded into the seed so that replays of a captured hipGraph draw fresh masks. */
+int icl_dropout(const float* x, float* y, int64_t n, uint32_t seed, float p, const uint32_t* seed_dev, void* stream);
 
 /* ---- fused softmax + Dice / CE / soft-Dice / MSE reductions (utils/losses.py:22-59,68-90,200-231 and the
  * CrossEntropyLoss at train_inherent_consistent_unet_3D_BraTS.py:107).  a is [B,nc,S] logits (or probabilities when
@@ -112,11 +113,12 @@ int icl_attn_bwd(const float* q, const float* kv, const float* logits, const flo
                  const float* glog, float* gq, float* gkv, int b, int h, int nc, int n, int d, float scale, void* stream);
 
 /* ---- fused SGD(momentum, weight decay) step, torch.optim.SGD semantics (train_inherent_consistent_unet_3D_BraTS.py:85-86,115):
- * d = g + wd*p; m = first ? d : momentum*m + d; p -= lr*m.  The multi form takes HOST arrays of device pointers. */
+ * d = g + wd*p; m = first ? d : momentum*m + d; p -= lr*m.  The multi form takes HOST arrays of device pointers.
+ * lr_dev (may be NULL): when given, the learning rate is read from this device scalar instead of `lr` (hipGraph replay). */
 int icl_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float weight_decay, int first,
-                 void* stream);
+                 const float* lr_dev, void* stream);
 int icl_sgd_step_multi(void* const* p, const void* const* g, void* const* m, const int64_t* n, int count, float lr,
-                       float momentum, float weight_decay, int first, void* stream);
+                       float momentum, float weight_decay, int first, const float* lr_dev, void* stream);
 
 #ifdef __cplusplus
 }
