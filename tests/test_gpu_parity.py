@@ -413,3 +413,44 @@ def test_sliding_window_validation_and_checkpoint_interop(dev):
         assert (got != ref).mean() < 1e-4   # identical up to argmax ties of fp32 sums taken in a different order
         dice, hd = cal_metric(ref == 1, got == 1)
         assert dice > 0.9999
+
+
+def test_graph_replay_equals_eager_steps(dev):
+    """hipGraph replay of the whole iteration is a real training step: 2 eager + 2 replayed steps == 4 eager steps
+    (same poly-LR schedule through the device-resident lr, same updates), and dropout masks change between replays."""
+    from icl_amd import ops
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, 2).to(dev)
+    finals = []
+    for graphed in (False, True):
+        ops.StepRNG.tensor = None
+        model = unet_3D_icl(n_classes=2, in_channels=1, device=dev)
+        fill_like_reference_init(list(model.named_parameters()))
+        _parity_mode(model)
+        model.train()
+        tr = ICLTrainer(model, ICLConfig(num_classes=2, labeled_bs=1, max_iterations=10))
+        if graphed:
+            tr.capture(vol, lab, warmup=2)
+            losses = [tr.step(vol, lab)["loss"].clone() for _ in range(2)]
+        else:
+            losses = [tr.step(vol, lab)["loss"].clone() for _ in range(4)][2:]
+        assert tr.iter_num == 4
+        finals.append((model.final.weight.detach().clone(), model.sspa.class_decoders[2].mlp2.fc1.bias.detach().clone(),
+                       [float(l) for l in losses]))
+        del tr, model
+        torch.cuda.empty_cache()
+    (w0, b0, l0), (w1, b1, l1) = finals
+    assert rel_err(w1.cpu(), w0.cpu()) < 1e-4 and rel_err(b1.cpu(), b0.cpu()) < 1e-4
+    assert np.allclose(l0, l1, rtol=1e-4), (l0, l1)
+    # dropout under replay: the device-resident step counter changes the mask between replays
+    ops.StepRNG.enable(dev)
+    x = torch.ones(1 << 16, device=dev)
+    ops.StepRNG.begin_step()
+    a = ops.dropout(x, 0.3)
+    ops.StepRNG.end_step()
+    ops.StepRNG.begin_step()
+    b = ops.dropout(x, 0.3)
+    assert abs((a != 0).float().mean().item() - 0.7) < 0.02 and not torch.equal(a != 0, b != 0)
+    ops.StepRNG.tensor = None
