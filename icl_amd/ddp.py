@@ -7,8 +7,12 @@ The reference is single-GPU; this is a capability the build ad
    ``updated_Qs`` batch means and batch-wide Dice sums stay per rank by design;
  - parameters whose ``.grad`` is None after backward (33 tensors in an ICL step) are skipped,
    never zero-filled — torch SGD skips them too, so weight decay must not touch them;
- - gradients travel as fp32 in a few large flat buckets (the payload is 3.14 GB, 99 % of it the four
-   13,824^2 ``mlp2`` matrices): large buckets keep every xGMI link busy and amortise launch latency.
+ - gradients travel as fp32.  The payload is 3.14 GB and 99 % of it is twelve token-axis ``mlp2`` matrices
+   (four of them 764 MB each).  Those are produced FIRST in backward (the aligners are the last thing in forward),
+   so every large gradient is handed to RCCL the moment autograd has finished accumulating it
+   (``register_post_accumulate_grad_hook``) and its all-reduce runs on RCCL's stream underneath the whole
+   backbone backward; only the small tensors (~6 M elements, one flat bucket) are reduced after backward.
+   xGMI is point-to-point (7 links x ~153 GB/s per GPU): few, very large messages keep all links busy.
 """
 from __future__ import annotations
 
@@ -19,20 +23,35 @@ import torch.distributed as dist
 
 
 class GradientReducer:
-    def __init__(self, model: torch.nn.Module, world_size: int, bucket_bytes: int = 512 << 20):
+    def __init__(self, model: torch.nn.Module, world_size: int, bucket_bytes: int = 256 << 20, overlap_min_elems: int = 1 << 22):
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         self.world = world_size
         self.bucket_elems = max(1, bucket_bytes // 4)
-        self._flat = {}
+        self.overlap_min = overlap_min_elems
+        self._handles = []
+        self._early = set()
+        self._avg = dist.is_initialized() and dist.get_backend() == "nccl"   # RCCL averages in the collective
+        if world_size > 1:
+            for p in self.params:
+                if p.numel() >= overlap_min_elems:
+                    p.register_post_accumulate_grad_hook(self._on_grad_ready)
 
     def broadcast_parameters(self, src: int = 0):
         for p in self.params:
             dist.broadcast(p.data, src)
 
+    # -- large tensors: start the all-reduce as soon as the gradient is complete, overlap with the rest of backward
+    def _on_grad_ready(self, p: torch.nn.Parameter):
+        if p.grad is None:
+            return
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._handles.append((dist.all_reduce(p.grad, op=op, async_op=True), p))
+        self._early.add(id(p))
+
     def _buckets(self):
         cur, n = [], 0
         for p in self.params:
-            if p.grad is None:
+            if p.grad is None or id(p) in self._early:
                 continue
             if cur and n + p.grad.numel() > self.bucket_elems:
                 yield cur
@@ -43,22 +62,31 @@ class GradientReducer:
             yield cur
 
     def reduce_gradients(self):
-        """Average .grad over ranks in place.  Every rank must hold the same set of non-None grads
-        (true for ICL: the set is a property of the graph, not of the data)."""
+        """Call after ``loss.backward()``: reduces the remaining (small) gradients and waits for the overlapped ones.
+        Every rank must hold the same set of non-None grads (true for ICL: a property of the graph, not of the data)."""
         if self.world == 1:
             return
         inv = 1.0 / self.world
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         for bucket in self._buckets():
             if len(bucket) == 1:
                 g = bucket[0].grad
-                dist.all_reduce(g)
-                g.mul_(inv)
+                dist.all_reduce(g, op=op)
+                if not self._avg:
+                    g.mul_(inv)
                 continue
             flat = torch.cat([p.grad.reshape(-1) for p in bucket])
-            dist.all_reduce(flat)
-            flat.mul_(inv)
+            dist.all_reduce(flat, op=op)
+            if not self._avg:
+                flat.mul_(inv)
             off = 0
             for p in bucket:
                 n = p.grad.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
+        for h, p in self._handles:
+            h.wait()
+            if not self._avg:
+                p.grad.mul_(inv)
+        self._handles.clear()
+        self._early.clear()

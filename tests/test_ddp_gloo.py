@@ -37,7 +37,9 @@ def _worker(rank, world, port, tmp):
     from icl_amd.ddp import GradientReducer
     torch.manual_seed(100 + rank)          # different initial weights per rank: broadcast must fix that
     model = Tiny()
-    red = GradientReducer(model, world, bucket_bytes=4096)   # small buckets: multi-tensor and single-tensor paths
+    # small buckets (multi-tensor and single-tensor paths) and a low overlap threshold so that `big` takes the
+    # start-the-all-reduce-from-the-autograd-hook path that the 764 MB mlp2 gradients take on the GPUs
+    red = GradientReducer(model, world, bucket_bytes=4096, overlap_min_elems=10000)
     red.broadcast_parameters()
     torch.manual_seed(7)
     data = torch.randn(world, 4, 7)        # every rank knows all shards so it can build the reference result
