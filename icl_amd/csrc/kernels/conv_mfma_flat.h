@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_fwd_flat_kernel(const float* 
   const int n0 = blockIdx.y * NB;
   const long HW = (long)g.H * g.W, DHW = g.D * HW;
   const float* xb = x + (long)blockIdx.z * g.x_bstride;
-  float* yb = y + (long)blockIdx.z * g.y_bstride;
+  float* yb = g.ksplit > 1 ? g.slab + ((long)ks * gridDim.z + blockIdx.z) * g.Cout * DHW : y + (long)blockIdx.z * g.y_bstride;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int lq = lane >> 4, lr = lane & 15;
 
@@ -174,13 +174,12 @@ __global__ __launch_bounds__(256) void conv3d_mfma_fwd_flat_kernel(const float* 
     }
   }
 
-  const bool vec = TC::VEC && g.ksplit == 1;
-  const bool atomic = g.ksplit > 1;
+  const bool vec = TC::VEC;
 #pragma unroll
   for (int j = 0; j < NBT; ++j) {
     const int co = n0 + j * 16 + lr;
     if (co >= g.Cout) continue;
-    const float bv = (bias && ks == 0) ? bias[co] : 0.f;
+    const float bv = (bias && g.ksplit == 1) ? bias[co] : 0.f;
     float* yc = yb + (long)co * DHW;
 #pragma unroll
     for (int m = 0; m < MV; ++m) {
@@ -200,9 +199,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_fwd_flat_kernel(const float* 
           const int tx = vt % TC::TX, t2 = vt / TC::TX;
           const int gz = z0 + t2 / TC::TY, gy = y0 + t2 % TC::TY, gx = x0 + tx;
           if (gz < g.D && gy < g.H && gx < g.W) {
-            float* dst = yc + gz * HW + (long)gy * g.W + gx;
-            if (atomic) atomicAdd(dst, acc[m][j][r] + bv);
-            else *dst = acc[m][j][r] + bv;
+            yc[gz * HW + (long)gy * g.W + gx] = acc[m][j][r] + bv;
           }
         }
       }

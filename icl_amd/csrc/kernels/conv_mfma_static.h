@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_fwd_static_kernel(const float
   const int n0 = blockIdx.y * NB;
   const long HW = (long)g.H * g.W, DHW = g.D * HW;
   const float* xb = x + (long)blockIdx.z * g.x_bstride;
-  float* yb = y + (long)blockIdx.z * g.y_bstride;
+  float* yb = g.ksplit > 1 ? g.slab + ((long)ks * gridDim.z + blockIdx.z) * g.Cout * DHW : y + (long)blockIdx.z * g.y_bstride;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int lq = lane >> 4, lr = lane & 15;
 
@@ -166,13 +166,12 @@ __global__ __launch_bounds__(256) void conv3d_mfma_fwd_static_kernel(const float
   }
 
   // ---- epilogue: lane holds rows x = lq*4 + r of row group (wid*MV + m), column co = n0 + j*16 + lr ----
-  const bool atomic = g.ksplit > 1;
   const int gx = x0 + lq * 4;
 #pragma unroll
   for (int j = 0; j < NBT; ++j) {
     const int co = n0 + j * 16 + lr;
     if (co >= g.Cout) continue;
-    const float bv = (bias && ks == 0) ? bias[co] : 0.f;
+    const float bv = (bias && g.ksplit == 1) ? bias[co] : 0.f;
     float* yc = yb + (long)co * DHW;
 #pragma unroll
     for (int m = 0; m < MV; ++m) {
@@ -180,12 +179,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_fwd_static_kernel(const float
       const int gz = z0 + grp / TC::TY, gy = y0 + grp % TC::TY;
       if (gz < g.D && gy < g.H && gx < g.W) {
         float* dst = yc + gz * HW + (long)gy * g.W + gx;
-        if (!atomic) {
-          *reinterpret_cast<float4*>(dst) = make_float4(acc[m][j][0] + bv, acc[m][j][1] + bv, acc[m][j][2] + bv, acc[m][j][3] + bv);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[m][j][r] + bv);
-        }
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[m][j][0] + bv, acc[m][j][1] + bv, acc[m][j][2] + bv, acc[m][j][3] + bv);
       }
     }
   }

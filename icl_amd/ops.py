@@ -124,8 +124,10 @@ def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_b
     # algorithmic work of this launch: 2*taps*Cin*Cout FLOP per voxel; 4*(I+O+W) bytes
     flops = 2.0 * ks ** 3 * cin * cout * s * n
     nbytes = 4.0 * (n * s * (cin + cout) + ks ** 3 * cin * cout)
+    need = L.icl_conv3d_fwd_ws_bytes(n, cin, cout, d, h, w, ks)
+    ws = _ws(need, x) if need else None
     with _timed("conv3d_mfma_fwd_kernel", flops, nbytes, x):
-        _lib.check(L.icl_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), n, cin, cout, d, h, w, ks,
+        _lib.check(L.icl_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(ws), n, cin, cout, d, h, w, ks,
                                     x_bstride, y_bstride, _stream(x)), "conv3d_fwd")
 
 

@@ -31,8 +31,12 @@ const char* icl_last_kernel_name(void);
 int64_t icl_conv3d_packed_elems(int cout, int cin, int ks, int mode);
 int icl_conv3d_pack_weights(const float* w, float* wp, int cout, int cin, int ks, int mode, void* stream);
 /* y[n, 0:cout] = conv(x[n, 0:cin], Wp) + bias (bias may be NULL).  dgrad: call with Wp packed in mode 1,
- * x = dY, cin/cout swapped, bias NULL.  Batch strides in elements; channel stride is D*H*W. */
-int icl_conv3d_fwd(const float* x, const float* wp, const float* bias, float* y, int n, int cin, int cout, int d, int h,
+ * x = dY, cin/cout swapped, bias NULL.  Batch strides in elements; channel stride is D*H*W.
+ * ws: icl_conv3d_fwd_ws_bytes(...) bytes (0 for most shapes): launches with too few output tiles to fill the chip
+ * split their Cin range over workgroups, each split writes a partial-output slab there and a fixed-order reduction adds
+ * them (bitwise reproducible); ws may be NULL, the launch then runs unsplit. */
+int64_t icl_conv3d_fwd_ws_bytes(int n, int cin, int cout, int d, int h, int w, int ks);
+int icl_conv3d_fwd(const float* x, const float* wp, const float* bias, float* y, void* ws, int n, int cin, int cout, int d, int h,
                    int w, int ks, int64_t x_bstride, int64_t y_bstride, void* stream);
 /* gw[cout][cin][taps] = sum over batch and voxels; ws >= icl_conv3d_wgrad_ws_bytes(n,cin,cout,ks) bytes (one packed
  * partial-sum slab per workgroup row, reduced in a fixed order: bitwise reproducible).  gbias (may be NULL) [cout] = sum of gy. */
