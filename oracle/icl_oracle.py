@@ -145,15 +145,16 @@ def separable_conv3d(p: P, pre: str, x: torch.Tensor, training: bool) -> torch.T
 
 
 def inherent_consistent(p: P, pre: str, feats: Sequence[torch.Tensor], heads: Sequence[int],
-                        guided_q=None, modal: str = "labeled", training: bool = True):
-    """InherentConsistent.forward, networks/unet_3D_icl.py:202-242.
+                        guided_q=None, modal: str = "labeled", training: bool = True, q_name: str = "guided_Q"):
+    """InherentConsistent.forward, networks/unet_3D_icl.py:202-242 (swinunetr_icl.py:406-446 is the same code with the
+    learnable query named ``guide_Q``: pass ``q_name``).
 
     labeled: queries start from the learnable ``guided_Q`` and are handed down through
     ``query_convs`` (:208-221); unlabeled: each scale starts from ``guided_q[i]`` (:229).
     Returns (feat_maps[3], updated_Qs[3])."""
     bs = feats[0].shape[0]
     maps, upd = [], []
-    nxt = p[f"{pre}.guided_Q"].expand(bs, -1, -1) if modal == "labeled" else None
+    nxt = p[f"{pre}.{q_name}"].expand(bs, -1, -1) if modal == "labeled" else None
     for i, f in enumerate(feats):
         tok = _convnd(f, p[f"{pre}.proj_layers.{i}.weight"], p[f"{pre}.proj_layers.{i}.bias"])
         tok = _ln(p, f"{pre}.norm_layers.{i}", tok.flatten(2).transpose(1, 2))
@@ -330,11 +331,12 @@ def backbone_shapes(nc: int, in_ch: int, feature_scale: int = 4):
     return out
 
 
-def aligner_shapes(pre: str, in_chans: Sequence[int], res: Sequence[int], nc: int, heads: Sequence[int]):
+def aligner_shapes(pre: str, in_chans: Sequence[int], res: Sequence[int], nc: int, heads: Sequence[int],
+                   q_name: str = "guided_Q"):
     """Parameters of InherentConsistent in registration order (networks/unet_3D_icl.py:178-200):
     guided_Q first (nn.Parameter registered... last in __init__, but named_parameters lists direct
     parameters of a module before its children), then the six ModuleLists."""
-    out = [(f"{pre}guided_Q", (1, nc, in_chans[0]))]
+    out = [(f"{pre}{q_name}", (1, nc, in_chans[0]))]
     L = range(len(in_chans))
     for i in L:
         c = in_chans[i]

@@ -68,6 +68,102 @@ def install_monai_stub():
                         "monai.networks.layers": layers, "monai.utils": utils})
 
 
+def install_monai_block_stubs():
+    """SwinUNETR-ICL only: the five MONAI 1.0.1 blocks the reference imports at
+    swinunetr_icl.py:22-23 are not available (MONAI is not installed, no network).  These stand-ins follow the published
+    MONAI 1.0.1 definitions (networks/blocks/{mlp,patchembedding,dynunet_block,unetr_block}.py) and keep MONAI's
+    state_dict key names.  The goldens made with them pin the reference's OWN vendored Swin code (rows S1-S4), its model
+    wiring and the aligners (S6); the res-block / up-block arithmetic (S5) stays "parity unpinned"."""
+    from collections import OrderedDict
+
+    def _conv(cin, cout, k, stride=1, transposed=False, bias=False):
+        if transposed:
+            c = nn.ConvTranspose3d(cin, cout, kernel_size=k, stride=stride, padding=0, output_padding=0, bias=bias)
+        else:
+            c = nn.Conv3d(cin, cout, kernel_size=k, stride=stride, padding=(k - stride + 1) // 2 if k > 1 else 0, bias=bias)
+        return nn.Sequential(OrderedDict(conv=c))   # monai Convolution(conv_only=True): one child named "conv"
+
+    class MLPBlock(nn.Module):
+        def __init__(self, hidden_size, mlp_dim, dropout_rate=0.0, act="GELU", dropout_mode="vit"):
+            super().__init__()
+            self.linear1 = nn.Linear(hidden_size, mlp_dim)
+            self.linear2 = nn.Linear(mlp_dim, hidden_size)
+            self.fn = nn.GELU()
+            self.drop1 = nn.Dropout(dropout_rate)
+            self.drop2 = nn.Dropout(dropout_rate) if dropout_mode == "swin" else self.drop1
+
+        def forward(self, x):
+            return self.drop2(self.linear2(self.drop1(self.fn(self.linear1(x)))))
+
+    class PatchEmbed(nn.Module):
+        def __init__(self, patch_size=2, in_chans=1, embed_dim=48, norm_layer=None, spatial_dims=3):
+            super().__init__()
+            self.patch_size = tuple(patch_size)
+            self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+            self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+        def forward(self, x):
+            assert all(s % p == 0 for s, p in zip(x.shape[2:], self.patch_size)) and self.norm is None
+            return self.proj(x)
+
+    class UnetResBlock(nn.Module):
+        def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name, **kw):
+            super().__init__()
+            assert norm_name == "instance" and spatial_dims == 3
+            self.conv1 = _conv(in_channels, out_channels, kernel_size, stride)
+            self.conv2 = _conv(out_channels, out_channels, kernel_size, 1)
+            self.lrelu = nn.LeakyReLU(negative_slope=0.01, inplace=True)
+            self.norm1 = nn.InstanceNorm3d(out_channels)
+            self.norm2 = nn.InstanceNorm3d(out_channels)
+            self.downsample = in_channels != out_channels or stride != 1
+            if self.downsample:
+                self.conv3 = _conv(in_channels, out_channels, 1, stride)
+                self.norm3 = nn.InstanceNorm3d(out_channels)
+
+        def forward(self, inp):
+            residual = inp
+            out = self.lrelu(self.norm1(self.conv1(inp)))
+            out = self.norm2(self.conv2(out))
+            if self.downsample:
+                residual = self.norm3(self.conv3(residual))
+            out += residual
+            return self.lrelu(out)
+
+    class UnetrBasicBlock(nn.Module):
+        def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name, res_block=False):
+            super().__init__()
+            assert res_block
+            self.layer = UnetResBlock(spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name)
+
+        def forward(self, inp):
+            return self.layer(inp)
+
+    class UnetrUpBlock(nn.Module):
+        def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, upsample_kernel_size, norm_name, res_block=False):
+            super().__init__()
+            assert res_block
+            self.transp_conv = _conv(in_channels, out_channels, upsample_kernel_size, upsample_kernel_size, transposed=True)
+            self.conv_block = UnetResBlock(spatial_dims, out_channels + out_channels, out_channels, kernel_size, 1, norm_name)
+
+        def forward(self, inp, skip):
+            out = self.transp_conv(inp)
+            return self.conv_block(torch.cat((out, skip), dim=1))
+
+    class UnetOutBlock(nn.Module):
+        def __init__(self, spatial_dims, in_channels, out_channels, dropout=None):
+            super().__init__()
+            self.conv = _conv(in_channels, out_channels, 1, 1, bias=True)
+
+        def forward(self, inp):
+            return self.conv(inp)
+
+    blocks = types.ModuleType("monai.networks.blocks")
+    blocks.MLPBlock, blocks.PatchEmbed, blocks.UnetOutBlock = MLPBlock, PatchEmbed, UnetOutBlock
+    blocks.UnetrBasicBlock, blocks.UnetrUpBlock = UnetrBasicBlock, UnetrUpBlock
+    sys.modules["monai.networks.blocks"] = blocks
+    sys.modules["monai.networks"].blocks = blocks
+
+
 def import_reference():
     install_monai_stub()
     sys.argv = ["x"]
@@ -353,6 +449,69 @@ def gen_model2d(R, out, nc=4):
     print("model2d: losses", d["losses"], "grad_none", len(none))
 
 
+# ---------------------------------------------------------------- SwinUNETR-ICL (BASELINE config 4)
+def gen_swin(R, out, nc=2):
+    install_monai_block_stubs()
+    from networks.swinunetr_icl import SwinUNETR_icl
+    L = R["losses"]
+    model = SwinUNETR_icl(img_size=(96, 96, 96), in_channels=1, out_channels=nc, feature_size=48, drop_rate=0.0,
+                          attn_drop_rate=0.0, dropout_path_rate=0.0, use_checkpoint=False)   # net_factory_3d.py:54-63
+    parity_mode(model)
+    fill(model)
+    d = {}
+    d["keys"] = np.array(list(model.state_dict().keys()))
+    d["param_keys"] = np.array([k for k, _ in model.named_parameters()])
+    d["param_shapes"] = np.array([",".join(map(str, p.shape)) for _, p in model.named_parameters()])
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, nc)
+    model.train()
+    with torch.no_grad():
+        hs = model.swinViT(vol[:1], True)
+    for i, h in enumerate(hs):
+        d[f"hidden{i}_l2"] = npy(h.double().pow(2).sum().sqrt())
+        d[f"hidden{i}_sub"] = npy(h)[:, ::max(1, h.shape[1] // 8), ::max(1, h.shape[2] // 6), ::max(1, h.shape[3] // 6), ::max(1, h.shape[4] // 6)]
+    outs = model(vol[:1], vol[1:])
+    for name, t in (("final_lab", outs[0]), ("final_unlab", outs[1])):
+        d[name + "_sub"] = npy(t)[:, :, ::8, ::8, ::8]
+        d[name + "_l2"] = npy(t.double().pow(2).sum(dim=(0, 2, 3, 4)).sqrt())
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            d[f"{name}{i}"] = npy(t)
+    soft = torch.softmax(outs[0], 1)
+    l_ce = nn.CrossEntropyLoss()(outs[0], lab)
+    l_dice = L.DiceLoss(nc)(soft, lab.unsqueeze(1))
+    l_aux = L.AuxLoss3D(nc)(outs[2], lab)
+    l_pse = L.PseudoSoftLoss3D(nc)(outs[3], outs[1])
+    l_con = L.softmax_mse_loss(outs[3], outs[4])
+    loss = l_dice + l_ce + l_aux + l_pse + 10 * l_con     # train_inherent_consistent_swinunetr_3D_BraTS.py
+    d["losses"] = np.array([float(v.detach()) for v in (l_dice, l_ce, l_aux, l_pse, l_con, loss)])
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    opt.zero_grad()
+    loss.backward()
+    gn, none = {}, []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            none.append(k)
+        else:
+            gn[k] = float(p.grad.double().pow(2).sum().sqrt())
+    d["grad_none"] = np.array(none)
+    d["grad_norm_keys"] = np.array(list(gn.keys()))
+    d["grad_norms"] = np.array(list(gn.values()))
+    sd_ = dict(model.named_parameters())
+    for k in ("out.conv.conv.weight", "swinViT.patch_embed.proj.weight", "swinViT.layers1.0.blocks.1.attn.relative_position_bias_table",
+              "swinViT.layers4.0.blocks.0.attn.qkv.bias", "decoder5.transp_conv.conv.weight"):
+        g = npy(sd_[k].grad)
+        d["grad." + k] = g if g.size <= 8192 else g.reshape(-1)[::97].copy()
+    opt.step()
+    d["post_sgd_norms"] = np.array([float(p.detach().double().pow(2).sum().sqrt()) for _, p in model.named_parameters()])
+    model.eval()
+    with torch.no_grad():
+        y = model(vol[:1], inference=True)
+    d["inf_logits_sub"] = npy(y)[:, :, ::8, ::8, ::8]
+    np.savez_compressed(os.path.join(out, f"model_swinunetr_icl_nc{nc}.npz"), **d)
+    print("swin: losses", d["losses"], "grad_none", len(none), "params", sum(p.numel() for p in model.parameters()))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -367,3 +526,5 @@ if __name__ == "__main__":
         gen_model(R, HERE, 16)
     if a.only in ("all", "model2d"):
         gen_model2d(R, HERE)
+    if a.only in ("all", "swin"):
+        gen_swin(R, HERE)

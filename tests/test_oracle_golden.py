@@ -222,3 +222,56 @@ def test_2d_unet_icl_step_matches_reference():
         assert abs(got_n - r) <= 3e-3 * max(r, 1e-7) + 1e-9, (k, got_n, r)
     assert rel_err(p["decoder.out_conv.weight"].grad, g["grad.decoder.out_conv.weight"]) < 1e-4
     assert rel_err(p["encoder.in_conv.conv_conv.1.running_var"], g["buf.encoder.in_conv.conv_conv.1.running_var"]) < 1e-5
+
+
+@pytest.mark.slow
+def test_swinunetr_icl_step_matches_reference():
+    """BASELINE config 4: SwinUNETR-ICL 96^3, nc=2 — hidden states of the vendored Swin
+    encoder, forward 5-tuple, losses, grad-None set, grad norms and one SGD step of the 844 M parameter model.
+    (The five MONAI blocks are a restatement on both sides: "parity unpinned" for row S5, see oracle/swin_oracle.py.)"""
+    from oracle import swin_oracle as S
+    nc = 2
+    g = load_golden("model_swinunetr_icl_nc2.npz")
+    shapes = S.swinunetr_icl_shapes(nc)
+    assert [k for k, _ in shapes] == list(g["param_keys"])
+    assert [",".join(map(str, s)) for _, s in shapes] == list(g["param_shapes"])
+    p = S.make_swin_params(nc, requires_grad=True)
+    # parameters + relative_position_index + BatchNorm running stats
+    assert set(p.keys()) == {k for k in g["keys"] if not k.endswith("num_batches_tracked")}
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, nc)
+    with torch.no_grad():
+        hs = S.swin_vit(p, vol[:1])
+        for i, h in enumerate(hs):
+            sub = h[:, ::max(1, h.shape[1] // 8), ::max(1, h.shape[2] // 6), ::max(1, h.shape[3] // 6), ::max(1, h.shape[4] // 6)]
+            assert rel_err(sub, g[f"hidden{i}_sub"]) < 1e-4, i
+    outs = S.swinunetr_icl_forward(p, vol[:1], vol[1:], training=True)
+    assert rel_err(outs[0].detach()[:, :, ::8, ::8, ::8], g["final_lab_sub"]) < 1e-4
+    assert rel_err(outs[1].detach()[:, :, ::8, ::8, ::8], g["final_unlab_sub"]) < 1e-4
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            assert rel_err(t.detach(), g[f"{name}{i}"]) < 2e-4, (name, i)
+    total, parts = O.icl_losses(outs, lab, nc)
+    got = [float(parts[k]) for k in ("dice", "ce", "aux", "pse", "con")] + [float(total)]
+    assert np.allclose(got, g["losses"], rtol=0, atol=1e-5), (got, g["losses"])
+    total.backward()
+    none = [k for k, _ in shapes if p[k].grad is None]
+    assert none == list(g["grad_none"])
+    ref = dict(zip(g["grad_norm_keys"], g["grad_norms"]))
+    bad = []
+    for k, r in ref.items():
+        if "attn_convs1" in k and k.endswith("bias"):
+            continue
+        got_n = float(p[k].grad.double().norm())
+        if abs(got_n - r) > 2e-3 * max(r, 1e-7) + 1e-9:
+            bad.append((k, got_n, r))
+    assert not bad, bad[:10]
+    for k in ("out.conv.conv.weight", "swinViT.patch_embed.proj.weight", "swinViT.layers4.0.blocks.0.attn.qkv.bias"):
+        assert rel_err(p[k].grad, g["grad." + k]) < 2e-4, k
+    assert rel_err(p["swinViT.layers1.0.blocks.1.attn.relative_position_bias_table"].grad.reshape(-1)[::97] if
+                   p["swinViT.layers1.0.blocks.1.attn.relative_position_bias_table"].numel() > 8192 else
+                   p["swinViT.layers1.0.blocks.1.attn.relative_position_bias_table"].grad,
+                   g["grad.swinViT.layers1.0.blocks.1.attn.relative_position_bias_table"]) < 2e-4
+    O.sgd_step(p, {k: p[k].grad for k, _ in shapes}, {}, lr=0.01)
+    post = np.array([float(p[k].detach().double().norm()) for k, _ in shapes])
+    assert np.allclose(post, g["post_sgd_norms"], rtol=1e-6)
