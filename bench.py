@@ -36,7 +36,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 
 
-def cpu_baseline(num_classes: int):
+def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
     """Time the oracle (CPU port of the reference) on the bench workload: thread-pool warm-up on a 32^3 backbone,
     then ONE full ICL step (2 volumes).  Threads are capped at 16: torch-CPU oversubscribes badly on the 256-core
     GPU hosts (a 256-thread step took 222 s; 8 threads take ~10 s in the build container)."""
@@ -44,16 +44,23 @@ def cpu_baseline(num_classes: int):
     from oracle import icl_oracle as O
     threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
-    p = O.make_params(O.unet_3d_icl_shapes(num_classes), requires_grad=True)
-    p.update(O.aligner_buffers("sspa.", O.UNET3D_HEADS))
-    p.update(O.aligner_buffers("uscl.", O.UNET3D_HEADS))
-    names = [k for k, _ in O.unet_3d_icl_shapes(num_classes)]
+    if model == "swinunetr_icl":
+        from oracle import swin_oracle as S
+        p = S.make_swin_params(num_classes, requires_grad=True)
+        names = [k for k, _ in S.swinunetr_icl_shapes(num_classes)]
+        forward = S.swinunetr_icl_forward
+    else:
+        p = O.make_params(O.unet_3d_icl_shapes(num_classes), requires_grad=True)
+        p.update(O.aligner_buffers("sspa.", O.UNET3D_HEADS))
+        p.update(O.aligner_buffers("uscl.", O.UNET3D_HEADS))
+        names = [k for k, _ in O.unet_3d_icl_shapes(num_classes)]
+        forward = O.unet_3d_icl_forward
     vol = synthetic_volume((2, 1, 96, 96, 96), 1337)
     lab = synthetic_labels((1, 96, 96, 96), 4242, num_classes)
     with torch.no_grad():
         O.backbone(p, synthetic_volume((1, 1, 32, 32, 32), 5))
     t0 = time.time()
-    outs = O.unet_3d_icl_forward(p, vol[:1], vol[1:], training=True)
+    outs = forward(p, vol[:1], vol[1:], training=True)
     total, _ = O.icl_losses(outs, lab, num_classes)
     total.backward()
     O.sgd_step(p, {k: p[k].grad for k in names}, {}, lr=0.01)
@@ -68,6 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--num-classes", type=int, default=2)
+    ap.add_argument("--model", default="unet_3D_icl", choices=["unet_3D_icl", "swinunetr_icl"],
+                    help="unet_3D_icl = BASELINE configs[1] (the headline line); swinunetr_icl = configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
@@ -97,7 +106,11 @@ def main():
 
     torch.manual_seed(1337 + rank)
     nc = args.num_classes
-    model = unet_3D_icl(n_classes=nc, in_channels=1, device=dev)
+    if args.model == "swinunetr_icl":
+        from icl_amd.networks.swinunetr_icl import SwinUNETR_icl
+        model = SwinUNETR_icl(img_size=(96, 96, 96), in_channels=1, out_channels=nc, feature_size=48, device=dev)
+    else:
+        model = unet_3D_icl(n_classes=nc, in_channels=1, device=dev)
     model.train()
     if world > 1:
         ddp = GradientReducer(model, world)
@@ -166,7 +179,7 @@ def main():
             "metric": "3D volumes/sec/node (fwd+bwd, 96^3 patch)", "value": round(value, 3), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"3D U-Net ICL BraTS-shape synthetic 96x96x96, num_classes={nc}, "
+            "config": {"workload": f"{'SwinUNETR' if args.model == 'swinunetr_icl' else '3D U-Net'} ICL BraTS-shape synthetic 96x96x96, num_classes={nc}, "
                                    f"batch=2 per GPU (1 labeled + 1 unlabeled), full ICL step incl. SGD",
                        "global_batch": 2 * world, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if graphed else "eager"},
@@ -175,7 +188,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             del trainer, model
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(nc)
+            out["cpu_baseline"] = cpu_baseline(nc, args.model)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -32,6 +32,8 @@ _SIGNATURES = {
     "icl_norm_ws_bytes": (c_int64, [I, I, L]),
     "icl_norm_fwd": (c_int, [P, P, P, P, P, P, P, P, I, I, L, I, I, I, F, F, P, P]),
     "icl_norm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, L, I, I, I, P, P]),
+    "icl_norm_res_fwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, L, I, I, I, F, F, P, P]),
+    "icl_norm_res_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, L, I, I, I, P, P]),
     "icl_rstd_from_var": (c_int, [P, P, I, F, P]),
     "icl_maxpool2_fwd": (c_int, [P, P, P, L, I, I, I, I, P]),
     "icl_maxpool2_bwd": (c_int, [P, P, P, L, I, I, I, I, P]),

@@ -101,12 +101,13 @@ __global__ void rstd_from_var_kernel(const float* __restrict__ var, float* __res
   if (c < C) rstd[c] = 1.0f / sqrtf(var[c] + eps);
 }
 
-// y = act(((x-mean[g])*rstd[g]) * gamma[c] + beta[c]); act 0 = identity, 1 = ReLU, 2 = LeakyReLU(0.01) (nn.LeakyReLU default).
-// grid (nchunks, R)
+// y = act(((x-mean[g])*rstd[g]) * gamma[c] + beta[c] [+ res]); act 0 = identity, 1 = ReLU, 2 = LeakyReLU(0.01)
+// (nn.LeakyReLU default).  `res` (optional, same shape as x) is the residual branch of MONAI's UnetResBlock:
+// lrelu(norm2(conv2(.)) + residual) in one pass.   grid (nchunks, R)
 __global__ __launch_bounds__(kNormThreads) void norm_act_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    long S, int C, int batch_mode, int act) {
+    long S, int C, int batch_mode, int act, const float* __restrict__ res) {
   const long r = blockIdx.y;
   const int c = (int)(r % C);
   const int g = batch_mode ? c : (int)r;
@@ -117,12 +118,15 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_fwd_kernel(
   const long hi = (lo + kNormChunk < S) ? lo + kNormChunk : S;
   const float* xr = x + r * S;
   float* yr = y + r * S;
+  const float* rr = res ? res + r * S : nullptr;
   if ((S & 3) == 0) {
     const float4* x4 = reinterpret_cast<const float4*>(xr);
+    const float4* r4 = reinterpret_cast<const float4*>(rr);
     float4* y4 = reinterpret_cast<float4*>(yr);
     for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += kNormThreads) {
       float4 v = x4[i];
       v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+      if (rr) { const float4 q = r4[i]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
       if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       else if (act == 2) { v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y; v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w; }
       y4[i] = v;
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_fwd_kernel(
   } else {
     for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
       float v = xr[i] * sc + sh;
+      if (rr) v += rr[i];
       yr[i] = act == 1 ? fmaxf(v, 0.f) : (act == 2 && v < 0.f ? 0.01f * v : v);
     }
   }
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_fwd_kernel(
 __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_partial_kernel(
     const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ part, long S, int C, int nchunks, int batch_mode, int act) {
+    float* __restrict__ part, long S, int C, int nchunks, int batch_mode, int act, const float* __restrict__ res) {
   const long r = blockIdx.y;
   const int c = (int)(r % C);
   const int g = batch_mode ? c : (int)r;
@@ -149,11 +154,12 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_partial_kernel(
   const long hi = (lo + kNormChunk < S) ? lo + kNormChunk : S;
   const float* xr = x + r * S;
   const float* gr = gy + r * S;
+  const float* rr = res ? res + r * S : nullptr;
   float p1 = 0.f, p2 = 0.f;
   for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
     const float xh = (xr[i] - m) * rs;
     float h = gr[i];
-    if (act && !(xh * ga + be > 0.f)) h = (act == 2) ? 0.01f * h : 0.f;
+    if (act && !(xh * ga + be + (rr ? rr[i] : 0.f) > 0.f)) h = (act == 2) ? 0.01f * h : 0.f;
     p1 += h;
     p2 += h * xh;
   }
@@ -185,12 +191,12 @@ __global__ void norm_bwd_group_reduce_kernel(const float* __restrict__ part, flo
   if (batch_mode && dgamma) { dgamma[g] = p2; dbeta[g] = p1; }
 }
 
-// gx = rstd*gamma*(h - (P1 + xhat*P2)/M)   (batch statistics)   or   rstd*gamma*h   (fixed statistics)
+// gx = rstd*gamma*(h - (P1 + xhat*P2)/M)   (batch statistics)   or   rstd*gamma*h   (fixed statistics);  gres = h
 __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_apply_kernel(
     const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ gsum, float* __restrict__ gx, long S, int C, int batch_mode, int act,
-    float inv_count, int use_batch_stats) {
+    float inv_count, int use_batch_stats, const float* __restrict__ res, float* __restrict__ gres) {
   const long r = blockIdx.y;
   const int c = (int)(r % C);
   const int g = batch_mode ? c : (int)r;
@@ -204,11 +210,14 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_apply_kernel(
   const float* xr = x + r * S;
   const float* gr = gy + r * S;
   float* o = gx + r * S;
+  const float* rr = res ? res + r * S : nullptr;
+  float* go = gres ? gres + r * S : nullptr;
   for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
     const float xh = (xr[i] - m) * rs;
     float h = gr[i];
-    if (act && !(xh * ga + be > 0.f)) h = (act == 2) ? 0.01f * h : 0.f;
+    if (act && !(xh * ga + be + (rr ? rr[i] : 0.f) > 0.f)) h = (act == 2) ? 0.01f * h : 0.f;
     o[i] = k * (h - a1 - xh * a2);
+    if (go) go[i] = h;
   }
 }
 

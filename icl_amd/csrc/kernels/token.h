@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   for (int c = lane; c < C; c += stride) { const float d = xr[c] - m; q += d * d; }
   const float rs = 1.0f / sqrtf(team_sum<BLOCKROW>(q, red) / (float)C + eps);
   float* yr = y + r * C;
-  for (int c = lane; c < C; c += stride) yr[c] = (xr[c] - m) * rs * gamma[c] + beta[c];
+  for (int c = lane; c < C; c += stride) yr[c] = gamma ? (xr[c] - m) * rs * gamma[c] + beta[c] : (xr[c] - m) * rs;
   if (lane == 0) { mean[r] = m; rstd[r] = rs; }
 }
 
@@ -50,14 +50,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   const float m = mean[r], rs = rstd[r];
   float s1 = 0.f, s2 = 0.f;
   for (int c = lane; c < C; c += stride) {
-    const float g = gr[c] * gamma[c];
+    const float g = gamma ? gr[c] * gamma[c] : gr[c];
     s1 += g;
     s2 += g * (xr[c] - m) * rs;
   }
   s1 = team_sum<BLOCKROW>(s1, red) / (float)C;
   s2 = team_sum<BLOCKROW>(s2, red) / (float)C;
   float* o = gx + r * C;
-  for (int c = lane; c < C; c += stride) o[c] = rs * (gr[c] * gamma[c] - s1 - (xr[c] - m) * rs * s2);
+  for (int c = lane; c < C; c += stride) o[c] = rs * ((gamma ? gr[c] * gamma[c] : gr[c]) - s1 - (xr[c] - m) * rs * s2);
 }
 
 // dgamma[c] += sum_rows gy*xhat, dbeta[c] += sum_rows gy  (pre-zeroed).  A workgroup covers `cols` = min(C,256)

@@ -178,8 +178,9 @@ class InherentConsistent(nn.Module):
     def __init__(self, in_chans: Sequence[int], depths=(2, 2, 2), patch_size=(2, 2, 2),
                  input_resolution: Sequence[int] = (6, 12, 24), num_classes: int = 2,
                  num_heads: Sequence[int] = (16, 8, 4), norm_layer=None, patch_norm=False,
-                 spatial_dims: int = 3, drop_path_rate: float = 0.1, device=None):
+                 spatial_dims: int = 3, drop_path_rate: float = 0.1, device=None, query_name: str = "guided_Q"):
         super().__init__()
+        self._qname = query_name   # "guided_Q" in the U-Net files, "guide_Q" in swinunetr_icl.py:403
         self.in_chans, self.depth = tuple(in_chans), tuple(depths)
         self.resolutions = tuple(input_resolution)
         self.dims = spatial_dims   # 3: unet_3D_icl.py:155-242; 2: unet_icl.py:253-340 (r^2 tokens, Conv2d/BatchNorm2d)
@@ -199,7 +200,7 @@ class InherentConsistent(nn.Module):
             self.attn_convs0.append(SeparableConv3d(h, device, spatial_dims))
             self.attn_convs1.append(conv(h, 1, 1, device=device))
             self.query_convs.append(Conv1d(c, c // 2, device))
-        self.guided_Q = nn.Parameter(torch.zeros(1, num_classes, in_chans[0], device=device))
+        self.register_parameter(query_name, nn.Parameter(torch.zeros(1, num_classes, in_chans[0], device=device)))
 
     def _tokens(self, i, feat):
         """``proj_layers[i](feat).flatten(2).transpose(1, 2)`` (:212): a 1x1x1 convolution followed by the token transpose is
@@ -217,7 +218,7 @@ class InherentConsistent(nn.Module):
         ba = feats_a[0].shape[0]
         bs = ba + feats_b[0].shape[0]
         maps_a, maps_b, qs_a, qs_b = [], [], [], []
-        nxt = self.guided_Q.expand(bs, -1, -1)
+        nxt = getattr(self, self._qname).expand(bs, -1, -1)
         for i in range(len(self.depth)):
             f = torch.cat([feats_a[i], feats_b[i]], 0)
             tok = self.norm_layers[i](self._tokens(i, f))
@@ -238,7 +239,7 @@ class InherentConsistent(nn.Module):
     def forward(self, feats, guided_Q=None, modal="labeled"):
         bs = feats[0].shape[0]
         feat_maps, updated_qs = [], []
-        nxt = self.guided_Q.expand(bs, -1, -1) if modal == "labeled" else None
+        nxt = getattr(self, self._qname).expand(bs, -1, -1) if modal == "labeled" else None
         for i in range(len(self.depth)):
             tok = self._tokens(i, feats[i])
             tok = self.norm_layers[i](tok)

@@ -242,6 +242,52 @@ def instance_norm_relu(x: torch.Tensor, relu: bool = True, eps: float = 1e-5) ->
     return _NormAct.apply(x, None, None, None, None, 0, True, int(relu), eps, 0.0)
 
 
+def instance_norm_act(x: torch.Tensor, act: int, eps: float = 1e-5) -> torch.Tensor:
+    """InstanceNorm3d(affine=False) fused with act 0 none / 1 ReLU / 2 LeakyReLU(0.01) (MONAI UnetResBlock norm1+lrelu, norm3)."""
+    return _NormAct.apply(x, None, None, None, None, 0, True, int(act), eps, 0.0)
+
+
+class _InstanceNormAddAct(torch.autograd.Function):
+    """act(InstanceNorm3d(x) + res): the tail of MONAI UnetResBlock.forward in one pass (and one backward pass that
+    produces both gx and gres)."""
+
+    @staticmethod
+    def forward(ctx, x, res, act, eps):
+        _require(x, res)
+        L = _lib.lib()
+        x, res = x.contiguous(), res.contiguous()
+        assert x.shape == res.shape
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        y = torch.empty_like(x)
+        ws = _ws(L.icl_norm_ws_bytes(n, c, s), x)
+        mean = torch.empty(n * c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(n * c, dtype=torch.float32, device=x.device)
+        _lib.check(L.icl_norm_res_fwd(_ptr(x), _ptr(res), _ptr(y), _ptr(mean), _ptr(rstd), None, None, None, None, n, c, s, 0, 1, act,
+                                      eps, 0.0, _ptr(ws), _stream(x)), "norm_res_fwd")
+        ctx.save_for_backward(x, res, mean, rstd)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, res, mean, rstd = ctx.saved_tensors
+        L = _lib.lib()
+        gy = gy.contiguous()
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x)
+        ws = _ws(L.icl_norm_ws_bytes(n, c, s), x)
+        _lib.check(L.icl_norm_res_bwd(_ptr(gy), _ptr(x), _ptr(res), _ptr(mean), _ptr(rstd), None, None, _ptr(gx), _ptr(gres), None,
+                                      None, n, c, s, 0, 1, ctx.act, _ptr(ws), _stream(x)), "norm_res_bwd")
+        return gx, gres, None, None
+
+
+def instance_norm_add_act(x: torch.Tensor, res: torch.Tensor, act: int = 2, eps: float = 1e-5) -> torch.Tensor:
+    return _InstanceNormAddAct.apply(x, res, int(act), eps)
+
+
 def batch_norm_relu(x, gamma, beta, running_mean, running_var, training: bool, relu: bool = True,
                     eps: float = 1e-5, momentum: float = 0.1) -> torch.Tensor:
     """BatchNorm3d (batch statistics + running-stat update in training, running stats in eval) [+ ReLU]."""
@@ -536,14 +582,14 @@ class _LayerNorm(torch.autograd.Function):
         c = x.shape[-1]
         rows = x.numel() // c
         gx = torch.empty_like(x)
-        dg = torch.empty_like(weight)
-        db = torch.empty_like(weight)
+        dg = torch.empty_like(weight) if weight is not None else None   # no-affine: F.layer_norm(x, [C]) (swinunetr_icl.py:1214)
+        db = torch.empty_like(weight) if weight is not None else None
         _lib.check(L.icl_layernorm_bwd(_ptr(gy), _ptr(x), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dg), _ptr(db), rows, c,
                                        _stream(x)), "layernorm_bwd")
         return gx, dg, db, None
 
 
-def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+def layer_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
     return _LayerNorm.apply(x, weight, bias, eps)
 
 
@@ -570,6 +616,37 @@ class _Gelu(torch.autograd.Function):
 
 def gelu(x: torch.Tensor) -> torch.Tensor:
     return _Gelu.apply(x)
+
+
+# --------------------------------------------------------------------------------------
+# SwinUNETR pieces (networks/swinunetr_icl.py)
+# --------------------------------------------------------------------------------------
+
+def conv_transpose3d_k2s2(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """nn.ConvTranspose3d(cin, cout, kernel 2, stride 2, no bias) — MONAI UnetrUpBlock.transp_conv.  Kernel == stride, so
+    the output voxels do not overlap: out[b, co, 2z+i, 2y+j, 2x+k] = sum_ci x[b, ci, z, y, x] * W[ci, co, i, j, k], i.e. ONE
+    plain GEMM  [B*S, Cin] x [Cin, Cout*8]  (library GEMM, rocBLAS) followed by a depth-to-space shuffle."""
+    b, cin, d, h, w = x.shape
+    cout = weight.shape[1]
+    y = linear(x.flatten(2).transpose(1, 2), weight.flatten(1).t(), None)          # [B, S, Cout*8]
+    y = y.view(b, d, h, w, cout, 2, 2, 2).permute(0, 4, 1, 5, 2, 6, 3, 7)
+    return y.reshape(b, cout, 2 * d, 2 * h, 2 * w)
+
+
+def window_attention(qkv: torch.Tensor, bias: torch.Tensor, regions: Optional[torch.Tensor], heads: int, scale: float) -> torch.Tensor:
+    """WindowAttention.forward core (swinunetr_icl.py:728-747).  qkv [B_, n, 3C] (q|k|v, each head-major), bias [heads, n, n],
+    regions int32 [nW, n] or None (tokens of one window attend to each other iff their region ids match: the 0/-100 mask).
+    Returns [B_, n, C]."""
+    b_, n, c3 = qkv.shape
+    c = c3 // 3
+    q, k, v = qkv.view(b_, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4).unbind(0)
+    attn = (q * scale) @ k.transpose(-2, -1) + bias.unsqueeze(0)
+    if regions is not None:
+        nw = regions.shape[0]
+        mask = (regions.unsqueeze(1) != regions.unsqueeze(2)).to(attn.dtype) * -100.0
+        attn = (attn.view(b_ // nw, nw, heads, n, n) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, n, n)
+    attn = attn.softmax(-1)
+    return (attn @ v).transpose(1, 2).reshape(b_, n, c)
 
 
 class _ProtoAttention(torch.autograd.Function):

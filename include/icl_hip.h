@@ -55,6 +55,15 @@ int icl_norm_fwd(const float* x, float* y, float* mean, float* rstd, const float
 int icl_norm_bwd(const float* gy, const float* x, const float* mean, const float* rstd, const float* gamma,
                  const float* beta, float* gx, float* dgamma, float* dbeta, int n, int c, int64_t s, int mode,
                  int use_batch_stats, int act, void* ws, void* stream);
+/* Same, with a residual branch: y = act(norm(x) + res) and, backward, gres = act'(.) * gy next to gx.  This is the tail of
+ * MONAI 1.0.1 UnetResBlock.forward ("out = norm2(conv2(.)); out += residual; out = lrelu(out)") used by every encoder/decoder
+ * block of SwinUNETR (networks/swinunetr_icl.py:123-223).  res / gres may be NULL (then identical to icl_norm_fwd/_bwd). */
+int icl_norm_res_fwd(const float* x, const float* res, float* y, float* mean, float* rstd, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, int n, int c, int64_t s, int mode, int use_batch_stats,
+                     int act, float eps, float momentum, void* ws, void* stream);
+int icl_norm_res_bwd(const float* gy, const float* x, const float* res, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, float* gx, float* gres, float* dgamma, float* dbeta, int n, int c, int64_t s, int mode,
+                     int use_batch_stats, int act, void* ws, void* stream);
 int icl_rstd_from_var(const float* var, float* rstd, int c, float eps, void* stream);
 
 /* ---- MaxPool3d(2) (networks/unet_3D_icl.py:41-53) and MaxPool2d(2) (networks/unet_icl.py:64, pool_depth = 1 on a

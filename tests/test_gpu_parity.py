@@ -312,6 +312,66 @@ def test_full_icl_step_matches_reference_golden(dev, nc):
     assert rel_err(model.final.weight.detach().cpu(), g["post_sgd.final.weight"]) < 1e-5
 
 
+def test_swinunetr_icl_step_matches_reference_golden(dev):
+    """BASELINE configs[3]: SwinUNETR-ICL 96^3, nc=2, batch 1+1 — hidden states of the Swin encoder, forward 5-tuple,
+    losses, grad-None set, gradient norms and one SGD step against the reference golden."""
+    from icl_amd.networks.swinunetr_icl import SwinUNETR_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    nc = 2
+    g = load_golden("model_swinunetr_icl_nc2.npz")
+    model = SwinUNETR_icl(img_size=(96, 96, 96), in_channels=1, out_channels=nc, feature_size=48, device=dev)
+    assert list(model.state_dict().keys()) == list(g["keys"])
+    assert [k for k, _ in model.named_parameters()] == list(g["param_keys"])
+    fill_like_reference_init(list(model.named_parameters()))
+    _parity_mode(model)
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, nc).to(dev)
+    model.eval()
+    with torch.no_grad():
+        hs = model.swinViT(vol[:1], True)
+        for i, h in enumerate(hs):
+            sub = h[:, ::max(1, h.shape[1] // 8), ::max(1, h.shape[2] // 6), ::max(1, h.shape[3] // 6), ::max(1, h.shape[4] // 6)]
+            assert rel_err(sub.cpu(), g[f"hidden{i}_sub"]) < 1e-3, i
+        y = model(vol[:1], inference=True)
+    assert rel_err(y[:, :, ::8, ::8, ::8].cpu(), g["inf_logits_sub"]) < 1e-3
+    model.train()
+    tr = ICLTrainer(model, ICLConfig(num_classes=nc, labeled_bs=1))
+    outs = model(vol[:1], vol[1:])
+    assert rel_err(outs[0].detach()[:, :, ::8, ::8, ::8].cpu(), g["final_lab_sub"]) < 1e-3
+    assert rel_err(outs[1].detach()[:, :, ::8, ::8, ::8].cpu(), g["final_unlab_sub"]) < 1e-3
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            assert rel_err(t.detach().cpu(), g[f"{name}{i}"]) < 1e-3, (name, i)
+    loss, parts = tr.compute_loss(outs, lab)
+    got = [float(parts[k]) for k in ("dice", "ce", "aux", "pse", "con")] + [float(loss)]
+    assert np.allclose(got, g["losses"], rtol=0, atol=1e-4), (got, g["losses"])
+    tr.optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    none = [k for k, p in model.named_parameters() if p.grad is None]
+    assert none == list(g["grad_none"])
+    ref = dict(zip(g["grad_norm_keys"], g["grad_norms"]))
+    bad = []
+    for k, p in model.named_parameters():
+        if p.grad is None or ("attn_convs1" in k and k.endswith("bias")):
+            continue
+        got_n = float(p.grad.double().norm())
+        if abs(got_n - ref[k]) > 1e-2 * max(ref[k], 1e-7) + 1e-9:
+            bad.append((k, got_n, ref[k]))
+    assert not bad, bad[:10]
+    sd = dict(model.named_parameters())
+    for k in ("out.conv.conv.weight", "swinViT.patch_embed.proj.weight", "swinViT.layers4.0.blocks.0.attn.qkv.bias",
+              "decoder5.transp_conv.conv.weight", "swinViT.layers1.0.blocks.1.attn.relative_position_bias_table"):
+        gg = sd[k].grad.cpu()
+        gg = gg if gg.numel() <= 8192 else gg.reshape(-1)[::97]
+        assert rel_err(gg, g["grad." + k]) < 5e-3, k
+    tr.optimizer.step()
+    post = np.array([float(p.detach().double().norm()) for _, p in model.named_parameters()])
+    names = [k for k, _ in model.named_parameters()]
+    off = [(names[i], post[i], g["post_sgd_norms"][i]) for i in range(len(names))
+           if abs(post[i] - g["post_sgd_norms"][i]) > 1e-4 * g["post_sgd_norms"][i]]
+    assert not off, off[:8]
+
+
 def test_2d_unet_icl_step_matches_reference_golden(dev):
     """BASELINE config 1 (2D U-Net ICL, 256x256, nc=4, batch 2+2) on the HIP kernels vs the reference golden."""
     from icl_amd.networks.unet import UNet
