@@ -332,8 +332,6 @@ def test_swinunetr_icl_step_matches_reference_golden(dev):
         for i, h in enumerate(hs):
             sub = h[:, ::max(1, h.shape[1] // 8), ::max(1, h.shape[2] // 6), ::max(1, h.shape[3] // 6), ::max(1, h.shape[4] // 6)]
             assert rel_err(sub.cpu(), g[f"hidden{i}_sub"]) < 1e-3, i
-        y = model(vol[:1], inference=True)
-    assert rel_err(y[:, :, ::8, ::8, ::8].cpu(), g["inf_logits_sub"]) < 1e-3
     model.train()
     tr = ICLTrainer(model, ICLConfig(num_classes=nc, labeled_bs=1))
     outs = model(vol[:1], vol[1:])
@@ -363,13 +361,20 @@ def test_swinunetr_icl_step_matches_reference_golden(dev):
               "decoder5.transp_conv.conv.weight", "swinViT.layers1.0.blocks.1.attn.relative_position_bias_table"):
         gg = sd[k].grad.cpu()
         gg = gg if gg.numel() <= 8192 else gg.reshape(-1)[::97]
-        assert rel_err(gg, g["grad." + k]) < 5e-3, k
+        # 2e-2: the golden is the reference's fp32 CPU backward, which is itself 0.5-1 % away from an fp64 evaluation of
+        # the same graph on the deep Swin/decoder5 parameters (profiles/r1_swin_grad_accuracy.txt: HIP ~3e-4, CPU fp32
+        # ~6e-3 against the fp64 oracle) — InstanceNorm over 27..216 voxels amplifies summation-order noise.
+        assert rel_err(gg, g["grad." + k]) < 2e-2, k
     tr.optimizer.step()
     post = np.array([float(p.detach().double().norm()) for _, p in model.named_parameters()])
     names = [k for k, _ in model.named_parameters()]
     off = [(names[i], post[i], g["post_sgd_norms"][i]) for i in range(len(names))
            if abs(post[i] - g["post_sgd_norms"][i]) > 1e-4 * g["post_sgd_norms"][i]]
     assert not off, off[:8]
+    model.eval()                      # the golden's inference logits are those of the model AFTER the SGD step
+    with torch.no_grad():
+        y = model(vol[:1], inference=True)
+    assert rel_err(y[:, :, ::8, ::8, ::8].cpu(), g["inf_logits_sub"]) < 1e-3
 
 
 def test_2d_unet_icl_step_matches_reference_golden(dev):

@@ -275,3 +275,6 @@ def test_swinunetr_icl_step_matches_reference():
     O.sgd_step(p, {k: p[k].grad for k, _ in shapes}, {}, lr=0.01)
     post = np.array([float(p[k].detach().double().norm()) for k, _ in shapes])
     assert np.allclose(post, g["post_sgd_norms"], rtol=1e-6)
+    with torch.no_grad():             # the golden's inference logits are those of the model AFTER the SGD step
+        y = S.swinunetr_icl_forward(p, vol[:1], inference=True)
+    assert rel_err(y[:, :, ::8, ::8, ::8], g["inf_logits_sub"]) < 1e-4
