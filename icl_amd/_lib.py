@@ -45,6 +45,9 @@ _SIGNATURES = {
     "icl_dwconv3_wgrad": (c_int, [P, P, P, I, I, I, I, I, P]),
     "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P, P]),
     "icl_loss_fwd": (c_int, [P, P, P, P, P, P, I, I, L, I, I, P]),
+    "icl_window_attn_bias_elems": (c_int64, [I, I]),
+    "icl_window_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, F, P]),
+    "icl_window_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, F, P]),
     "icl_layernorm_fwd": (c_int, [P, P, P, P, P, P, L, I, F, P]),
     "icl_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, L, I, P]),
     "icl_gelu_fwd": (c_int, [P, P, L, P]),

@@ -1,0 +1,327 @@
+// winattn.h — Swin window attention (shifted-window multi-head self-attention inside 7x7x7 windows) on the fp32 MFMA.
+//
+// Reference: WindowAttention.forward, /root/reference/code/networks/swinunetr_icl.py:727-750 —
+//     attn = softmax((q * scale) @ k^T + relative_position_bias + shift_mask);   x = attn @ v
+// for every (window, head): n <= 343 tokens, head dim 16 in every stage of SwinUNETR (C / heads = 48/3 = ... = 16).
+// Nothing of size n x n ever reaches HBM: one workgroup owns one (window, head), keeps K and V (n x 16 each) in LDS and
+// each wave keeps the full score row block of its 16 queries in registers (22 key blocks x 4 VGPRs).
+//
+// MFMA mapping (v_mfma_f32_16x16x4_f32; lane l = (lr = l & 15, lg = l >> 4); A[row lr][k lg], B[k lg][col lr],
+// D[row 4*lg + r][col lr] in register r).  The k index of an MFMA step is only a label, so operand rows are chosen such
+// that NO register transposes are needed between the two GEMMs:
+//   S^T block = K_blk (16 keys x 16 dims) * Q_blk^T : step t uses dims 4*lg + t on both operands (one ds_read_b128 of K and
+//               one 16-byte load of Q per lane) -> lane holds S^T[key 4*lg + r][query lr];
+//   O block   = P (16 queries x 16 keys) * V_blk    : step r uses key 4*lg + r on both operands: A is exactly the score
+//               register r of the lane, B = V[key 4*lg + r][dim lr] (ds_read_b32, conflict-free with row stride 20).
+// The softmax of a query runs over the 4 registers x key blocks of a lane and the 4 lanes sharing lr (2 shuffles).
+//
+// Shift mask: instead of the dense [nW, n, n] 0/-100 tensor of compute_mask (:979-1016; 161 MB for the 48^3 stage) the
+// kernel reads the region id of every token ([nW, n] int32) and adds -100 where the ids of query and key differ.
+// Bias: [heads, n, npad] with npad = n rounded up to 16 and the pad columns = -1e30 (masks the padded keys for free).
+//
+// Backward: (a) window_attn_bwd_qkv — same ownership, Q K V dO in LDS, scores recomputed from the saved log-sum-exp;
+// pass 1 (waves own query blocks, S^T layout) gives dQ, pass 2 (waves own key blocks, S layout) gives dK and dV, so no
+// gradient needs atomics;  (b) window_attn_bwd_bias — d(bias)[h, i, j] sums dS over all windows of the batch: waves own a
+// (head, query block), walk over a slice of the windows keeping their 16 x n slab of the sum in registers, and add it to
+// HBM once at the end.
+#pragma once
+
+namespace icl {
+
+constexpr int kWaLd = 20;          // LDS row stride in floats (16 dims + 4 pad): ds_read_b128 rows and ds_read_b32 columns conflict-free
+constexpr float kWaMaskAdd = -100.0f;
+constexpr float kWaPad = -1.0e30f; // bias value of the padded key columns
+
+struct WinAttnGeom {
+  int B_, n, npad, heads, nW;      // B_ = batch * nW windows; window id of row b_ is b_ % nW (window_partition order)
+  float scale;
+};
+
+// rows [0, n) <- src[row * row_stride + 0..15] (optionally scaled), rows [n, npad) <- 0
+__device__ __forceinline__ void wa_stage_rows(float* dst, const float* __restrict__ src, long row_stride, int n, int npad, float mul) {
+  for (int it = threadIdx.x; it < npad * 4; it += blockDim.x) {
+    const int row = it >> 2, q = it & 3;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < n) {
+      v = *reinterpret_cast<const float4*>(src + row * row_stride + q * 4);
+      v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+    }
+    *reinterpret_cast<float4*>(dst + row * kWaLd + q * 4) = v;
+  }
+}
+
+// S^T block for (key block kb, the wave's query block): lane -> scores of query lr against keys kb*16 + 4*lg + r.
+__device__ __forceinline__ f32x4 wa_scores_t(const float* Ks, int kb, int lr, int lg, const float (&qv)[4], const float* brow,
+                                             const int* rid, int rq, bool masked) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float4 k4 = *reinterpret_cast<const float4*>(Ks + (kb * 16 + lr) * kWaLd + lg * 4);
+  acc = icl_mfma_16x16x4(k4.x, qv[0], acc);
+  acc = icl_mfma_16x16x4(k4.y, qv[1], acc);
+  acc = icl_mfma_16x16x4(k4.z, qv[2], acc);
+  acc = icl_mfma_16x16x4(k4.w, qv[3], acc);
+  const float4 b4 = *reinterpret_cast<const float4*>(brow + kb * 16 + lg * 4);
+  acc[0] += b4.x; acc[1] += b4.y; acc[2] += b4.z; acc[3] += b4.w;
+  if (masked) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (rid[kb * 16 + lg * 4 + r] != rq) acc[r] += kWaMaskAdd;
+  }
+  return acc;
+}
+
+// grid = B_ * heads workgroups of 256 threads; LDS = (2 * npad * 20 + npad) * 4 bytes.
+template <int NKB>
+__global__ __launch_bounds__(256) void window_attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                              const int* __restrict__ regions, float* __restrict__ out,
+                                                              float* __restrict__ lse, WinAttnGeom g) {
+  ICL_DYN_LDS(float, lds);
+  float* Ks = lds;
+  float* Vs = Ks + g.npad * kWaLd;
+  int* rid = reinterpret_cast<int*>(Vs + g.npad * kWaLd);
+  const int b_ = blockIdx.x / g.heads, h = blockIdx.x % g.heads;
+  const int C = g.heads * 16, nkb = g.npad / 16;
+  const long rs = 3L * C;
+  const float* base = qkv + (long)b_ * g.n * rs + h * 16;
+  wa_stage_rows(Ks, base + C, rs, g.n, g.npad, 1.f);
+  wa_stage_rows(Vs, base + 2 * C, rs, g.n, g.npad, 1.f);
+  const bool masked = regions != nullptr;
+  for (int i = threadIdx.x; i < g.npad; i += blockDim.x) rid[i] = (masked && i < g.n) ? regions[(long)(b_ % g.nW) * g.n + i] : 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  for (int qb = wid; qb < nkb; qb += 4) {
+    const int query = qb * 16 + lr, qc = query < g.n ? query : g.n - 1;
+    const float4 q4 = *reinterpret_cast<const float4*>(base + (long)qc * rs + lg * 4);
+    const float qv[4] = {q4.x * g.scale, q4.y * g.scale, q4.z * g.scale, q4.w * g.scale};
+    const int rq = rid[qc];
+    const float* brow = bias + ((long)h * g.n + qc) * g.npad;
+    f32x4 s[NKB];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb < nkb) {
+        s[kb] = wa_scores_t(Ks, kb, lr, lg, qv, brow, rid, rq, masked);
+        m = fmaxf(m, fmaxf(fmaxf(s[kb][0], s[kb][1]), fmaxf(s[kb][2], s[kb][3])));
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb < nkb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = expf(s[kb][r] - m);
+          s[kb][r] = p;
+          l += p;
+        }
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (lg == 0 && query < g.n) lse[((long)b_ * g.heads + h) * g.n + query] = m + logf(l);
+    const float inv = 1.0f / l;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb < nkb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o = icl_mfma_16x16x4(s[kb][r], Vs[(kb * 16 + lg * 4 + r) * kWaLd + lr], o);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = qb * 16 + lg * 4 + r;
+      const float iv = __shfl(inv, lg * 4 + r, 64);   // lane (lr = 4*lg + r, lg = 0) holds 1/l of that query
+      if (q < g.n) out[((long)b_ * g.n + q) * C + h * 16 + lr] = o[r] * iv;
+    }
+  }
+}
+
+// grid = B_ * heads; LDS = (4 * npad * 20 + 3 * npad) * 4 bytes.  dqkv has the layout of qkv.
+__global__ __launch_bounds__(256) void window_attn_bwd_qkv_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                                  const int* __restrict__ regions, const float* __restrict__ out,
+                                                                  const float* __restrict__ lse, const float* __restrict__ dout,
+                                                                  float* __restrict__ dqkv, WinAttnGeom g) {
+  ICL_DYN_LDS(float, lds);
+  const int np = g.npad;
+  float* Qs = lds;                 // scale * Q
+  float* Ks = Qs + np * kWaLd;
+  float* Vs = Ks + np * kWaLd;
+  float* Gs = Vs + np * kWaLd;     // dO
+  float* Ls = Gs + np * kWaLd;     // log-sum-exp per query (+1e30 on pad rows -> p = 0)
+  float* Ds = Ls + np;             // delta[q] = sum_dim dO * O
+  int* rid = reinterpret_cast<int*>(Ds + np);
+  const int b_ = blockIdx.x / g.heads, h = blockIdx.x % g.heads;
+  const int C = g.heads * 16, nkb = np / 16;
+  const long rs = 3L * C;
+  const float* base = qkv + (long)b_ * g.n * rs + h * 16;
+  const float* dob = dout + (long)b_ * g.n * C + h * 16;
+  const float* ob = out + (long)b_ * g.n * C + h * 16;
+  wa_stage_rows(Qs, base, rs, g.n, np, g.scale);
+  wa_stage_rows(Ks, base + C, rs, g.n, np, 1.f);
+  wa_stage_rows(Vs, base + 2 * C, rs, g.n, np, 1.f);
+  wa_stage_rows(Gs, dob, C, g.n, np, 1.f);
+  const bool masked = regions != nullptr;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) {
+    rid[i] = (masked && i < g.n) ? regions[(long)(b_ % g.nW) * g.n + i] : 0;
+    float dl = 0.f, ls = 1.0e30f;
+    if (i < g.n) {
+      ls = lse[((long)b_ * g.heads + h) * g.n + i];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(dob + (long)i * C + q * 4);
+        const float4 b = *reinterpret_cast<const float4*>(ob + (long)i * C + q * 4);
+        dl += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+      }
+    }
+    Ls[i] = ls;
+    Ds[i] = dl;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+
+  // ---- pass 1: waves own query blocks (S^T layout) -> dQ
+  for (int qb = wid; qb < nkb; qb += 4) {
+    const int query = qb * 16 + lr, qc = query < g.n ? query : g.n - 1;
+    const float4 q4 = *reinterpret_cast<const float4*>(Qs + query * kWaLd + lg * 4);
+    const float4 g4 = *reinterpret_cast<const float4*>(Gs + query * kWaLd + lg * 4);
+    const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
+    const float lq = Ls[query], dq_ = Ds[query];
+    const int rq = rid[qc];
+    const float* brow = bias + ((long)h * g.n + qc) * np;
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < nkb; ++kb) {
+      const f32x4 s = wa_scores_t(Ks, kb, lr, lg, qv, brow, rid, rq, masked);
+      f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+      const float4 v4 = *reinterpret_cast<const float4*>(Vs + (kb * 16 + lr) * kWaLd + lg * 4);
+      dp = icl_mfma_16x16x4(v4.x, g4.x, dp);
+      dp = icl_mfma_16x16x4(v4.y, g4.y, dp);
+      dp = icl_mfma_16x16x4(v4.z, g4.z, dp);
+      dp = icl_mfma_16x16x4(v4.w, g4.w, dp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ds = expf(s[r] - lq) * (dp[r] - dq_);
+        dq = icl_mfma_16x16x4(ds, Ks[(kb * 16 + lg * 4 + r) * kWaLd + lr], dq);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = qb * 16 + lg * 4 + r;
+      if (q < g.n) dqkv[((long)b_ * g.n + q) * rs + h * 16 + lr] = dq[r] * g.scale;
+    }
+  }
+
+  // ---- pass 2: waves own key blocks (S layout: lane -> query 4*lg + r of the block, key lr) -> dK, dV
+  for (int kb = wid; kb < nkb; kb += 4) {
+    const int key = kb * 16 + lr;
+    const float4 k4 = *reinterpret_cast<const float4*>(Ks + key * kWaLd + lg * 4);
+    const float4 v4 = *reinterpret_cast<const float4*>(Vs + key * kWaLd + lg * 4);
+    const int rk = rid[key];
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < nkb; ++qb) {
+      const float4 q4 = *reinterpret_cast<const float4*>(Qs + (qb * 16 + lr) * kWaLd + lg * 4);
+      const float4 g4 = *reinterpret_cast<const float4*>(Gs + (qb * 16 + lr) * kWaLd + lg * 4);
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      s = icl_mfma_16x16x4(q4.x, k4.x, s);
+      s = icl_mfma_16x16x4(q4.y, k4.y, s);
+      s = icl_mfma_16x16x4(q4.z, k4.z, s);
+      s = icl_mfma_16x16x4(q4.w, k4.w, s);
+      dp = icl_mfma_16x16x4(g4.x, v4.x, dp);
+      dp = icl_mfma_16x16x4(g4.y, v4.y, dp);
+      dp = icl_mfma_16x16x4(g4.z, v4.z, dp);
+      dp = icl_mfma_16x16x4(g4.w, v4.w, dp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = qb * 16 + lg * 4 + r, qc = q < g.n ? q : g.n - 1;
+        float sv = s[r] + bias[((long)h * g.n + qc) * np + key];
+        if (masked && rid[qc] != rk) sv += kWaMaskAdd;
+        const float p = expf(sv - Ls[q]);
+        const float ds = p * (dp[r] - Ds[q]);
+        dv = icl_mfma_16x16x4(p, Gs[q * kWaLd + lr], dv);
+        dk = icl_mfma_16x16x4(ds, Qs[q * kWaLd + lr], dk);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = kb * 16 + lg * 4 + r;
+      if (k < g.n) {
+        float* row = dqkv + ((long)b_ * g.n + k) * rs + h * 16 + lr;
+        row[C] = dk[r];
+        row[2 * C] = dv[r];
+      }
+    }
+  }
+}
+
+// grid (ceil(nkb/4), heads, chunks); LDS = (2 * npad * 20 + npad) * 4 bytes.  dbias [heads, n, npad] must be zeroed.
+template <int NKB>
+__global__ __launch_bounds__(256) void window_attn_bwd_bias_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                                   const int* __restrict__ regions, const float* __restrict__ out,
+                                                                   const float* __restrict__ lse, const float* __restrict__ dout,
+                                                                   float* __restrict__ dbias, WinAttnGeom g) {
+  ICL_DYN_LDS(float, lds);
+  float* Ks = lds;
+  float* Vs = Ks + g.npad * kWaLd;
+  int* rid = reinterpret_cast<int*>(Vs + g.npad * kWaLd);
+  const int h = blockIdx.y, C = g.heads * 16, nkb = g.npad / 16;
+  const long rs = 3L * C;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int qb = blockIdx.x * 4 + wid;
+  const bool active = qb < nkb;
+  const int query = qb * 16 + lr, qc = (active && query < g.n) ? query : g.n - 1;
+  const bool qvalid = active && query < g.n;
+  const bool masked = regions != nullptr;
+  const float* brow = bias + ((long)h * g.n + qc) * g.npad;
+  const int per = (g.B_ + gridDim.z - 1) / gridDim.z;
+  const int b0 = blockIdx.z * per, b1 = (b0 + per < g.B_) ? b0 + per : g.B_;
+  f32x4 acc[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) acc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b_ = b0; b_ < b1; ++b_) {
+    const float* base = qkv + (long)b_ * g.n * rs + h * 16;
+    __syncthreads();
+    wa_stage_rows(Ks, base + C, rs, g.n, g.npad, 1.f);
+    wa_stage_rows(Vs, base + 2 * C, rs, g.n, g.npad, 1.f);
+    for (int i = threadIdx.x; i < g.npad; i += blockDim.x) rid[i] = (masked && i < g.n) ? regions[(long)(b_ % g.nW) * g.n + i] : 0;
+    __syncthreads();
+    if (!active) continue;
+    const float4 q4 = *reinterpret_cast<const float4*>(base + (long)qc * rs + lg * 4);
+    const float4 g4 = *reinterpret_cast<const float4*>(dout + ((long)b_ * g.n + qc) * C + h * 16 + lg * 4);
+    const float4 o4 = *reinterpret_cast<const float4*>(out + ((long)b_ * g.n + qc) * C + h * 16 + lg * 4);
+    const float qv[4] = {q4.x * g.scale, q4.y * g.scale, q4.z * g.scale, q4.w * g.scale};
+    float dl = g4.x * o4.x + g4.y * o4.y + g4.z * o4.z + g4.w * o4.w;
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    const float lq = qvalid ? lse[((long)b_ * g.heads + h) * g.n + qc] : 1.0e30f;
+    const int rq = rid[qc];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb < nkb) {
+        const f32x4 s = wa_scores_t(Ks, kb, lr, lg, qv, brow, rid, rq, masked);
+        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+        const float4 v4 = *reinterpret_cast<const float4*>(Vs + (kb * 16 + lr) * kWaLd + lg * 4);
+        dp = icl_mfma_16x16x4(v4.x, g4.x, dp);
+        dp = icl_mfma_16x16x4(v4.y, g4.y, dp);
+        dp = icl_mfma_16x16x4(v4.z, g4.z, dp);
+        dp = icl_mfma_16x16x4(v4.w, g4.w, dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[kb][r] += expf(s[r] - lq) * (dp[r] - dl);
+      }
+    }
+  }
+  if (!qvalid) return;
+  float* drow = dbias + ((long)h * g.n + query) * g.npad;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    if (kb < nkb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = kb * 16 + lg * 4 + r;
+        if (k < g.n) atomicAdd(drow + k, acc[kb][r]);
+      }
+    }
+  }
+}
+
+}  // namespace icl

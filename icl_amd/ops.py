@@ -30,7 +30,7 @@ def _require(*ts: Optional[torch.Tensor]):
     for t in ts:
         if t is None:
             continue
-        if t.dtype not in (torch.float32, torch.uint8, torch.int64):
+        if t.dtype not in (torch.float32, torch.uint8, torch.int64, torch.int32):
             raise TypeError(f"icl_amd: unsupported dtype {t.dtype}")
         if not t.is_cuda and not _lib.host_pointers_ok():
             raise RuntimeError("icl_amd: HIP kernels need device tensors (no CPU fallback)")
@@ -633,20 +633,54 @@ def conv_transpose3d_k2s2(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor
     return y.reshape(b, cout, 2 * d, 2 * h, 2 * w)
 
 
+class _WindowAttention(torch.autograd.Function):
+    """One fused MFMA kernel per direction (csrc/kernels/winattn.h): scores, bias, shift mask, softmax and P@V never leave
+    the CU; backward recomputes the scores from the saved log-sum-exp."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, regions, heads, scale):
+        _require(qkv, bias, regions)
+        L = _lib.lib()
+        qkv = qkv.contiguous()
+        b_, n, c3 = qkv.shape
+        c = c3 // 3
+        if c != heads * 16:
+            raise ValueError("icl_amd window attention: head dim must be 16 (every SwinUNETR stage has C / heads = 16)")
+        npad = (n + 15) // 16 * 16
+        bias_pad = torch.full((heads, n, npad), -1.0e30, dtype=torch.float32, device=qkv.device)
+        bias_pad[:, :, :n] = bias
+        nw = regions.shape[0] if regions is not None else 1
+        out = torch.empty((b_, n, c), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((b_, heads, n), dtype=torch.float32, device=qkv.device)
+        flops = 4.0 * b_ * heads * n * n * 16
+        with _timed("window_attn_fwd_kernel", flops, 4.0 * (qkv.numel() + out.numel()), qkv):
+            _lib.check(L.icl_window_attn_fwd(_ptr(qkv), _ptr(bias_pad), _ptr(regions), _ptr(out), _ptr(lse), b_, n, heads, nw,
+                                             scale, _stream(qkv)), "window_attn_fwd")
+        ctx.save_for_backward(qkv, bias_pad, regions, out, lse)
+        ctx.cfg = (heads, scale, nw)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, bias_pad, regions, out, lse = ctx.saved_tensors
+        heads, scale, nw = ctx.cfg
+        L = _lib.lib()
+        gout = gout.contiguous()
+        b_, n, _ = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        dbias = torch.empty_like(bias_pad) if ctx.needs_input_grad[1] else None
+        flops = 14.0 * b_ * heads * n * n * 16
+        with _timed("window_attn_bwd_kernel", flops, 4.0 * (2 * qkv.numel() + 2 * out.numel()), qkv):
+            _lib.check(L.icl_window_attn_bwd(_ptr(qkv), _ptr(bias_pad), _ptr(regions), _ptr(out), _ptr(lse), _ptr(gout), _ptr(dqkv),
+                                             _ptr(dbias), b_, n, heads, nw, scale, _stream(qkv)), "window_attn_bwd")
+        return dqkv, (dbias[:, :, :n] if dbias is not None else None), None, None, None
+
+
 def window_attention(qkv: torch.Tensor, bias: torch.Tensor, regions: Optional[torch.Tensor], heads: int, scale: float) -> torch.Tensor:
     """WindowAttention.forward core (swinunetr_icl.py:728-747).  qkv [B_, n, 3C] (q|k|v, each head-major), bias [heads, n, n],
     regions int32 [nW, n] or None (tokens of one window attend to each other iff their region ids match: the 0/-100 mask).
     Returns [B_, n, C]."""
-    b_, n, c3 = qkv.shape
-    c = c3 // 3
-    q, k, v = qkv.view(b_, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4).unbind(0)
-    attn = (q * scale) @ k.transpose(-2, -1) + bias.unsqueeze(0)
-    if regions is not None:
-        nw = regions.shape[0]
-        mask = (regions.unsqueeze(1) != regions.unsqueeze(2)).to(attn.dtype) * -100.0
-        attn = (attn.view(b_ // nw, nw, heads, n, n) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, n, n)
-    attn = attn.softmax(-1)
-    return (attn @ v).transpose(1, 2).reshape(b_, n, c)
+    return _WindowAttention.apply(qkv, bias, regions, heads, float(scale))
 
 
 class _ProtoAttention(torch.autograd.Function):

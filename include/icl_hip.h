@@ -125,6 +125,21 @@ int icl_attn_fwd(const float* q, const float* kv, float* logits, float* out, flo
 int icl_attn_bwd(const float* q, const float* kv, const float* logits, const float* stats, const float* out, const float* gout,
                  const float* glog, float* gq, float* gkv, int b, int h, int nc, int n, int d, float scale, void* stream);
 
+/* ---- Swin window attention: WindowAttention.forward core, networks/swinunetr_icl.py:728-747 —
+ *   attn = softmax((q*scale) @ k^T + relative_position_bias [+ shift mask]);  out = attn @ v   per (window, head), head dim 16.
+ * qkv  [B_, n, 3, heads, 16]  output of the qkv Linear (B_ = batch * nW windows, window id of row b_ = b_ % nW);  n <= 352
+ * bias [heads, n, npad], npad = n rounded up to 16, pad columns = -1e30 (icl_window_attn_bias_elems floats; the caller gathers
+ *      relative_position_bias_table[relative_position_index[:n,:n]] into it, :733-737)
+ * regions int32 [nW, n] or NULL: region id of every token of the rolled volume; query/key pairs with different ids get -100
+ *      (the dense attn_mask of compute_mask, :979-1016, is exactly -100 * (id_i != id_j))
+ * out [B_, n, heads*16];  lse [B_, heads, n] = log-sum-exp of every score row (saved for backward).
+ * Backward: dqkv (layout of qkv) and, if dbias != NULL, dbias [heads, n, npad] summed over all B_ windows (zeroed by the callee). */
+int64_t icl_window_attn_bias_elems(int n, int heads);
+int icl_window_attn_fwd(const float* qkv, const float* bias, const int32_t* regions, float* out, float* lse, int b_, int n, int heads,
+                        int nw, float scale, void* stream);
+int icl_window_attn_bwd(const float* qkv, const float* bias, const int32_t* regions, const float* out, const float* lse,
+                        const float* dout, float* dqkv, float* dbias, int b_, int n, int heads, int nw, float scale, void* stream);
+
 /* ---- fused SGD(momentum, weight decay) step, torch.optim.SGD semantics (train_inherent_consistent_unet_3D_BraTS.py:85-86,115):
  * d = g + wd*p; m = first ? d : momentum*m + d; p -= lr*m.  The multi form takes HOST arrays of device pointers.
  * lr_dev (may be NULL): when given, the learning rate is read from this device scalar instead of `lr` (hipGraph replay). */

@@ -88,7 +88,7 @@ def test_conv_transpose_k2s2():
 @pytest.mark.parametrize("dims,shifted", [((14, 14, 14), True), ((7, 14, 7), False), ((4, 4, 4), False)])
 def test_window_attention_matches_oracle(dims, shifted):
     """ops.window_attention (region ids) == oracle window_attention (dense 0/-100 mask), incl. clipped windows."""
-    heads, c, b = 3, 12, 2
+    heads, c, b = 3, 48, 2
     ws, ss = SW.get_window_size(dims, (7, 7, 7), (3, 3, 3))
     n = ws[0] * ws[1] * ws[2]
     nw = (dims[0] // ws[0]) * (dims[1] // ws[1]) * (dims[2] // ws[2])
@@ -108,34 +108,99 @@ def test_window_attention_matches_oracle(dims, shifted):
         assert torch.equal(dense, mask)
 
 
-@pytest.mark.parametrize("size", [32, (32, 64, 32)])
-def test_swin_transformer_matches_oracle(size):
-    """swinViT on 32^3 (stages 16/8/4/2: padded+shifted 7^3 windows, then clipped unshifted windows) and on a
-    non-cubic volume, feature_size 12, forward hidden states and parameter gradients."""
-    f = 12
-    size = (size,) * 3 if isinstance(size, int) else size
-    p = O.make_params(S.swin_vit_shapes("swinViT.", 1, f), requires_grad=True)
-    p.update(S.swin_buffers())
-    m = SW.SwinTransformer(1, f, (7, 7, 7), (2, 2, 2, 2), (3, 6, 12, 24))
-    _load(m, p, "swinViT.")
-    x = _rand((1, 1) + size, 51)
-    want = S.swin_vit(p, x)
-    got = m(x, True)
-    for i, (g, w) in enumerate(zip(got, want)):
-        assert g.shape == w.shape
-        assert rel_err(g.detach(), w.detach()) < 2e-4, i
-    gs = [_rand(w.shape, 60 + i) for i, w in enumerate(want)]
-    sum((g * t).sum() for g, t in zip(got, gs)).backward()
-    sum((w * t).sum() for w, t in zip(want, gs)).backward()
+def _window_attention_torch(qkv, bias, regions, heads, scale):
+    """WindowAttention.forward core written with torch ops (swinunetr_icl.py:728-747)."""
+    b_, n, c3 = qkv.shape
+    c = c3 // 3
+    q, k, v = qkv.view(b_, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4).unbind(0)
+    attn = (q * scale) @ k.transpose(-2, -1) + bias.unsqueeze(0)
+    if regions is not None:
+        nw = regions.shape[0]
+        mask = (regions.unsqueeze(1) != regions.unsqueeze(2)).to(attn.dtype) * -100.0
+        attn = (attn.view(b_ // nw, nw, heads, n, n) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, n, n)
+    return (attn.softmax(-1) @ v).transpose(1, 2).reshape(b_, n, c)
+
+
+@pytest.mark.parametrize("dims,shifted,batch,heads", [((14, 14, 14), True, 1, 2), ((7, 7, 7), False, 3, 1), ((6, 6, 6), False, 2, 3),
+                                                     ((4, 4, 4), False, 1, 2), ((7, 14, 7), True, 2, 1)])
+def test_window_attention_kernel_fwd_bwd(dims, shifted, batch, heads):
+    """The fused MFMA kernels (csrc/kernels/winattn.h) against the torch formula: output, dqkv and the bias gradient summed
+    over all windows; n = 343 (22 key blocks, 7 padded keys), 216 and 64, with and without the shift mask."""
+    ws, ss = SW.get_window_size(dims, (7, 7, 7), (3, 3, 3))
+    n = ws[0] * ws[1] * ws[2]
+    nw = (dims[0] // ws[0]) * (dims[1] // ws[1]) * (dims[2] // ws[2])
+    c = heads * 16
+    qkv = (_rand((batch * nw, n, 3 * c), 71) * 1.5).requires_grad_()
+    bias = _rand((heads, n, n), 72).requires_grad_()
+    regions = SW.window_regions(dims, ws, ss, "cpu") if shifted else None
+    gy = _rand((batch * nw, n, c), 73)
+    y = ops.window_attention(qkv, bias, regions, heads, 0.25)
+    y.backward(gy)
+    qr, br = qkv.detach().clone().requires_grad_(), bias.detach().clone().requires_grad_()
+    yr = _window_attention_torch(qr, br, regions, heads, 0.25)
+    yr.backward(gy)
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    assert rel_err(qkv.grad, qr.grad) < 1e-4
+    assert rel_err(bias.grad, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("grid", [(8, 8, 8), (5, 9, 5), (2, 2, 2)])
+def test_swin_stage_matches_oracle(grid):
+    """One BasicLayer (two blocks + patch merging) on small token grids: 8^3 (padded to 14^3, shifted 7^3 windows with the
+    region mask), 5x9x5 (windows clipped to 5x7x5, shift on one axis only, odd sizes -> the PatchMerging padding path; the
+    reference's pad argument order only works when all three sizes have the same parity) and 2^3
+    (one clipped window): forward and every parameter gradient against the oracle."""
+    c, heads = 48, 3
+    shapes = [(k, sh) for k, sh in S.swin_vit_shapes("swinViT.", 1, c) if k.startswith("swinViT.layers1.0.")]
+    p = O.make_params(shapes, requires_grad=True)
+    p.update({k: v for k, v in S.swin_buffers().items() if k.startswith("swinViT.layers1.0.")})
+    m = SW.BasicLayer(c, 2, heads, (7, 7, 7))
+    _load(m, p, "swinViT.layers1.0.")
+    x = _rand((2, c) + grid, 51)
+    if any(g % 2 for g in grid):
+        # the oracle restates only the even-size path of PatchMerging; compare the blocks and check the merge separately
+        xo = x.permute(0, 2, 3, 4, 1)
+        mask = S.compute_mask([-(-g // w) * w for g, w in zip(grid, SW.get_window_size(grid, (7, 7, 7)))],
+                              *SW.get_window_size(grid, (7, 7, 7), (3, 3, 3)))
+        for i in range(2):
+            xo = S.swin_block(p, f"swinViT.layers1.0.blocks.{i}", xo, mask, heads, (7, 7, 7), (0, 0, 0) if i == 0 else (3, 3, 3))
+        xg = x.permute(0, 2, 3, 4, 1).contiguous()
+        regions = SW.window_regions([-(-g // w) * w for g, w in zip(grid, SW.get_window_size(grid, (7, 7, 7)))],
+                                    *SW.get_window_size(grid, (7, 7, 7), (3, 3, 3)), "cpu")
+        for blk in m.blocks:
+            xg = blk(xg, regions)
+        assert rel_err(xg.detach(), xo.detach()) < 2e-5
+        d, h, w = grid
+        xp = F.pad(xo.detach(), (0, 0, 0, d % 2, 0, w % 2, 0, h % 2))      # swinunetr_icl.py:951, argument order as written
+        cat = torch.cat([xp[:, i::2, j::2, k::2, :] for i, j, k in SW.PatchMerging.SLICES], -1)
+        want = F.linear(F.layer_norm(cat, (8 * c,), p["swinViT.layers1.0.downsample.norm.weight"], p["swinViT.layers1.0.downsample.norm.bias"]),
+                        p["swinViT.layers1.0.downsample.reduction.weight"])
+        assert rel_err(m.downsample(xo.detach()).detach(), want.detach()) < 2e-5
+        return
+    want = S.basic_layer(p, "swinViT.layers1.0", x, heads)
+    got = m(x.permute(0, 2, 3, 4, 1).contiguous()).permute(0, 4, 1, 2, 3)
+    assert rel_err(got.detach(), want.detach()) < 2e-5
+    gy = _rand(want.shape, 60)
+    (got * gy).sum().backward()
+    (want * gy).sum().backward()
     bad = []
     for k, t in m.named_parameters():
-        r = p["swinViT." + k].grad
-        if r is None:
-            assert t.grad is None or float(t.grad.abs().max()) == 0.0, k
-            continue
-        if rel_err(t.grad, r) > 2e-3:
+        r = p["swinViT.layers1.0." + k].grad
+        if rel_err(t.grad, r) > 1e-3:
             bad.append((k, rel_err(t.grad, r)))
     assert not bad, bad
+
+
+def test_patch_embed_and_hidden_state_norm():
+    p = O.make_params([("proj.weight", (48, 1, 2, 2, 2)), ("proj.bias", (48,))])
+    m = SW.PatchEmbed(1, 48)
+    _load(m, p)
+    x = _rand((2, 1, 8, 12, 4), 52)
+    want = F.conv3d(x, p["proj.weight"], p["proj.bias"], stride=2)
+    with torch.no_grad():
+        got = m(x)
+        assert rel_err(got.permute(0, 4, 1, 2, 3), want) < 1e-5
+        assert rel_err(SW.SwinTransformer.proj_out(got, True), S.proj_out(want)) < 1e-5
 
 
 def test_state_dict_keys_match_reference():
