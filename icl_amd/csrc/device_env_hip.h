@@ -18,6 +18,9 @@ __device__ __forceinline__ f32x16 icl_mfma_32x32x2(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// v_exp_f32 based exp (2 instructions); the CPU emulation maps it to expf
+__device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
+
 #define ICL_DYN_LDS(type, name)                                              \
   extern __shared__ __attribute__((aligned(16))) unsigned char icl_dyn_lds_raw[]; \
   type* name = reinterpret_cast<type*>(icl_dyn_lds_raw)

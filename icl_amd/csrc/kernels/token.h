@@ -67,16 +67,29 @@ __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __res
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C,
                                                               long rows_per_block, int cols) {
   const int lanes = 256 / cols;
-  const int c = blockIdx.x * cols + threadIdx.x % cols;
+  const int tc = threadIdx.x % cols;
+  const int c = blockIdx.x * cols + tc;
   const int rl = threadIdx.x / cols;
-  if (c >= C || rl >= lanes) return;
+  const bool valid = c < C && rl < lanes;
   const long r0 = (long)blockIdx.y * rows_per_block;
   const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float a = 0.f, b = 0.f;
-  for (long r = r0 + rl; r < r1; r += lanes) {
-    const float g = gy[r * C + c];
-    a += g * (x[r * C + c] - mean[r]) * rstd[r];
-    b += g;
+  if (valid) {
+    for (long r = r0 + rl; r < r1; r += lanes) {
+      const float g = gy[r * C + c];
+      a += g * (x[r * C + c] - mean[r]) * rstd[r];
+      b += g;
+    }
+  }
+  // one atomic per column and workgroup: fold the row lanes through LDS first
+  __shared__ float sa[256], sb[256];
+  sa[threadIdx.x] = a;
+  sb[threadIdx.x] = b;
+  __syncthreads();
+  if (!valid || rl != 0) return;
+  for (int l = 1; l < lanes; ++l) {
+    a += sa[l * cols + tc];
+    b += sb[l * cols + tc];
   }
   atomicAdd(dgamma + c, a);
   atomicAdd(dbeta + c, b);

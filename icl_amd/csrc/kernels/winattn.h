@@ -30,12 +30,17 @@ namespace icl {
 
 constexpr int kWaLd = 20;          // LDS row stride in floats (16 dims + 4 pad): ds_read_b128 rows and ds_read_b32 columns conflict-free
 constexpr float kWaMaskAdd = -100.0f;
+constexpr int kWaThreads = 512;   // 8 waves per workgroup: two per SIMD hide the exp / LDS latency between MFMA chains
+constexpr int kWaWaves = kWaThreads / 64;
 constexpr float kWaPad = -1.0e30f; // bias value of the padded key columns
 
 struct WinAttnGeom {
   int B_, n, npad, heads, nW;      // B_ = batch * nW windows; window id of row b_ is b_ % nW (window_partition order)
   float scale;
 };
+
+// exp via v_exp_f32 (2^x): relative error ~1e-6 for |x| < 20, far inside the 1e-3 parity budget
+__device__ __forceinline__ float wa_exp(float x) { return icl_fast_exp(x); }
 
 // rows [0, n) <- src[row * row_stride + 0..15] (optionally scaled), rows [n, npad) <- 0
 __device__ __forceinline__ void wa_stage_rows(float* dst, const float* __restrict__ src, long row_stride, int n, int npad, float mul) {
@@ -69,9 +74,35 @@ __device__ __forceinline__ f32x4 wa_scores_t(const float* Ks, int kb, int lr, in
   return acc;
 }
 
-// grid = B_ * heads workgroups of 256 threads; LDS = (2 * npad * 20 + npad) * 4 bytes.
+// bias[h][i][j] = table[index[i * idx_stride + j]][h] for j < n, kWaPad for n <= j < npad
+// (relative_position_bias_table[relative_position_index[:n, :n]], swinunetr_icl.py:733-737; idx_stride = 343).
+__global__ __launch_bounds__(256) void relpos_bias_gather_kernel(const float* __restrict__ table, const long* __restrict__ index,
+                                                                 float* __restrict__ bias, int n, int npad, int heads, int idx_stride) {
+  const long total = (long)heads * n * npad;
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(it % npad);
+    const int i = (int)((it / npad) % n);
+    const int h = (int)(it / ((long)npad * n));
+    bias[it] = j < n ? table[index[(long)i * idx_stride + j] * heads + h] : kWaPad;
+  }
+}
+
+// dtable[index[i, j]][h] += dbias[h][i][j]   (dtable zeroed by the launcher; <= 343 adders per address)
+__global__ __launch_bounds__(256) void relpos_bias_scatter_kernel(const float* __restrict__ dbias, const long* __restrict__ index,
+                                                                  float* __restrict__ dtable, int n, int npad, int heads, int idx_stride) {
+  const long total = (long)heads * n * npad;
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(it % npad);
+    if (j >= n) continue;
+    const int i = (int)((it / npad) % n);
+    const int h = (int)(it / ((long)npad * n));
+    atomicAdd(dtable + index[(long)i * idx_stride + j] * heads + h, dbias[it]);
+  }
+}
+
+// grid = B_ * heads workgroups of kWaThreads threads; LDS = (2 * npad * 20 + npad) * 4 bytes.
 template <int NKB>
-__global__ __launch_bounds__(256) void window_attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+__global__ __launch_bounds__(kWaThreads) void window_attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
                                                               const int* __restrict__ regions, float* __restrict__ out,
                                                               float* __restrict__ lse, WinAttnGeom g) {
   ICL_DYN_LDS(float, lds);
@@ -88,7 +119,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const float* __res
   for (int i = threadIdx.x; i < g.npad; i += blockDim.x) rid[i] = (masked && i < g.n) ? regions[(long)(b_ % g.nW) * g.n + i] : 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
-  for (int qb = wid; qb < nkb; qb += 4) {
+  for (int qb = wid; qb < nkb; qb += kWaWaves) {
     const int query = qb * 16 + lr, qc = query < g.n ? query : g.n - 1;
     const float4 q4 = *reinterpret_cast<const float4*>(base + (long)qc * rs + lg * 4);
     const float qv[4] = {q4.x * g.scale, q4.y * g.scale, q4.z * g.scale, q4.w * g.scale};
@@ -111,7 +142,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const float* __res
       if (kb < nkb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = expf(s[kb][r] - m);
+          const float p = wa_exp(s[kb][r] - m);
           s[kb][r] = p;
           l += p;
         }
@@ -139,7 +170,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const float* __res
 }
 
 // grid = B_ * heads; LDS = (4 * npad * 20 + 3 * npad) * 4 bytes.  dqkv has the layout of qkv.
-__global__ __launch_bounds__(256) void window_attn_bwd_qkv_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+__global__ __launch_bounds__(kWaThreads) void window_attn_bwd_qkv_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
                                                                   const int* __restrict__ regions, const float* __restrict__ out,
                                                                   const float* __restrict__ lse, const float* __restrict__ dout,
                                                                   float* __restrict__ dqkv, WinAttnGeom g) {
@@ -182,7 +213,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_qkv_kernel(const float* _
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
 
   // ---- pass 1: waves own query blocks (S^T layout) -> dQ
-  for (int qb = wid; qb < nkb; qb += 4) {
+  for (int qb = wid; qb < nkb; qb += kWaWaves) {
     const int query = qb * 16 + lr, qc = query < g.n ? query : g.n - 1;
     const float4 q4 = *reinterpret_cast<const float4*>(Qs + query * kWaLd + lg * 4);
     const float4 g4 = *reinterpret_cast<const float4*>(Gs + query * kWaLd + lg * 4);
@@ -191,6 +222,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_qkv_kernel(const float* _
     const int rq = rid[qc];
     const float* brow = bias + ((long)h * g.n + qc) * np;
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
     for (int kb = 0; kb < nkb; ++kb) {
       const f32x4 s = wa_scores_t(Ks, kb, lr, lg, qv, brow, rid, rq, masked);
       f32x4 dp = {0.f, 0.f, 0.f, 0.f};
@@ -201,7 +233,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_qkv_kernel(const float* _
       dp = icl_mfma_16x16x4(v4.w, g4.w, dp);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float ds = expf(s[r] - lq) * (dp[r] - dq_);
+        const float ds = wa_exp(s[r] - lq) * (dp[r] - dq_);
         dq = icl_mfma_16x16x4(ds, Ks[(kb * 16 + lg * 4 + r) * kWaLd + lr], dq);
       }
     }
@@ -213,12 +245,13 @@ __global__ __launch_bounds__(256) void window_attn_bwd_qkv_kernel(const float* _
   }
 
   // ---- pass 2: waves own key blocks (S layout: lane -> query 4*lg + r of the block, key lr) -> dK, dV
-  for (int kb = wid; kb < nkb; kb += 4) {
+  for (int kb = wid; kb < nkb; kb += kWaWaves) {
     const int key = kb * 16 + lr;
     const float4 k4 = *reinterpret_cast<const float4*>(Ks + key * kWaLd + lg * 4);
     const float4 v4 = *reinterpret_cast<const float4*>(Vs + key * kWaLd + lg * 4);
     const int rk = rid[key];
     f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
     for (int qb = 0; qb < nkb; ++qb) {
       const float4 q4 = *reinterpret_cast<const float4*>(Qs + (qb * 16 + lr) * kWaLd + lg * 4);
       const float4 g4 = *reinterpret_cast<const float4*>(Gs + (qb * 16 + lr) * kWaLd + lg * 4);
@@ -236,7 +269,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_qkv_kernel(const float* _
         const int q = qb * 16 + lg * 4 + r, qc = q < g.n ? q : g.n - 1;
         float sv = s[r] + bias[((long)h * g.n + qc) * np + key];
         if (masked && rid[qc] != rk) sv += kWaMaskAdd;
-        const float p = expf(sv - Ls[q]);
+        const float p = wa_exp(sv - Ls[q]);
         const float ds = p * (dp[r] - Ds[q]);
         dv = icl_mfma_16x16x4(p, Gs[q * kWaLd + lr], dv);
         dk = icl_mfma_16x16x4(ds, Qs[q * kWaLd + lr], dk);
@@ -254,9 +287,9 @@ __global__ __launch_bounds__(256) void window_attn_bwd_qkv_kernel(const float* _
   }
 }
 
-// grid (ceil(nkb/4), heads, chunks); LDS = (2 * npad * 20 + npad) * 4 bytes.  dbias [heads, n, npad] must be zeroed.
+// grid (ceil(nkb/kWaWaves), heads, chunks); LDS = (2 * npad * 20 + npad) * 4 bytes.  dbias [heads, n, npad] must be zeroed.
 template <int NKB>
-__global__ __launch_bounds__(256) void window_attn_bwd_bias_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+__global__ __launch_bounds__(kWaThreads) void window_attn_bwd_bias_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
                                                                    const int* __restrict__ regions, const float* __restrict__ out,
                                                                    const float* __restrict__ lse, const float* __restrict__ dout,
                                                                    float* __restrict__ dbias, WinAttnGeom g) {
@@ -267,7 +300,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_bias_kernel(const float* 
   const int h = blockIdx.y, C = g.heads * 16, nkb = g.npad / 16;
   const long rs = 3L * C;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
-  const int qb = blockIdx.x * 4 + wid;
+  const int qb = blockIdx.x * kWaWaves + wid;
   const bool active = qb < nkb;
   const int query = qb * 16 + lr, qc = (active && query < g.n) ? query : g.n - 1;
   const bool qvalid = active && query < g.n;
@@ -306,7 +339,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_bias_kernel(const float* 
         dp = icl_mfma_16x16x4(v4.z, g4.z, dp);
         dp = icl_mfma_16x16x4(v4.w, g4.w, dp);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[kb][r] += expf(s[r] - lq) * (dp[r] - dl);
+        for (int r = 0; r < 4; ++r) acc[kb][r] += wa_exp(s[r] - lq) * (dp[r] - dl);
       }
     }
   }

@@ -100,10 +100,8 @@ class WindowAttention(nn.Module):
 
     def forward(self, x, regions):
         """x [B*nW, n, C]; regions int32 [nW, n] or None (unshifted block)."""
-        n = x.shape[1]
-        idx = self.relative_position_index[:n, :n].reshape(-1)
-        bias = self.relative_position_bias_table[idx].reshape(n, n, self.num_heads).permute(2, 0, 1).contiguous()
-        out = ops.window_attention(self.qkv(x), bias, regions, self.num_heads, self.scale)
+        out = ops.window_attention(self.qkv(x), self.relative_position_bias_table, self.relative_position_index, regions,
+                                   self.num_heads, self.scale)
         return self.proj(out)
 
 

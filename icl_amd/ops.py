@@ -635,20 +635,24 @@ def conv_transpose3d_k2s2(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor
 
 class _WindowAttention(torch.autograd.Function):
     """One fused MFMA kernel per direction (csrc/kernels/winattn.h): scores, bias, shift mask, softmax and P@V never leave
-    the CU; backward recomputes the scores from the saved log-sum-exp."""
+    the CU; backward recomputes the scores from the saved log-sum-exp.  The relative-position bias is gathered from the
+    table into the kernel's padded [heads, n, npad] layout by a small kernel (and its gradient scattered back)."""
 
     @staticmethod
-    def forward(ctx, qkv, bias, regions, heads, scale):
-        _require(qkv, bias, regions)
+    def forward(ctx, qkv, table, index, regions, heads, scale):
+        _require(qkv, table, index, regions)
         L = _lib.lib()
         qkv = qkv.contiguous()
         b_, n, c3 = qkv.shape
         c = c3 // 3
         if c != heads * 16:
             raise ValueError("icl_amd window attention: head dim must be 16 (every SwinUNETR stage has C / heads = 16)")
+        if table.shape[1] != heads or index.dim() != 2 or index.shape[0] != index.shape[1] or n > index.shape[0]:
+            raise ValueError("icl_amd window attention: table [T, heads] / index [N, N] with n <= N expected")
+        table, index = table.contiguous(), index.contiguous()
         npad = (n + 15) // 16 * 16
-        bias_pad = torch.full((heads, n, npad), -1.0e30, dtype=torch.float32, device=qkv.device)
-        bias_pad[:, :, :n] = bias
+        bias_pad = torch.empty((heads, n, npad), dtype=torch.float32, device=qkv.device)
+        _lib.check(L.icl_relpos_bias_fwd(_ptr(table), _ptr(index), _ptr(bias_pad), n, heads, index.shape[0], _stream(qkv)), "relpos_bias_fwd")
         nw = regions.shape[0] if regions is not None else 1
         out = torch.empty((b_, n, c), dtype=torch.float32, device=qkv.device)
         lse = torch.empty((b_, heads, n), dtype=torch.float32, device=qkv.device)
@@ -656,31 +660,39 @@ class _WindowAttention(torch.autograd.Function):
         with _timed("window_attn_fwd_kernel", flops, 4.0 * (qkv.numel() + out.numel()), qkv):
             _lib.check(L.icl_window_attn_fwd(_ptr(qkv), _ptr(bias_pad), _ptr(regions), _ptr(out), _ptr(lse), b_, n, heads, nw,
                                              scale, _stream(qkv)), "window_attn_fwd")
-        ctx.save_for_backward(qkv, bias_pad, regions, out, lse)
-        ctx.cfg = (heads, scale, nw)
+        ctx.save_for_backward(qkv, bias_pad, index, regions, out, lse)
+        ctx.cfg = (heads, scale, nw, table.shape[0])
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        qkv, bias_pad, regions, out, lse = ctx.saved_tensors
-        heads, scale, nw = ctx.cfg
+        qkv, bias_pad, index, regions, out, lse = ctx.saved_tensors
+        heads, scale, nw, trows = ctx.cfg
         L = _lib.lib()
         gout = gout.contiguous()
         b_, n, _ = qkv.shape
         dqkv = torch.empty_like(qkv)
-        dbias = torch.empty_like(bias_pad) if ctx.needs_input_grad[1] else None
+        need_table = ctx.needs_input_grad[1]
+        dbias = torch.empty_like(bias_pad) if need_table else None
         flops = 14.0 * b_ * heads * n * n * 16
         with _timed("window_attn_bwd_kernel", flops, 4.0 * (2 * qkv.numel() + 2 * out.numel()), qkv):
             _lib.check(L.icl_window_attn_bwd(_ptr(qkv), _ptr(bias_pad), _ptr(regions), _ptr(out), _ptr(lse), _ptr(gout), _ptr(dqkv),
                                              _ptr(dbias), b_, n, heads, nw, scale, _stream(qkv)), "window_attn_bwd")
-        return dqkv, (dbias[:, :, :n] if dbias is not None else None), None, None, None
+        dtable = None
+        if need_table:
+            dtable = torch.empty((trows, heads), dtype=torch.float32, device=qkv.device)
+            _lib.check(L.icl_relpos_bias_bwd(_ptr(dbias), _ptr(index), _ptr(dtable), trows, n, heads, index.shape[0], _stream(qkv)),
+                       "relpos_bias_bwd")
+        return dqkv, dtable, None, None, None, None
 
 
-def window_attention(qkv: torch.Tensor, bias: torch.Tensor, regions: Optional[torch.Tensor], heads: int, scale: float) -> torch.Tensor:
-    """WindowAttention.forward core (swinunetr_icl.py:728-747).  qkv [B_, n, 3C] (q|k|v, each head-major), bias [heads, n, n],
-    regions int32 [nW, n] or None (tokens of one window attend to each other iff their region ids match: the 0/-100 mask).
-    Returns [B_, n, C]."""
-    return _WindowAttention.apply(qkv, bias, regions, heads, float(scale))
+def window_attention(qkv: torch.Tensor, table: torch.Tensor, index: torch.Tensor, regions: Optional[torch.Tensor], heads: int,
+                     scale: float) -> torch.Tensor:
+    """WindowAttention.forward core (swinunetr_icl.py:728-747).  qkv [B_, n, 3C] (q|k|v, each head-major); table
+    ``relative_position_bias_table`` [T, heads] and index ``relative_position_index`` [343, 343] (the bias of a window with
+    n tokens is table[index[:n, :n]] — also for clipped windows, as the reference does); regions int32 [nW, n] or None
+    (tokens of one window attend to each other iff their region ids match: the 0/-100 mask).  Returns [B_, n, C]."""
+    return _WindowAttention.apply(qkv, table, index, regions, heads, float(scale))
 
 
 class _ProtoAttention(torch.autograd.Function):

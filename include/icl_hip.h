@@ -135,6 +135,12 @@ int icl_attn_bwd(const float* q, const float* kv, const float* logits, const flo
  * out [B_, n, heads*16];  lse [B_, heads, n] = log-sum-exp of every score row (saved for backward).
  * Backward: dqkv (layout of qkv) and, if dbias != NULL, dbias [heads, n, npad] summed over all B_ windows (zeroed by the callee). */
 int64_t icl_window_attn_bias_elems(int n, int heads);
+/* bias[h][i][j] = table[index[i*idx_stride + j]][h] (j < n), -1e30 (n <= j < npad): the gather of :733-737 into the padded layout;
+ * index = the int64 relative_position_index buffer [idx_stride, idx_stride] (343 x 343), table [table_rows, heads].
+ * Backward scatters dbias into dtable (zeroed by the callee). */
+int icl_relpos_bias_fwd(const float* table, const int64_t* index, float* bias, int n, int heads, int idx_stride, void* stream);
+int icl_relpos_bias_bwd(const float* dbias, const int64_t* index, float* dtable, int64_t table_rows, int n, int heads, int idx_stride,
+                        void* stream);
 int icl_window_attn_fwd(const float* qkv, const float* bias, const int32_t* regions, float* out, float* lse, int b_, int n, int heads,
                         int nw, float scale, void* stream);
 int icl_window_attn_bwd(const float* qkv, const float* bias, const int32_t* regions, const float* out, const float* lse,

@@ -108,10 +108,11 @@ def test_window_attention_matches_oracle(dims, shifted):
         assert torch.equal(dense, mask)
 
 
-def _window_attention_torch(qkv, bias, regions, heads, scale):
+def _window_attention_torch(qkv, table, index, regions, heads, scale):
     """WindowAttention.forward core written with torch ops (swinunetr_icl.py:728-747)."""
     b_, n, c3 = qkv.shape
     c = c3 // 3
+    bias = table[index[:n, :n].reshape(-1)].reshape(n, n, heads).permute(2, 0, 1)
     q, k, v = qkv.view(b_, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4).unbind(0)
     attn = (q * scale) @ k.transpose(-2, -1) + bias.unsqueeze(0)
     if regions is not None:
@@ -131,17 +132,18 @@ def test_window_attention_kernel_fwd_bwd(dims, shifted, batch, heads):
     nw = (dims[0] // ws[0]) * (dims[1] // ws[1]) * (dims[2] // ws[2])
     c = heads * 16
     qkv = (_rand((batch * nw, n, 3 * c), 71) * 1.5).requires_grad_()
-    bias = _rand((heads, n, n), 72).requires_grad_()
+    table = _rand((2197, heads), 72).requires_grad_()
+    index = S.relative_position_index()
     regions = SW.window_regions(dims, ws, ss, "cpu") if shifted else None
     gy = _rand((batch * nw, n, c), 73)
-    y = ops.window_attention(qkv, bias, regions, heads, 0.25)
+    y = ops.window_attention(qkv, table, index, regions, heads, 0.25)
     y.backward(gy)
-    qr, br = qkv.detach().clone().requires_grad_(), bias.detach().clone().requires_grad_()
-    yr = _window_attention_torch(qr, br, regions, heads, 0.25)
+    qr, tr = qkv.detach().clone().requires_grad_(), table.detach().clone().requires_grad_()
+    yr = _window_attention_torch(qr, tr, index, regions, heads, 0.25)
     yr.backward(gy)
     assert rel_err(y.detach(), yr.detach()) < 1e-5
     assert rel_err(qkv.grad, qr.grad) < 1e-4
-    assert rel_err(bias.grad, br.grad) < 1e-4
+    assert rel_err(table.grad, tr.grad) < 1e-4
 
 
 @pytest.mark.parametrize("grid", [(8, 8, 8), (5, 9, 5), (2, 2, 2)])
