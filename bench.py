@@ -173,6 +173,12 @@ def main():
                                  "hbm_frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
                     "per_kernel": {k: {"launches_per_step": v[0] // 3, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
                                        "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(conv.items())}}
+            wa = {k: v for k, v in summ.items() if k.startswith("window_attn")}
+            if wa:   # SwinUNETR: the fused window-attention kernels (fp32 MFMA), forward and backward (dQKV + bias gradient)
+                roof["window_attention"] = {k: {"launches_per_step": v[0] // 3, "ms_per_step": round(v[1] / 3, 3),
+                                                "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2),
+                                                "frac": round(v[2] / (v[1] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                                            for k, v in sorted(wa.items())}
 
     if rank == 0:
         out = {
