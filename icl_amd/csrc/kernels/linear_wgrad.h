@@ -1,0 +1,102 @@
+// linear_wgrad.h — weight/bias gradient of nn.Linear for TALL activations:  dW[O][I] = sum_r G[r][O] * X[r][I],  db[O] = sum_r G[r][O]
+// with r running over up to 221,184 tokens (the 48^3 x 2 token grid of SwinUNETR's first stage,
+// /root/reference/code/networks/swinunetr_icl.py:703,705,812 — qkv / proj / MLPBlock linears) while O x I is only 48..768 wide.
+// A library GEMM sees a 48x144 output and launches ten workgroups for a 221K-deep reduction (0.65 ms); the op is a pure
+// HBM stream of G and X (170 MB -> ~35 us), so the rows are split over hundreds of waves instead:
+//   wave = one 48x48 block of dW (3x3 MFMA tiles) over one slice of the rows; both MFMA operands are loaded straight from
+//   HBM in their natural layout (A[o][k=row] = G[row][o], B[k=row][i] = X[row][i]: 16 consecutive floats per row group,
+//   64-byte segments), every wave writes its partial block to its own slab, and a second kernel sums the slabs in a fixed
+//   order (bitwise reproducible, no atomics).
+#pragma once
+
+namespace icl {
+
+constexpr int kLwT = 3;             // MFMA tiles per block side: 48 x 48 outputs per wave
+constexpr int kLwB = 16 * kLwT;
+constexpr int kLwUnroll = 4;        // row groups (of 4 rows) in flight per iteration
+
+// grid (nsplit/4, ceil(O/48), ceil(I/48)), block 256 (4 waves = 4 row slices).  slab layout: [nsplit][O*I + O].
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                           float* __restrict__ slabs, long rows, int O, int I, int nsplit) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int split = blockIdx.x * 4 + wid;
+  const int o0 = blockIdx.y * kLwB, i0 = blockIdx.z * kLwB;
+  const long steps = (rows + 3) / 4;                       // row groups of 4 (one MFMA k-step each)
+  const long per = (steps + nsplit - 1) / nsplit;
+  const long s0 = (long)split * per, s1 = (s0 + per < steps) ? s0 + per : steps;
+  f32x4 acc[kLwT][kLwT];
+  float bsum[kLwT];
+#pragma unroll
+  for (int a = 0; a < kLwT; ++a) {
+    bsum[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < kLwT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bool ov[kLwT], iv[kLwT];
+#pragma unroll
+  for (int a = 0; a < kLwT; ++a) {
+    ov[a] = o0 + a * 16 + lr < O;
+    iv[a] = i0 + a * 16 + lr < I;
+  }
+  for (long s = s0; s < s1; s += kLwUnroll) {
+    float av[kLwUnroll][kLwT], bv[kLwUnroll][kLwT];
+#pragma unroll
+    for (int u = 0; u < kLwUnroll; ++u) {
+      const long r = (s + u) * 4 + lg;
+      const bool rv = (s + u) < s1 && r < rows;
+#pragma unroll
+      for (int a = 0; a < kLwT; ++a) {
+        av[u][a] = (rv && ov[a]) ? g[r * O + o0 + a * 16 + lr] : 0.f;
+        bv[u][a] = (rv && iv[a]) ? x[r * I + i0 + a * 16 + lr] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kLwUnroll; ++u)
+#pragma unroll
+      for (int a = 0; a < kLwT; ++a) {
+        bsum[a] += av[u][a];
+#pragma unroll
+        for (int b = 0; b < kLwT; ++b) acc[a][b] = icl_mfma_16x16x4(av[u][a], bv[u][b], acc[a][b]);
+      }
+  }
+  float* slab = slabs + (long)split * ((long)O * I + O);
+#pragma unroll
+  for (int a = 0; a < kLwT; ++a)
+#pragma unroll
+    for (int b = 0; b < kLwT; ++b) {
+      const int i = i0 + b * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = o0 + a * 16 + lg * 4 + r;
+        if (o < O && i < I) slab[(long)o * I + i] = acc[a][b][r];
+      }
+    }
+  if (blockIdx.z == 0) {
+#pragma unroll
+    for (int a = 0; a < kLwT; ++a) {
+      float v = bsum[a];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lg == 0 && ov[a]) slab[(long)O * I + o0 + a * 16 + lr] = v;
+    }
+  }
+}
+
+// out[e] = sum_s slabs[s][e] for e < E (E = O*I + O; dW and db are contiguous in `out`).  grid ceil(E/64), block 256.
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                  float* __restrict__ db, long E, long EW, int nsplit) {
+  __shared__ float red[4][64];
+  const int le = threadIdx.x & 63, ls = threadIdx.x >> 6;
+  const long e = (long)blockIdx.x * 64 + le;
+  float v = 0.f;
+  if (e < E)
+    for (int s = ls; s < nsplit; s += 4) v += slabs[(long)s * E + e];
+  red[ls][le] = v;
+  __syncthreads();
+  if (ls != 0 || e >= E) return;
+  v = (red[0][le] + red[1][le]) + (red[2][le] + red[3][le]);
+  if (e < EW) dw[e] = v;
+  else if (db) db[e - EW] = v;
+}
+
+}  // namespace icl

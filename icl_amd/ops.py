@@ -554,8 +554,68 @@ def dropout(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Tens
 # measure 5.8 TB/s on the weight stream of the skinny mlp2 products (profiles/) — already at the HBM roofline.
 # --------------------------------------------------------------------------------------
 
+LINEAR_WGRAD_MIN_ROWS = 2048
+
+
+def _tall_atb(a: torch.Tensor, b: torch.Tensor, want_colsum: bool):
+    """a^T b for tall row-major a [rows, A], b [rows, B] (-> [A, B]) and, optionally, the column sums of a (-> [A]).
+    rows >= LINEAR_WGRAD_MIN_ROWS: csrc/kernels/linear_wgrad.h (rows split over many waves); otherwise the library GEMM."""
+    rows, A = a.shape
+    B = b.shape[1]
+    if rows < LINEAR_WGRAD_MIN_ROWS:
+        return torch.matmul(a.t(), b), (a.sum(0) if want_colsum else None)
+    _require(a, b)
+    L = _lib.lib()
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty((A, B), dtype=torch.float32, device=a.device)
+    colsum = torch.empty(A, dtype=torch.float32, device=a.device) if want_colsum else None
+    ws = _ws(L.icl_linear_wgrad_ws_bytes(rows, A, B), a)
+    with _timed("linear_wgrad_kernel", 2.0 * rows * A * B, 4.0 * rows * (A + B), a):
+        _lib.check(L.icl_linear_wgrad(_ptr(a), _ptr(b), _ptr(out), _ptr(colsum), _ptr(ws), rows, A, B, _stream(a)), "linear_wgrad")
+    return out, colsum
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b.  Forward and dx are plain library GEMMs (rocBLAS); dW/db of TALL inputs (>= 2048 rows: the Swin token
+    grids) use csrc/kernels/linear_wgrad.h — the library runs a 221K-deep reduction on ten workgroups there."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        o, i = weight.shape
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.matmul(gy, weight)
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or need_b:
+            gw, gb = _tall_atb(gy.reshape(-1, o), x.reshape(-1, i), need_b)
+        return gx, gw, gb
+
+
+class _MatmulTall(torch.autograd.Function):
+    """y = x W for tall x [..., I] and W [I, O] (the k2s2 transposed convolution as a GEMM); dW = x^T gy on the tall path."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.matmul(x, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = torch.matmul(gy, w.t()) if ctx.needs_input_grad[0] else None
+        gw = _tall_atb(x.reshape(-1, w.shape[0]), gy.reshape(-1, w.shape[1]), False)[0] if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    return torch.nn.functional.linear(x, weight, bias)
+    return _Linear.apply(x, weight, bias)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -628,7 +688,7 @@ def conv_transpose3d_k2s2(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor
     plain GEMM  [B*S, Cin] x [Cin, Cout*8]  (library GEMM, rocBLAS) followed by a depth-to-space shuffle."""
     b, cin, d, h, w = x.shape
     cout = weight.shape[1]
-    y = linear(x.flatten(2).transpose(1, 2), weight.flatten(1).t(), None)          # [B, S, Cout*8]
+    y = _MatmulTall.apply(x.flatten(2).transpose(1, 2), weight.flatten(1))          # [B, S, Cout*8]
     y = y.view(b, d, h, w, cout, 2, 2, 2).permute(0, 4, 1, 5, 2, 6, 3, 7)
     return y.reshape(b, cout, 2 * d, 2 * h, 2 * w)
 

@@ -125,6 +125,13 @@ int icl_attn_fwd(const float* q, const float* kv, float* logits, float* out, flo
 int icl_attn_bwd(const float* q, const float* kv, const float* logits, const float* stats, const float* out, const float* gout,
                  const float* glog, float* gq, float* gkv, int b, int h, int nc, int n, int d, float scale, void* stream);
 
+/* ---- nn.Linear weight/bias gradient for tall token matrices (qkv / proj / MLPBlock linears of the Swin stages,
+ * networks/swinunetr_icl.py:703,705,812; PatchEmbed; the k2s2 transposed convolutions written as GEMMs):
+ * dw[o][i] = sum_r gy[r][o] * x[r][i], db[o] = sum_r gy[r][o] (db may be NULL); gy [rows, o], x [rows, i] row-major.
+ * Rows are split over many waves (fp32 MFMA), partial blocks go to ws (icl_linear_wgrad_ws_bytes) and are summed in a fixed order. */
+int64_t icl_linear_wgrad_ws_bytes(int64_t rows, int o, int i);
+int icl_linear_wgrad(const float* gy, const float* x, float* dw, float* db, void* ws, int64_t rows, int o, int i, void* stream);
+
 /* ---- Swin window attention: WindowAttention.forward core, networks/swinunetr_icl.py:728-747 —
  *   attn = softmax((q*scale) @ k^T + relative_position_bias [+ shift mask]);  out = attn @ v   per (window, head), head dim 16.
  * qkv  [B_, n, 3, heads, 16]  output of the qkv Linear (B_ = batch * nW windows, window id of row b_ = b_ % nW);  n <= 352

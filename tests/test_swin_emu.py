@@ -73,9 +73,29 @@ def test_layernorm_without_affine():
     assert rel_err(y.detach(), yr.detach()) < 1e-5 and rel_err(x.grad, xr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("rows,o,i,bias", [(2500, 144, 48, True), (2049, 40, 8, True), (4100, 96, 200, False)])
+def test_linear_tall_weight_gradient(rows, o, i, bias):
+    """ops.linear backward on the tall path (>= 2048 rows): dW / db from csrc/kernels/linear_wgrad.h; ragged last row group,
+    output blocks that are not multiples of 48, several row slices."""
+    x = _rand((2, rows // 2 + rows % 2, i), 81)[:, :, :].reshape(-1, i)[:rows].clone().requires_grad_()
+    w = (_rand((o, i), 82) * 0.3).requires_grad_()
+    b = _rand((o,), 83).requires_grad_() if bias else None
+    gy = _rand((rows, o), 84)
+    y = ops.linear(x, w, b)
+    y.backward(gy)
+    xr, wr = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    br = b.detach().clone().requires_grad_() if bias else None
+    yr = F.linear(xr, wr, br)
+    yr.backward(gy)
+    assert rel_err(y.detach(), yr.detach()) < 1e-5 and rel_err(x.grad, xr.grad) < 1e-5
+    assert rel_err(w.grad, wr.grad) < 1e-5
+    if bias:
+        assert rel_err(b.grad, br.grad) < 1e-5
+
+
 def test_conv_transpose_k2s2():
-    x, w = _rand((2, 5, 3, 4, 2), 31, True), _rand((5, 7, 2, 2, 2), 32, True)
-    gy = _rand((2, 7, 6, 8, 4), 33)
+    x, w = _rand((2, 5, 13, 10, 8), 31, True), _rand((5, 7, 2, 2, 2), 32, True)     # 2080 rows: tall dW path
+    gy = _rand((2, 7, 26, 20, 16), 33)
     y = ops.conv_transpose3d_k2s2(x, w)
     y.backward(gy)
     xr, wr = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
