@@ -61,11 +61,31 @@ class GradientReducer:
         if cur:
             yield cur
 
+    def _gather_factored(self):
+        """Parameters whose gradient is still factored (ops.FactoredGrads: dW = g^T x with a few dozen rows): the mean over
+        ranks of g_r^T x_r is [g_1/W; ...; g_W/W]^T [x_1; ...; x_W], so the ranks all-gather the row blocks (~1 MB per
+        13,824^2 matrix) instead of all-reducing 764 MB.  Every rank must hold the same number of rows."""
+        inv = 1.0 / self.world
+        for p in self.params:
+            fac = getattr(p, "_icl_factors", None)
+            if not fac:
+                continue
+            g = fac[0][0] if len(fac) == 1 else torch.cat([f[0] for f in fac], 0)
+            x = fac[0][1] if len(fac) == 1 else torch.cat([f[1] for f in fac], 0)
+            g = (g * inv).contiguous()
+            x = x.contiguous()
+            gs = [torch.empty_like(g) for _ in range(self.world)]
+            xs = [torch.empty_like(x) for _ in range(self.world)]
+            dist.all_gather(gs, g)
+            dist.all_gather(xs, x)
+            p._icl_factors = [(torch.cat(gs, 0), torch.cat(xs, 0))]
+
     def reduce_gradients(self):
         """Call after ``loss.backward()``: reduces the remaining (small) gradients and waits for the overlapped ones.
         Every rank must hold the same set of non-None grads (true for ICL: a property of the graph, not of the data)."""
         if self.world == 1:
             return
+        self._gather_factored()
         inv = 1.0 / self.world
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         for bucket in self._buckets():

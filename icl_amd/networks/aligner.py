@@ -29,7 +29,7 @@ class Linear(nn.Module):
                 self.bias.uniform_(-b, b)
 
     def forward(self, x):
-        return ops.linear(x, self.weight, self.bias)
+        return ops.linear(x, self.weight, self.bias, owner=self)
 
 
 class LayerNorm(nn.Module):

@@ -614,7 +614,59 @@ class _MatmulTall(torch.autograd.Function):
         return gx, gw
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+class FactoredGrads:
+    """Switch for keeping the weight gradient of HUGE Linear layers factored (ICLTrainer turns it on around its step).
+
+    The four 13,824^2 ``Class_Decoder.mlp2`` weights are 97 % of the ICL model and their gradient is a sum of
+    M = batch*classes*heads outer products, dW = g^T x.  With the switch on, backward does not form dW (764 MB each): it
+    appends the pair (g [M, out], x [M, in]) to ``weight._icl_factors`` and leaves ``weight.grad`` as None;
+    ``icl_amd.optim.FusedSGD`` applies the update straight from the factors (csrc/kernels/optim.h) and
+    ``icl_amd.ddp.GradientReducer`` all-gathers the ~1 MB factors instead of all-reducing the matrix.
+    Off (the default), ``weight.grad`` is a dense tensor as usual, e.g. for ``torch.optim.SGD`` in the reference trainers."""
+
+    enabled = False
+    min_elems = 1 << 22
+    max_rows = 512
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = FactoredGrads.enabled
+        FactoredGrads.enabled = self.on
+        return self
+
+    def __exit__(self, *a):
+        FactoredGrads.enabled = self.prev
+
+
+class _LinearFactored(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, owner):
+        ctx.save_for_backward(x, weight)
+        ctx.owner = owner
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        o, i = weight.shape
+        gx = torch.matmul(gy, weight) if ctx.needs_input_grad[0] else None
+        g2, x2 = gy.reshape(-1, o).contiguous(), x.reshape(-1, i).contiguous()
+        gb = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        param = ctx.owner.weight
+        if getattr(param, "_icl_factors", None) is None:
+            param._icl_factors = []
+        param._icl_factors.append((g2, x2))
+        return gx, None, gb, None
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], owner=None) -> torch.Tensor:
+    """F.linear.  ``owner``: the module whose ``.weight`` this is — lets the gradient stay factored (see FactoredGrads)."""
+    if (owner is not None and FactoredGrads.enabled and weight.requires_grad and weight.numel() >= FactoredGrads.min_elems
+            and x.numel() // x.shape[-1] <= FactoredGrads.max_rows and weight.shape[1] % 4 == 0 and torch.is_grad_enabled()):
+        return _LinearFactored.apply(x, weight, bias, owner)
     return _Linear.apply(x, weight, bias)
 
 

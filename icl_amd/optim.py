@@ -23,6 +23,34 @@ class FusedSGD(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.lr_dev = None   # optional device scalar read by the kernels instead of group['lr'] (hipGraph replay)
 
+    def zero_grad(self, set_to_none: bool = True):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if getattr(p, "_icl_factors", None) is not None:
+                    p._icl_factors = None
+        super().zero_grad(set_to_none=set_to_none)
+
+    def _step_factored(self, L, p, factors, lr, mom, wd):
+        """dW = sum over entries of g^T x, applied without forming it (ops.FactoredGrads, csrc/kernels/optim.h)."""
+        g = factors[0][0] if len(factors) == 1 else torch.cat([f[0] for f in factors], 0)
+        x = factors[0][1] if len(factors) == 1 else torch.cat([f[1] for f in factors], 0)
+        n, k = p.shape
+        if g.shape[1] != n or x.shape[1] != k or g.shape[0] != x.shape[0] or not p.is_contiguous():
+            raise RuntimeError("FusedSGD: factored gradient does not match its parameter")
+        if not p.is_cuda and not _lib.host_pointers_ok():
+            raise RuntimeError("FusedSGD needs device tensors (no CPU fallback)")
+        st = self.state[p]
+        first = 0
+        if "momentum_buffer" not in st:
+            st["momentum_buffer"] = torch.empty_like(p)
+            first = 1
+        m = st["momentum_buffer"]
+        stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream) if p.is_cuda else None
+        lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
+        g, x = g.contiguous(), x.contiguous()
+        _lib.check(L.icl_sgd_step_factored(p.data_ptr(), m.data_ptr(), g.data_ptr(), x.data_ptr(), g.shape[0], n, k, lr, mom, wd,
+                                           first, lrp, stream), "sgd_step_factored")
+
     @torch.no_grad()
     def step(self, closure=None):
         L = _lib.lib()
@@ -35,6 +63,13 @@ class FusedSGD(torch.optim.Optimizer):
             small = {0: [], 1: []}
             for p in group["params"]:
                 g = p.grad
+                fac = getattr(p, "_icl_factors", None)
+                if fac:
+                    if g is not None:
+                        raise RuntimeError("FusedSGD: parameter has both a dense and a factored gradient")
+                    self._step_factored(L, p, fac, lr, mom, wd)
+                    p._icl_factors = None
+                    continue
                 if g is None:
                     continue
                 if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32):

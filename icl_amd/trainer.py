@@ -34,6 +34,7 @@ class ICLConfig:
     w_pse: float = 1.0     # 0.1 in the AMOS trainer (train_..._AMOS22.py:230)
     w_con: float = 10.0    # 50 in the 2-D trainer (train_inherent_consistent_unet_2D.py:127)
     patch_size: tuple = (96, 96, 96)   # (256, 256) selects the 2-D losses (AuxLoss / PseudoSoftLoss)
+    factored_mlp2_grads: bool = True   # keep the 13,824^2 mlp2 weight gradients factored (ops.FactoredGrads)
 
 
 class ICLTrainer:
@@ -67,10 +68,11 @@ class ICLTrainer:
     def _step_body(self, volume_batch, label_batch):
         cfg = self.cfg
         ops.StepRNG.begin_step()
-        outputs = self.model(volume_batch[:cfg.labeled_bs], volume_batch[cfg.labeled_bs:])
-        loss, parts = self.compute_loss(outputs, label_batch)
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        with ops.FactoredGrads(cfg.factored_mlp2_grads):
+            outputs = self.model(volume_batch[:cfg.labeled_bs], volume_batch[cfg.labeled_bs:])
+            loss, parts = self.compute_loss(outputs, label_batch)
+            loss.backward()
         if self.ddp is not None:
             self.ddp.reduce_gradients()
         self.optimizer.step()

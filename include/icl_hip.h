@@ -158,6 +158,11 @@ int icl_window_attn_bwd(const float* qkv, const float* bias, const int32_t* regi
  * lr_dev (may be NULL): when given, the learning rate is read from this device scalar instead of `lr` (hipGraph replay). */
 int icl_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float weight_decay, int first,
                  const float* lr_dev, void* stream);
+/* The same step for a Linear weight p [n, k] whose gradient is still factored, dW[n][k] = sum_{r < rows} g[r][n] * x[r][k]
+ * (g [rows, n] = dL/dy, x [rows, k] = the layer input): the 13,824^2 token-axis MLP weights of Class_Decoder.mlp2
+ * (networks/unet_3D_icl.py:258,267) are updated in one pass over p and m without ever forming the 764 MB gradient. */
+int icl_sgd_step_factored(float* p, float* m, const float* g, const float* x, int rows, int n, int k, float lr, float momentum,
+                          float weight_decay, int first, const float* lr_dev, void* stream);
 int icl_sgd_step_multi(void* const* p, const void* const* g, void* const* m, const int64_t* n, int count, float lr,
                        float momentum, float weight_decay, int first, const float* lr_dev, void* stream);
 

@@ -72,6 +72,58 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+def _worker_factored(rank, world, port, tmp):
+    """Factored weight gradients (ops.FactoredGrads): ranks all-gather the (g, x) row blocks; the update applied by FusedSGD
+    equals SGD on the rank-averaged dense gradient."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    from build_emu import build_emu
+    from icl_amd import _lib, ops
+    from icl_amd.ddp import GradientReducer
+    from icl_amd.networks.aligner import Linear
+    from icl_amd.optim import FusedSGD
+    _lib._use_library_for_tests(build_emu(), host_pointers=True)
+    ops.FactoredGrads.min_elems = 1000
+    torch.manual_seed(3)
+    lin = Linear(64, 48)
+    red = GradientReducer(lin, world)
+    red.broadcast_parameters()
+    w0, b0 = lin.weight.detach().clone(), lin.bias.detach().clone()
+    torch.manual_seed(11)
+    data = torch.randn(world, 6, 64)
+    opt = FusedSGD(lin.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+    opt.zero_grad()
+    with ops.FactoredGrads(True):
+        lin(data[rank]).pow(2).mean().backward()
+    assert lin.weight.grad is None and lin.weight._icl_factors
+    red.reduce_gradients()
+    assert lin.weight._icl_factors[0][0].shape[0] == 6 * world
+    opt.step()
+    # reference: dense gradients of every shard on one process, averaged, torch SGD
+    rw, rb = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
+    gw, gb = torch.zeros_like(rw), torch.zeros_like(rb)
+    for r in range(world):
+        rw.grad = rb.grad = None
+        torch.nn.functional.linear(data[r], rw, rb).pow(2).mean().backward()
+        gw += rw.grad / world
+        gb += rb.grad / world
+    rw.grad, rb.grad = gw, gb
+    torch.optim.SGD([rw, rb], lr=0.1, momentum=0.9, weight_decay=1e-2).step()
+    assert torch.allclose(lin.weight.detach(), rw.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(lin.bias.detach(), rb.detach(), rtol=1e-5, atol=1e-6)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_factored_gradient_exchange_world2(tmp_path):
+    world = 2
+    from hipemu.build_emu import build_emu  # noqa: F401  (build once, before the workers race for it)
+    build_emu()
+    mp.spawn(_worker_factored, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+
+
 @pytest.mark.timeout(300)
 def test_gradient_reducer_world2(tmp_path):
     world = 2

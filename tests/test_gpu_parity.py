@@ -480,6 +480,45 @@ def test_sliding_window_validation_and_checkpoint_interop(dev):
         assert dice > 0.9999
 
 
+def test_trainer_step_with_factored_mlp2_gradients_matches_reference_golden(dev):
+    """ICLTrainer.step keeps the four 13,824^2 mlp2 weight gradients factored (ops.FactoredGrads) and FusedSGD applies them
+    without forming the matrices: every parameter after ONE step must equal the reference's post-SGD state."""
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    nc = 2
+    g = load_golden(f"model_unet3d_icl_nc{nc}.npz")
+    model = unet_3D_icl(n_classes=nc, in_channels=1, device=dev)
+    fill_like_reference_init(list(model.named_parameters()))
+    _parity_mode(model)
+    model.train()
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, nc).to(dev)
+    tr = ICLTrainer(model, ICLConfig(num_classes=nc, labeled_bs=1))
+    parts = tr.step(vol, lab)
+    got = [float(parts[k]) for k in ("dice", "ce", "aux", "pse", "con", "loss")]
+    assert np.allclose(got, g["losses"], rtol=0, atol=1e-4), (got, g["losses"])
+    big = [k for k, p in model.named_parameters() if p.numel() >= (1 << 22)]
+    assert len(big) == 4 and all(dict(model.named_parameters())[k].grad is None for k in big)   # never materialised
+    post = np.array([float(p.detach().double().norm()) for _, p in model.named_parameters()])
+    names = [k for k, _ in model.named_parameters()]
+    off = [(names[i], post[i], g["post_sgd_norms"][i]) for i in range(len(names))
+           if abs(post[i] - g["post_sgd_norms"][i]) > 1e-4 * g["post_sgd_norms"][i]]
+    assert not off, off[:8]
+    assert rel_err(model.final.weight.detach().cpu(), g["post_sgd.final.weight"]) < 1e-5
+    # the update itself, not only the norm: compare one big matrix with a dense-gradient step of a second model
+    model2 = unet_3D_icl(n_classes=nc, in_channels=1, device=dev)
+    fill_like_reference_init(list(model2.named_parameters()))
+    _parity_mode(model2)
+    model2.train()
+    tr2 = ICLTrainer(model2, ICLConfig(num_classes=nc, labeled_bs=1, factored_mlp2_grads=False))
+    tr2.step(vol, lab)
+    for k in big:
+        a, b = dict(model.named_parameters())[k].detach(), dict(model2.named_parameters())[k].detach()
+        w0 = torch.empty_like(a)
+        fill_like_reference_init([(k, w0)])
+        assert float(((a - w0) - (b - w0)).norm() / (b - w0).norm()) < 1e-3, k
+
+
 def test_graph_replay_equals_eager_steps(dev):
     """hipGraph replay of the whole iteration is a real training step: 2 eager + 2 replayed steps == 4 eager steps
     (same poly-LR schedule through the device-resident lr, same updates), and dropout masks change between replays."""

@@ -239,6 +239,39 @@ def test_fused_sgd_matches_torch():
     assert torch.equal(skip.detach(), skip_ref)
 
 
+def test_factored_gradient_sgd_matches_dense(monkeypatch):
+    """ops.FactoredGrads: the weight gradient of a huge Linear stays (g, x); FusedSGD applies g^T x + wd*p without forming it.
+    Three steps (first step initialises the momentum), two uses of the same weight in one backward (row blocks concatenate),
+    against F.linear + torch.optim.SGD with the dense gradient."""
+    from icl_amd.networks.aligner import Linear
+    from icl_amd.optim import FusedSGD
+    monkeypatch.setattr(ops.FactoredGrads, "min_elems", 1000)
+    torch.manual_seed(1)
+    lin = Linear(300, 70)            # weight [70, 300]: partial row block (70 = 4*16 + 6) and a partial 256-column slice
+    ref_w = torch.nn.Parameter(lin.weight.detach().clone())
+    ref_b = torch.nn.Parameter(lin.bias.detach().clone())
+    a = FusedSGD(lin.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-2)
+    b = torch.optim.SGD([ref_w, ref_b], lr=0.05, momentum=0.9, weight_decay=1e-2)
+    for it in range(3):
+        x1, x2 = _rand((2, 19, 300), 90 + it), _rand((5, 300), 95 + it)
+        a.zero_grad()
+        b.zero_grad()
+        with ops.FactoredGrads(True):
+            y = lin(x1).pow(2).sum() + lin(x2).sum()
+            y.backward()
+        assert lin.weight.grad is None and len(lin.weight._icl_factors) == 2 and lin.bias.grad is not None
+        yr = F.linear(x1, ref_w, ref_b).pow(2).sum() + F.linear(x2, ref_w, ref_b).sum()
+        yr.backward()
+        a.step()
+        b.step()
+        assert lin.weight._icl_factors is None
+        assert rel_err(lin.weight.detach(), ref_w.detach()) < 1e-5, it
+        assert rel_err(lin.bias.detach(), ref_b.detach()) < 1e-5
+    # switch off: dense gradient as usual
+    lin(x2).sum().backward()
+    assert lin.weight.grad is not None and lin.weight._icl_factors is None
+
+
 def test_layernorm_gelu():
     x = (_rand((3, 5, 37), 61) * 2 + 0.3).requires_grad_()
     w = (1 + 0.1 * _rand((37,), 62)).requires_grad_()
