@@ -21,6 +21,9 @@ __device__ __forceinline__ f32x16 icl_mfma_32x32x2(float a, float b, f32x16 c) {
 // v_exp_f32 based exp (2 instructions); the CPU emulation maps it to expf
 __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 
+// hide an integer from constant folding: keeps LDS offsets small enough for ds_read2_b32 pairing (8-bit dword offsets)
+#define ICL_OPAQUE_INT(x) asm volatile("" : "+v"(x))
+
 #define ICL_DYN_LDS(type, name)                                              \
   extern __shared__ __attribute__((aligned(16))) unsigned char icl_dyn_lds_raw[]; \
   type* name = reinterpret_cast<type*>(icl_dyn_lds_raw)

@@ -200,13 +200,20 @@ struct WgradTileT {
   static constexpr int GX = 16 * (MT / 4) / NT;  // dY float4 items per thread
 };
 
-template <class TC>
-__global__ __launch_bounds__(256) void conv3d_mfma_wgrad_static_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                       float* __restrict__ gwp, ConvGeom g) {
-  
-  constexpr int T = 27, NTW = 7, WAVES = 4, NT = 256;
+// WV waves per workgroup (4 or 8).  Waves 0-3 / 4-7 take the taps round-robin (tap = (wave & 3) + 4t); with 8 waves the two
+// groups split the x-rows of the tile between them and write separate slabs.  8 waves share one staged tile, so the
+// staging registers per thread halve and 16 waves per CU (4 per SIMD, <= 128 registers) hide the LDS latency that keeps a
+// 2-waves-per-SIMD launch at 63 % matrix-pipe utilisation (PMC, profiles/).
+template <class TC, int WV>
+__global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                              float* __restrict__ gwp, ConvGeom g) {
+  constexpr int T = 27, NTW = 7, TG = 4, NT = 64 * WV, HALVES = WV / 4;
   constexpr int PS = TC::PS, PXL = TC::PXL, PY = TC::PY, PZ = TC::PZ, MT = TC::MT, MTP = TC::MTP;
-  constexpr int NP = TC::NP, JX = TC::JX, CPP = TC::CPP, Q = TC::Q, GX = TC::GX;
+  constexpr int NP = TC::NP, CPP = TC::CPP, Q = TC::Q;
+  constexpr int JX = (CPP * TC::PER_CH + NT - 1) / NT;
+  constexpr int GX = (16 * (MT / 4) + NT - 1) / NT;
+  constexpr int ROWS = MT / 16, RPH = ROWS / HALVES;
+  static_assert(ROWS % HALVES == 0, "tile rows must split evenly over the wave groups");
   ICL_DYN_LDS(float, lds);
   float* Xs = lds;
   float* Gs = lds + 16 * PS;
@@ -217,6 +224,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_wgrad_static_kernel(const flo
   const float* xb = x + (long)blockIdx.z * g.x_bstride;
   const float* gb = gy + (long)blockIdx.z * g.y_bstride;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int tg = wid & 3, half = wid >> 2;
   const int lq = lane >> 4, lr = lane & 15;
   const int ntiles = g.ntz * g.nty * g.ntx;
 
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_wgrad_static_kernel(const flo
   for (int i = 0; i < GX; ++i) {
     const int it = threadIdx.x + i * NT;
     gvt[i] = (it % (MT / 4)) * 4;
-    gco[i] = it / (MT / 4);
+    gco[i] = it < 16 * (MT / 4) ? it / (MT / 4) : -1;
   }
   float4 xv[NP][JX];
   float4 gv[GX];
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_wgrad_static_kernel(const flo
       const int tx = vt % TC::TX, t2 = vt / TC::TX;
       const int gz = z0 + t2 / TC::TY, gyy = y0 + t2 % TC::TY, gx = x0 + tx;
       gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (co0 + gco[i] < g.Cout && gz < g.D && gyy < g.H && gx + 3 < g.W)
+      if (gco[i] >= 0 && co0 + gco[i] < g.Cout && gz < g.D && gyy < g.H && gx + 3 < g.W)
         gv[i] = *reinterpret_cast<const float4*>(gb + (long)(co0 + gco[i]) * DHW + gz * HW + (long)gyy * g.W + gx);
     }
   };
@@ -282,6 +290,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_wgrad_static_kernel(const flo
         }
 #pragma unroll
     for (int i = 0; i < GX; ++i) {
+      if (gco[i] < 0) continue;
       float* d = Gs + gco[i] * MTP + gvt[i];
       *reinterpret_cast<float2*>(d) = make_float2(gv[i].x, gv[i].y);
       *reinterpret_cast<float2*>(d + 2) = make_float2(gv[i].z, gv[i].w);
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_wgrad_static_kernel(const flo
   int bb[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
-    const int tap = wid + t * WAVES;
+    const int tap = tg + t * TG;
     const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
     bb[t] = lr * PS + lq + (TC::HX - 1) + (dz * PY + dy) * PXL + dx;
   }
@@ -307,16 +316,27 @@ __global__ __launch_bounds__(256) void conv3d_mfma_wgrad_static_kernel(const flo
     store_tile();
     __syncthreads();
     if (bt + (int)gridDim.x < ntiles) load_tile(bt + gridDim.x);
+    // one x-row of the tile (16 voxels = 4 k-steps) at a time: per operand ONE row base register and the four k-steps at
+    // dword offsets 0/4/8/12, which the compiler pairs into ds_read2_b32 (8-bit dword offsets) — half the LDS instructions
 #pragma unroll
-    for (int i = 0; i < MT / 4; ++i) {
-      const int row = i / 4, tx0 = (i % 4) * 4;
-      const int koff = ((row / TC::TY) * PY + (row % TC::TY)) * PXL + tx0;
-      const float a = Gs[ab + 4 * i];
+    for (int rr = 0; rr < RPH; ++rr) {
+      // rows of this wave group; (row / TY, row % TY) must be compile-time per unrolled step, so the half enters as an offset
+      int ai = ab + 16 * rr + half * (16 * RPH);
+      ICL_OPAQUE_INT(ai);
+      float a[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a[s] = Gs[ai + 4 * s];
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
-        if (t < NTW - 1 || wid + t * WAVES < T) {
-          const float b = Xs[bb[t] + koff];
-          acc[t] = icl_mfma_16x16x4(a, b, acc[t]);
+        if (t < NTW - 1 || tg + t * TG < T) {
+          // RPH is a multiple of TY for every tile used (4x4x16: 16 rows, TY 4; 8 rows per half = 2 z-planes)
+          int bi = bb[t] + ((rr / TC::TY) * PY + (rr % TC::TY)) * PXL + half * ((RPH / TC::TY) * PY * PXL);
+          ICL_OPAQUE_INT(bi);
+          float b[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[s] = Xs[bi + 4 * s];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[t] = icl_mfma_16x16x4(a[s], b[s], acc[t]);
         }
       }
     }
@@ -325,11 +345,11 @@ __global__ __launch_bounds__(256) void conv3d_mfma_wgrad_static_kernel(const flo
   if (ci < g.CinP) {
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-      const int tap = wid + t * WAVES;
+      const int tap = tg + t * TG;
       if (tap >= T) continue;
-      // every (split, batch) workgroup owns one slab of packed partial sums: plain 16-byte stores, no atomics;
+      // every (split, batch, wave group) owns one slab of packed partial sums: plain 16-byte stores, no atomics;
       // reduce_unpack_wgrad_kernel adds the slabs in a fixed order (bitwise reproducible gradients)
-      const long slab = (long)blockIdx.z * gridDim.x + blockIdx.x;
+      const long slab = ((long)blockIdx.z * gridDim.x + blockIdx.x) * HALVES + half;
       float* dst = gwp + slab * ((long)T * g.CinP * g.CoutP) + ((long)tap * g.CinP + ci) * g.CoutP + co0 + lq * 4;
       *reinterpret_cast<float4*>(dst) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
     }
