@@ -46,8 +46,12 @@ _SIGNATURES = {
     "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P, P]),
     "icl_loss_fwd": (c_int, [P, P, P, P, P, P, I, I, L, I, I, P]),
     "icl_window_attn_bias_elems": (c_int64, [I, I]),
+    "icl_im2col3": (c_int, [P, P, I, I, I, I, I, P]),
+    "icl_col2im3": (c_int, [P, P, I, I, I, I, I, P]),
     "icl_linear_wgrad_ws_bytes": (c_int64, [L, I, I]),
     "icl_linear_wgrad": (c_int, [P, P, P, P, P, L, I, I, P]),
+    "icl_conv1x1_wgrad_ws_bytes": (c_int64, [I, L, I, I]),
+    "icl_conv1x1_wgrad": (c_int, [P, P, P, P, P, I, I, I, L, L, L, P]),
     "icl_relpos_bias_fwd": (c_int, [P, P, P, I, I, I, P]),
     "icl_relpos_bias_bwd": (c_int, [P, P, P, L, I, I, I, P]),
     "icl_window_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, F, P]),

@@ -82,6 +82,84 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   }
 }
 
+// The same reduction for CHANNEL-MAJOR operands: the weight gradient of a 1x1x1 convolution on big volumes,
+//   dW[o][i] = sum_{b, v} gy[b][o][v] * x[b][i][v],  db[o] = sum gy   (x [N, I, S], gy [N, O, S], v contiguous)
+// (MONAI UnetResBlock.conv3 of SwinUNETR on 48^3 / 96^3 volumes, the 1x1 heads).  The MFMA k index is only a label, so lane
+// (lr, lg) takes the four voxels v0 + 4*lg + t (t = k-step): one 16-byte load per operand row and 4 k-steps, 64 contiguous
+// bytes per channel row and wave — no LDS, no transposes.  S % 4 == 0.  Same slab layout / reduce kernel as above.
+// grid (nsplit/4, ceil(O/48), ceil(I/48)), block 256; the (batch, voxel-group) range is split over nsplit waves.
+__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            float* __restrict__ slabs, int N, long S, int O, int I, int nsplit,
+                                                            long g_bstride, long x_bstride) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int split = blockIdx.x * 4 + wid;
+  const int o0 = blockIdx.y * kLwB, i0 = blockIdx.z * kLwB;
+  const long gps = S / 16;                                 // groups of 16 voxels per sample
+  const long groups = gps * N + ((S % 16) ? N : 0);        // a ragged tail group per sample when S % 16 != 0
+  const long gpsr = (S + 15) / 16;
+  const long per = (groups + nsplit - 1) / nsplit;
+  const long q0 = (long)split * per, q1 = (q0 + per < groups) ? q0 + per : groups;
+  (void)gps;
+  f32x4 acc[kLwT][kLwT];
+  float bsum[kLwT];
+#pragma unroll
+  for (int a = 0; a < kLwT; ++a) {
+    bsum[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < kLwT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bool ov[kLwT], iv[kLwT];
+#pragma unroll
+  for (int a = 0; a < kLwT; ++a) {
+    ov[a] = o0 + a * 16 + lr < O;
+    iv[a] = i0 + a * 16 + lr < I;
+  }
+  for (long q = q0; q < q1; ++q) {
+    const long b = q / gpsr, v = (q - b * gpsr) * 16 + lg * 4;
+    const bool rv = v < S;                                  // S % 4 == 0: a float4 is either fully inside or fully outside
+    float4 av[kLwT], bv[kLwT];
+#pragma unroll
+    for (int a = 0; a < kLwT; ++a) {
+      av[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rv && ov[a]) av[a] = *reinterpret_cast<const float4*>(g + b * g_bstride + (long)(o0 + a * 16 + lr) * S + v);
+      if (rv && iv[a]) bv[a] = *reinterpret_cast<const float4*>(x + b * x_bstride + (long)(i0 + a * 16 + lr) * S + v);
+    }
+#pragma unroll
+    for (int a = 0; a < kLwT; ++a) {
+      bsum[a] += (av[a].x + av[a].y) + (av[a].z + av[a].w);
+#pragma unroll
+      for (int c = 0; c < kLwT; ++c) {
+        acc[a][c] = icl_mfma_16x16x4(av[a].x, bv[c].x, acc[a][c]);
+        acc[a][c] = icl_mfma_16x16x4(av[a].y, bv[c].y, acc[a][c]);
+        acc[a][c] = icl_mfma_16x16x4(av[a].z, bv[c].z, acc[a][c]);
+        acc[a][c] = icl_mfma_16x16x4(av[a].w, bv[c].w, acc[a][c]);
+      }
+    }
+  }
+  float* slab = slabs + (long)split * ((long)O * I + O);
+#pragma unroll
+  for (int a = 0; a < kLwT; ++a)
+#pragma unroll
+    for (int c = 0; c < kLwT; ++c) {
+      const int i = i0 + c * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = o0 + a * 16 + lg * 4 + r;
+        if (o < O && i < I) slab[(long)o * I + i] = acc[a][c][r];
+      }
+    }
+  if (blockIdx.z == 0) {
+#pragma unroll
+    for (int a = 0; a < kLwT; ++a) {
+      float v = bsum[a];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lg == 0 && ov[a]) slab[(long)O * I + o0 + a * 16 + lr] = v;
+    }
+  }
+}
+
 // out[e] = sum_s slabs[s][e] for e < E (E = O*I + O; dW and db are contiguous in `out`).  grid ceil(E/64), block 256.
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                                   float* __restrict__ db, long E, long EW, int nsplit) {

@@ -82,6 +82,46 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restr
   }
 }
 
+// ---- im2col / col2im for 3^3 convolutions on TINY volumes (<= 6^3: the 384/768-channel bottleneck blocks of SwinUNETR and the
+// 256-channel centre of the U-Net).  There the convolution is a skinny GEMM that streams up to 64 MB of weights for 27..432
+// output voxels, so it runs as  colsT [N*S, Cin*27] x W[Cout, Cin*27]^T  on the library GEMM; these two kernels only move
+// the (small) activations.  colsT[b*S + v][ci*27 + tap] = x[b][ci][v + offset(tap)] (zero outside the volume).
+__global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ x, float* __restrict__ cols, int N, int C, int D, int H,
+                                                      int W) {
+  const long S = (long)D * H * W, K = (long)C * 27, total = (long)N * S * K;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % K);
+    const long r = e / K;
+    const int tap = k % 27, ci = k / 27;
+    const long v = r % S;
+    const int b = (int)(r / S);
+    const int ox = (int)(v % W), oy = (int)((v / W) % H), oz = (int)(v / ((long)W * H));
+    const int z = oz + tap / 9 - 1, yy = oy + (tap / 3) % 3 - 1, xx = ox + tap % 3 - 1;
+    float val = 0.f;
+    if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W) val = x[((long)b * C + ci) * S + ((long)z * H + yy) * W + xx];
+    cols[e] = val;
+  }
+}
+
+// dx[b][ci][u] = sum_tap g[b*S + (u - offset(tap))][ci*27 + tap]   (exact transpose of im2col3)
+__global__ __launch_bounds__(256) void col2im3_kernel(const float* __restrict__ g, float* __restrict__ dx, int N, int C, int D, int H, int W) {
+  const long S = (long)D * H * W, K = (long)C * 27, total = (long)N * C * S;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long u = e % S;
+    const int ci = (int)((e / S) % C);
+    const int b = (int)(e / (S * C));
+    const int ux = (int)(u % W), uy = (int)((u / W) % H), uz = (int)(u / ((long)W * H));
+    float acc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int z = uz - (tap / 9 - 1), yy = uy - ((tap / 3) % 3 - 1), xx = ux - (tap % 3 - 1);
+      if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
+        acc += g[((long)b * S + ((long)z * H + yy) * W + xx) * K + (long)ci * 27 + tap];
+    }
+    dx[e] = acc;
+  }
+}
+
 __device__ __forceinline__ unsigned mix32(unsigned x) {
   x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
   return x;

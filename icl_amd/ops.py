@@ -131,6 +131,9 @@ def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_b
                                     x_bstride, y_bstride, _stream(x)), "conv3d_fwd")
 
 
+CONV1X1_WGRAD_MIN_VOXELS = 4096
+
+
 class _Conv3d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, zero_bias_grad=False):
@@ -171,19 +174,64 @@ class _Conv3d(torch.autograd.Function):
                 # (the reference holds ~1e-8 rounding noise there); skip the reduction pass over dY.
                 gb.zero_()
                 gb_arg = None
-            ws = _ws(L.icl_conv3d_wgrad_ws_bytes(n, cin, cout, ks), x)
             flops = 2.0 * ks ** 3 * cin * cout * s * n
             nbytes = 4.0 * (n * s * (cin + cout) + 2 * ks ** 3 * cin * cout)
-            with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):
-                _lib.check(L.icl_conv3d_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin, cout, d, h, w, ks,
-                                              cin * s, cout * s, _stream(x)), "conv3d_wgrad")
+            if ks == 1 and s % 4 == 0 and n * s >= CONV1X1_WGRAD_MIN_VOXELS:
+                # big-volume 1x1x1 convolution: HBM-bound channel-major reduction, rows split over many waves
+                ws = _ws(L.icl_conv1x1_wgrad_ws_bytes(n, s, cin, cout), x)
+                with _timed("conv1x1_wgrad_kernel", flops, nbytes, x):
+                    _lib.check(L.icl_conv1x1_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin, cout, s, cin * s,
+                                                   cout * s, _stream(x)), "conv1x1_wgrad")
+            else:
+                ws = _ws(L.icl_conv3d_wgrad_ws_bytes(n, cin, cout, ks), x)
+                with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):
+                    _lib.check(L.icl_conv3d_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin, cout, d, h, w, ks,
+                                                  cin * s, cout * s, _stream(x)), "conv3d_wgrad")
         return gx, gw, gb, None
+
+
+class _Im2Col3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require(x)
+        L = _lib.lib()
+        x = x.contiguous()
+        n, c, d, h, w = x.shape
+        cols = torch.empty((n * d * h * w, c * 27), dtype=torch.float32, device=x.device)
+        _lib.check(L.icl_im2col3(_ptr(x), _ptr(cols), n, c, d, h, w, _stream(x)), "im2col3")
+        ctx.shape = (n, c, d, h, w)
+        return cols
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        n, c, d, h, w = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty((n, c, d, h, w), dtype=torch.float32, device=g.device)
+        _lib.check(L.icl_col2im3(_ptr(g), _ptr(dx), n, c, d, h, w, _stream(g)), "col2im3")
+        return dx
+
+
+SMALL_CONV_MAX_VOXELS = 216      # 6^3
+SMALL_CONV_MIN_WEIGHTS = 128 * 128 * 27
+
+
+def _conv3d_tiny_volume(x, weight, bias):
+    """3^3 convolution on <= 6^3 voxels with >= 128x128 channels: a skinny GEMM that streams the weights once
+    (csrc/kernels/misc.h im2col3 / col2im3 + the library GEMM; dW through the tall/skinny paths of ``linear``)."""
+    n, cin, d, h, w = x.shape
+    cout = weight.shape[0]
+    y = linear(_Im2Col3.apply(x), weight.flatten(1), bias)            # [n*S, cout]
+    return y.view(n, d * h * w, cout).permute(0, 2, 1).reshape(n, cout, d, h, w)
 
 
 def conv3d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            zero_bias_grad: bool = False) -> torch.Tensor:
     """Conv3d, kernel 3 (pad 1) or 1 (pad 0), stride 1.  ``zero_bias_grad``: the caller guarantees the output goes
     straight into a mean-removing normalisation, so the bias gradient is identically zero."""
+    if (weight.shape[2] == 3 and x.shape[2] * x.shape[3] * x.shape[4] <= SMALL_CONV_MAX_VOXELS
+            and weight.numel() >= SMALL_CONV_MIN_WEIGHTS):
+        return _conv3d_tiny_volume(x, weight, bias)
     return _Conv3d.apply(x, weight, bias, zero_bias_grad)
 
 

@@ -125,12 +125,25 @@ int icl_attn_fwd(const float* q, const float* kv, float* logits, float* out, flo
 int icl_attn_bwd(const float* q, const float* kv, const float* logits, const float* stats, const float* out, const float* gout,
                  const float* glog, float* gq, float* gkv, int b, int h, int nc, int n, int d, float scale, void* stream);
 
+/* ---- 3^3 convolutions on tiny volumes (<= 6^3 voxels, hundreds of channels: `encoder10`/`decoder5` of SwinUNETR,
+ * networks/swinunetr_icl.py:163-183, and the U-Net `center`, networks/unet_3D_icl.py:54) are skinny GEMMs over the weights:
+ * cols [n*S, c*27] with cols[b*S+v][ci*27+tap] = x[b][ci][v+offset(tap)] (zero padded), y = cols * W[cout, c*27]^T on the
+ * library GEMM.  col2im3 is the exact transpose (input gradient from d(cols)). */
+int icl_im2col3(const float* x, float* cols, int n, int c, int d, int h, int w, void* stream);
+int icl_col2im3(const float* g, float* dx, int n, int c, int d, int h, int w, void* stream);
+
 /* ---- nn.Linear weight/bias gradient for tall token matrices (qkv / proj / MLPBlock linears of the Swin stages,
  * networks/swinunetr_icl.py:703,705,812; PatchEmbed; the k2s2 transposed convolutions written as GEMMs):
  * dw[o][i] = sum_r gy[r][o] * x[r][i], db[o] = sum_r gy[r][o] (db may be NULL); gy [rows, o], x [rows, i] row-major.
  * Rows are split over many waves (fp32 MFMA), partial blocks go to ws (icl_linear_wgrad_ws_bytes) and are summed in a fixed order. */
 int64_t icl_linear_wgrad_ws_bytes(int64_t rows, int o, int i);
 int icl_linear_wgrad(const float* gy, const float* x, float* dw, float* db, void* ws, int64_t rows, int o, int i, void* stream);
+
+/* Weight/bias gradient of a 1x1x1 convolution on a big volume (channel-major operands, s = D*H*W voxels per sample, s % 4 == 0):
+ * gw[cout][cin] = sum_{b,v} gy[b][co][v] * x[b][ci][v]; gbias may be NULL.  Same row-split / slab scheme as icl_linear_wgrad. */
+int64_t icl_conv1x1_wgrad_ws_bytes(int n, int64_t s, int cin, int cout);
+int icl_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* gbias, void* ws, int n, int cin, int cout, int64_t s,
+                      int64_t x_bstride, int64_t gy_bstride, void* stream);
 
 /* ---- Swin window attention: WindowAttention.forward core, networks/swinunetr_icl.py:728-747 —
  *   attn = softmax((q*scale) @ k^T + relative_position_bias [+ shift mask]);  out = attn @ v   per (window, head), head dim 16.

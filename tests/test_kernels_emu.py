@@ -342,3 +342,18 @@ def test_2d_ops_through_3d_kernels():
     orf = F.conv2d(dr, dwr, None, padding=1, groups=4)
     orf.backward(go)
     assert rel_err(o.detach(), orf.detach()) < 1e-5 and rel_err(d.grad, dr.grad) < 1e-5 and rel_err(dw.grad, dwr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("n,cin,cout,d,h,w", [(2, 128, 128, 3, 3, 3), (1, 130, 128, 2, 3, 4)])
+def test_conv3d_tiny_volume_gemm_path(n, cin, cout, d, h, w):
+    """<= 6^3 voxels with >= 128x128 channels: im2col3 / col2im3 + library GEMM instead of the tile kernels."""
+    assert cin * cout * 27 >= ops.SMALL_CONV_MIN_WEIGHTS
+    _conv_check(n, cin, cout, d, h, w, 3)
+
+
+@pytest.mark.parametrize("n,cin,cout,d,h,w", [(2, 20, 50, 10, 12, 20), (1, 96, 48, 4, 32, 36), (3, 1, 48, 6, 14, 18)])
+def test_conv1x1_wgrad_big_volume_path(n, cin, cout, d, h, w):
+    """1x1x1 convolution with >= 4096 voxels: channel-major row-split MFMA reduction (conv1x1_wgrad_kernel): ragged
+    channel blocks, a ragged 16-voxel tail group (S % 16 != 0), several batch items."""
+    assert n * d * h * w >= ops.CONV1X1_WGRAD_MIN_VOXELS and (d * h * w) % 4 == 0
+    _conv_check(n, cin, cout, d, h, w, 1)
