@@ -46,6 +46,8 @@ _SIGNATURES = {
     "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P, P]),
     "icl_loss_fwd": (c_int, [P, P, P, P, P, P, I, I, L, I, I, P]),
     "icl_window_attn_bias_elems": (c_int64, [I, I]),
+    "icl_depth_to_space2": (c_int, [P, P, I, I, I, I, I, L, P]),
+    "icl_space_to_depth2": (c_int, [P, P, I, I, I, I, I, L, P]),
     "icl_im2col3": (c_int, [P, P, I, I, I, I, I, P]),
     "icl_col2im3": (c_int, [P, P, I, I, I, I, I, P]),
     "icl_linear_wgrad_ws_bytes": (c_int64, [L, I, I]),

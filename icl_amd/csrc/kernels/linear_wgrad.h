@@ -160,19 +160,24 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restr
   }
 }
 
-// out[e] = sum_s slabs[s][e] for e < E (E = O*I + O; dW and db are contiguous in `out`).  grid ceil(E/64), block 256.
+// out[e] = sum_s slabs[s][e] for e < E (E = O*I + O; dW then db).  Block 256 = 16 consecutive elements x 16 slab lanes:
+// every slab row is read as a 64-byte segment, each thread adds nsplit/16 values, the 16 partial sums are combined through
+// LDS in lane order (fixed summation order -> reproducible).  grid ceil(E/16).
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                                   float* __restrict__ db, long E, long EW, int nsplit) {
-  __shared__ float red[4][64];
-  const int le = threadIdx.x & 63, ls = threadIdx.x >> 6;
-  const long e = (long)blockIdx.x * 64 + le;
+  __shared__ float red[16][17];
+  const int le = threadIdx.x & 15, ls = threadIdx.x >> 4;
+  const long e = (long)blockIdx.x * 16 + le;
   float v = 0.f;
-  if (e < E)
-    for (int s = ls; s < nsplit; s += 4) v += slabs[(long)s * E + e];
+  if (e < E) {
+#pragma unroll 4
+    for (int s = ls; s < nsplit; s += 16) v += slabs[(long)s * E + e];
+  }
   red[ls][le] = v;
   __syncthreads();
   if (ls != 0 || e >= E) return;
-  v = (red[0][le] + red[1][le]) + (red[2][le] + red[3][le]);
+#pragma unroll
+  for (int k = 1; k < 16; ++k) v += red[k][le];
   if (e < EW) dw[e] = v;
   else if (db) db[e - EW] = v;
 }

@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __res
   const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float a = 0.f, b = 0.f;
   if (valid) {
+    // 8 rows in flight per thread: the loop is a pure stream of independent loads (one row every ~1 us otherwise)
+#pragma unroll 8
     for (long r = r0 + rl; r < r1; r += lanes) {
       const float g = gy[r * C + c];
       a += g * (x[r * C + c] - mean[r]) * rstd[r];

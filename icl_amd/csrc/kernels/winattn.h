@@ -87,16 +87,30 @@ __global__ __launch_bounds__(256) void relpos_bias_gather_kernel(const float* __
   }
 }
 
-// dtable[index[i, j]][h] += dbias[h][i][j]   (dtable zeroed by the launcher; <= 343 adders per address)
+// dtable[index[i, j]][h] += dbias[h][i][j].  Up to 343 (i, j) pairs share one table row, so a workgroup first accumulates
+// its slice of one head into an LDS copy of that head's column (ds_add_f32), then adds the non-empty rows to HBM: 32 adders per
+// address instead of 343.  grid (chunks, heads), block 256, LDS = table_rows floats.  dtable zeroed by the launcher.
 __global__ __launch_bounds__(256) void relpos_bias_scatter_kernel(const float* __restrict__ dbias, const long* __restrict__ index,
-                                                                  float* __restrict__ dtable, int n, int npad, int heads, int idx_stride) {
-  const long total = (long)heads * n * npad;
-  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+                                                                  float* __restrict__ dtable, int n, int npad, int heads, int idx_stride,
+                                                                  int table_rows) {
+  ICL_DYN_LDS(float, tab);
+  const int h = blockIdx.y;
+  for (int t = threadIdx.x; t < table_rows; t += blockDim.x) tab[t] = 0.f;
+  __syncthreads();
+  const long total = (long)n * npad;
+  const long per = (total + gridDim.x - 1) / gridDim.x;
+  const long lo = (long)blockIdx.x * per, hi = lo + per < total ? lo + per : total;
+  const float* src = dbias + (long)h * total;
+  for (long it = lo + threadIdx.x; it < hi; it += blockDim.x) {
     const int j = (int)(it % npad);
     if (j >= n) continue;
-    const int i = (int)((it / npad) % n);
-    const int h = (int)(it / ((long)npad * n));
-    atomicAdd(dtable + index[(long)i * idx_stride + j] * heads + h, dbias[it]);
+    const int i = (int)(it / npad);
+    atomicAdd(tab + index[(long)i * idx_stride + j], src[it]);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < table_rows; t += blockDim.x) {
+    const float v = tab[t];
+    if (v != 0.f) atomicAdd(dtable + (long)t * heads + h, v);
   }
 }
 

@@ -265,8 +265,8 @@ class _TransposedConvOnly(nn.Module):
         with torch.no_grad():
             self.conv.weight.uniform_(-bound, bound)
 
-    def forward(self, x):
-        return ops.conv_transpose3d_k2s2(x, self.conv.weight)
+    def forward(self, x, skip=None):
+        return ops.conv_transpose3d_k2s2(x, self.conv.weight, skip)
 
 
 class UnetResBlock(nn.Module):
@@ -306,7 +306,7 @@ class UnetrUpBlock(nn.Module):
         self.conv_block = UnetResBlock(2 * cout, cout, device)
 
     def forward(self, x, skip):
-        return self.conv_block(torch.cat((self.transp_conv(x), skip), 1))
+        return self.conv_block(self.transp_conv(x, skip))      # [up | skip] built in one buffer
 
 
 class UnetOutBlock(nn.Module):

@@ -782,15 +782,54 @@ def gelu(x: torch.Tensor) -> torch.Tensor:
 # SwinUNETR pieces (networks/swinunetr_icl.py)
 # --------------------------------------------------------------------------------------
 
-def conv_transpose3d_k2s2(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-    """nn.ConvTranspose3d(cin, cout, kernel 2, stride 2, no bias) — MONAI UnetrUpBlock.transp_conv.  Kernel == stride, so
-    the output voxels do not overlap: out[b, co, 2z+i, 2y+j, 2x+k] = sum_ci x[b, ci, z, y, x] * W[ci, co, i, j, k], i.e. ONE
-    plain GEMM  [B*S, Cin] x [Cin, Cout*8]  (library GEMM, rocBLAS) followed by a depth-to-space shuffle."""
+class _DepthToSpaceCat(torch.autograd.Function):
+    """[depth_to_space(yt) | skip] along channels in one buffer: the GEMM result of the k2s2 transposed convolution is moved
+    straight into the channel slice of the concat buffer MONAI's UnetrUpBlock builds (``torch.cat((out, skip), 1)``)."""
+
+    @staticmethod
+    def forward(ctx, yt, skip, dims):
+        _require(yt, skip)
+        L = _lib.lib()
+        n, d, h, w, cout = dims
+        yt = yt.contiguous()
+        so = 8 * d * h * w
+        cs = 0 if skip is None else skip.shape[1]
+        out = torch.empty((n, cout + cs, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=yt.device)
+        _lib.check(L.icl_depth_to_space2(_ptr(yt), _ptr(out), n, d, h, w, cout, (cout + cs) * so, _stream(yt)), "depth_to_space2")
+        if cs:
+            skip = skip.contiguous()
+            _lib.check(L.icl_copy_rows(_ptr(skip), _vp(out[:, cout:].data_ptr()), n, cs * so, cs * so, (cout + cs) * so, _stream(yt)),
+                       "copy_rows")
+        ctx.dims = (n, d, h, w, cout, cs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        n, d, h, w, cout, cs = ctx.dims
+        g = g.contiguous()
+        so = 8 * d * h * w
+        gt = gskip = None
+        if ctx.needs_input_grad[0]:
+            gt = torch.empty((n, d * h * w, cout * 8), dtype=torch.float32, device=g.device)
+            _lib.check(L.icl_space_to_depth2(_ptr(g), _ptr(gt), n, d, h, w, cout, (cout + cs) * so, _stream(g)), "space_to_depth2")
+        if cs and ctx.needs_input_grad[1]:
+            gskip = torch.empty((n, cs, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=g.device)
+            _lib.check(L.icl_copy_rows(_vp(g[:, cout:].data_ptr()), _ptr(gskip), n, cs * so, (cout + cs) * so, cs * so, _stream(g)),
+                       "copy_rows")
+        return gt, gskip, None
+
+
+def conv_transpose3d_k2s2(x: torch.Tensor, weight: torch.Tensor, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.ConvTranspose3d(cin, cout, kernel 2, stride 2, no bias) — MONAI UnetrUpBlock.transp_conv — optionally followed by
+    ``torch.cat((up, skip), 1)``.  Kernel == stride, so the output voxels do not overlap:
+    out[b, co, 2z+i, 2y+j, 2x+k] = sum_ci x[b, ci, z, y, x] * W[ci, co, i, j, k], i.e. ONE plain GEMM
+    [B*S, Cin] x [Cin, Cout*8] (library GEMM, rocBLAS) followed by a depth-to-space move (csrc/kernels/pool_resize.h) that
+    writes straight into the concat buffer."""
     b, cin, d, h, w = x.shape
     cout = weight.shape[1]
     y = _MatmulTall.apply(x.flatten(2).transpose(1, 2), weight.flatten(1))          # [B, S, Cout*8]
-    y = y.view(b, d, h, w, cout, 2, 2, 2).permute(0, 4, 1, 5, 2, 6, 3, 7)
-    return y.reshape(b, cout, 2 * d, 2 * h, 2 * w)
+    return _DepthToSpaceCat.apply(y, skip, (b, d, h, w, cout))
 
 
 class _WindowAttention(torch.autograd.Function):

@@ -132,6 +132,13 @@ int icl_attn_bwd(const float* q, const float* kv, const float* logits, const flo
 int icl_im2col3(const float* x, float* cols, int n, int c, int d, int h, int w, void* stream);
 int icl_col2im3(const float* g, float* dx, int n, int c, int d, int h, int w, void* stream);
 
+/* ---- ConvTranspose3d(kernel 2, stride 2, no bias) = GEMM + depth-to-space (MONAI UnetrUpBlock.transp_conv in SwinUNETR,
+ * networks/swinunetr_icl.py:186-230): yt [n, d*h*w, cout*8] (column co*8 + i*4 + j*2 + k) -> out[b][co][2z+i][2y+j][2x+k];
+ * out_bstride lets the result land in the channel slice of the concat buffer that UnetrUpBlock builds next.
+ * icl_space_to_depth2 is the inverse (gradient back to the GEMM layout). */
+int icl_depth_to_space2(const float* yt, float* out, int n, int d, int h, int w, int cout, int64_t out_bstride, void* stream);
+int icl_space_to_depth2(const float* g, float* gt, int n, int d, int h, int w, int cout, int64_t g_bstride, void* stream);
+
 /* ---- nn.Linear weight/bias gradient for tall token matrices (qkv / proj / MLPBlock linears of the Swin stages,
  * networks/swinunetr_icl.py:703,705,812; PatchEmbed; the k2s2 transposed convolutions written as GEMMs):
  * dw[o][i] = sum_r gy[r][o] * x[r][i], db[o] = sum_r gy[r][o] (db may be NULL); gy [rows, o], x [rows, i] row-major.

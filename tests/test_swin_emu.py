@@ -103,6 +103,18 @@ def test_conv_transpose_k2s2():
     yr.backward(gy)
     assert rel_err(y.detach(), yr.detach()) < 1e-5
     assert rel_err(x.grad, xr.grad) < 1e-5 and rel_err(w.grad, wr.grad) < 1e-5
+    # fused with the concat of UnetrUpBlock: [up | skip]
+    skip = _rand((2, 3, 26, 20, 16), 34, True)
+    x2, w2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    gy2 = _rand((2, 10, 26, 20, 16), 35)
+    z = ops.conv_transpose3d_k2s2(x2, w2, skip)
+    z.backward(gy2)
+    sr = skip.detach().clone().requires_grad_()
+    xr2, wr2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    zr = torch.cat((F.conv_transpose3d(xr2, wr2, stride=2), sr), 1)
+    zr.backward(gy2)
+    assert rel_err(z.detach(), zr.detach()) < 1e-5 and torch.equal(skip.grad, sr.grad)
+    assert rel_err(x2.grad, xr2.grad) < 1e-5 and rel_err(w2.grad, wr2.grad) < 1e-5
 
 
 @pytest.mark.parametrize("dims,shifted", [((14, 14, 14), True), ((7, 14, 7), False), ((4, 4, 4), False)])
