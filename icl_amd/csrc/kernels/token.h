@@ -76,8 +76,24 @@ __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __res
   float a = 0.f, b = 0.f;
   if (valid) {
     // 8 rows in flight per thread: the loop is a pure stream of independent loads (one row every ~1 us otherwise)
-#pragma unroll 8
-    for (long r = r0 + rl; r < r1; r += lanes) {
+    long r = r0 + rl;
+    for (; r + 7L * lanes < r1; r += 8L * lanes) {
+      float gv[8], xv[8], mu[8], rs[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long rr = r + (long)u * lanes;
+        gv[u] = gy[rr * C + c];
+        xv[u] = x[rr * C + c];
+        mu[u] = mean[rr];
+        rs[u] = rstd[rr];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a += gv[u] * (xv[u] - mu[u]) * rs[u];
+        b += gv[u];
+      }
+    }
+    for (; r < r1; r += lanes) {
       const float g = gy[r * C + c];
       a += g * (x[r * C + c] - mean[r]) * rstd[r];
       b += g;

@@ -357,3 +357,14 @@ def test_conv1x1_wgrad_big_volume_path(n, cin, cout, d, h, w):
     channel blocks, a ragged 16-voxel tail group (S % 16 != 0), several batch items."""
     assert n * d * h * w >= ops.CONV1X1_WGRAD_MIN_VOXELS and (d * h * w) % 4 == 0
     _conv_check(n, cin, cout, d, h, w, 1)
+
+
+def test_conv1x1_big_volume_runs_as_batched_gemm(monkeypatch):
+    """>= 65536 voxels: forward / input gradient of a 1x1x1 convolution are one batched library GEMM (with and without bias)."""
+    monkeypatch.setattr(ops, "CONV1X1_GEMM_MIN_VOXELS", 4096)
+    _conv_check(2, 20, 50, 10, 12, 20, 1)
+    x = _rand((1, 6, 16, 16, 16), 5, True)
+    w = (_rand((3, 6, 1, 1, 1), 6) * 0.3).requires_grad_()
+    y = ops.conv3d(x, w, None)
+    y.sum().backward()
+    assert rel_err(y.detach(), F.conv3d(x.detach(), w.detach())) < 1e-5 and x.grad is not None and w.grad is not None
