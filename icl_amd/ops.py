@@ -153,7 +153,9 @@ class _Conv3d(torch.autograd.Function):
             # 1x1x1 convolution on a big volume = one HBM-bound batched GEMM  W [Cout,Cin] x x[b] [Cin,S]  (plain library GEMM:
             # 3.2-3.8 TB/s against 1.9-2.4 for the halo-tile kernel, tools/conv1x1_probe.py)
             w2, x3 = weight.view(cout, cin), x.view(n, cin, s)
-            y = torch.matmul(w2, x3) if bias is None else torch.baddbmm(bias.view(1, cout, 1), w2.expand(n, cout, cin), x3)
+            # bmm with a stride-0 batch of W: torch.matmul(2-D, 3-D) would fold the batch by transposing (copying) the volume
+            wb = w2.unsqueeze(0).expand(n, cout, cin)
+            y = torch.bmm(wb, x3) if bias is None else torch.baddbmm(bias.view(1, cout, 1), wb, x3)
             return y.view(n, cout, d, h, w)
         y = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
         wp = pack_weights(weight, 0)
@@ -171,7 +173,7 @@ class _Conv3d(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if ctx.pointwise_gemm:
-                gx = torch.matmul(weight.view(cout, cin).t(), gy.view(n, cout, s)).view(n, cin, d, h, w)
+                gx = torch.bmm(weight.view(cout, cin).t().unsqueeze(0).expand(n, cin, cout), gy.view(n, cout, s)).view(n, cin, d, h, w)
             else:
                 gx = torch.empty_like(x)
                 wpt = pack_weights(weight, 1)
