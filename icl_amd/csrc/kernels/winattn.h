@@ -19,11 +19,12 @@
 // kernel reads the region id of every token ([nW, n] int32) and adds -100 where the ids of query and key differ.
 // Bias: [heads, n, npad] with npad = n rounded up to 16 and the pad columns = -1e30 (masks the padded keys for free).
 //
-// Backward: (a) window_attn_bwd_qkv — same ownership, Q K V dO in LDS, scores recomputed from the saved log-sum-exp;
-// pass 1 (waves own query blocks, S^T layout) gives dQ, pass 2 (waves own key blocks, S layout) gives dK and dV, so no
-// gradient needs atomics;  (b) window_attn_bwd_bias — d(bias)[h, i, j] sums dS over all windows of the batch: waves own a
-// (head, query block), walk over a slice of the windows keeping their 16 x n slab of the sum in registers, and add it to
-// HBM once at the end.
+// Backward recomputes the scores from the saved log-sum-exp in two kernels of 58-60 KB LDS each (two workgroups per CU):
+// (a) window_attn_bwd_kv — one workgroup per (window, head), scale*Q and dO of the window in LDS, waves own key blocks
+//     (S layout) -> dK, dV, no atomics;
+// (b) window_attn_bwd_q_bias — waves own a (head, query block) and walk over a slice of the windows (K, V staged per
+//     window, S^T layout): dQ of every window is written directly, and d(bias)[h, i, j] — the sum of dS over ALL windows of
+//     the batch — stays in a register-resident 16 x n slab that is added to HBM once at the end.
 #pragma once
 
 namespace icl {
@@ -183,17 +184,17 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_fwd_kernel(const float
   }
 }
 
-// grid = B_ * heads; LDS = (4 * npad * 20 + 3 * npad) * 4 bytes.  dqkv has the layout of qkv.
-__global__ __launch_bounds__(kWaThreads) void window_attn_bwd_qkv_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
-                                                                  const int* __restrict__ regions, const float* __restrict__ out,
-                                                                  const float* __restrict__ lse, const float* __restrict__ dout,
-                                                                  float* __restrict__ dqkv, WinAttnGeom g) {
+// dK and dV.  grid = B_ * heads; LDS = (2 * npad * 20 + 3 * npad) * 4 bytes (scale*Q, dO, log-sum-exp, delta, region ids of every
+// query of the window); waves own key blocks, their K / V rows come straight from HBM as MFMA operands.
+// S layout: lane -> query 4*lg + r of the block, key lr.  dqkv has the layout of qkv; only the k and v thirds are written here.
+__global__ __launch_bounds__(kWaThreads) void window_attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                                 const int* __restrict__ regions, const float* __restrict__ out,
+                                                                 const float* __restrict__ lse, const float* __restrict__ dout,
+                                                                 float* __restrict__ dqkv, WinAttnGeom g) {
   ICL_DYN_LDS(float, lds);
   const int np = g.npad;
   float* Qs = lds;                 // scale * Q
-  float* Ks = Qs + np * kWaLd;
-  float* Vs = Ks + np * kWaLd;
-  float* Gs = Vs + np * kWaLd;     // dO
+  float* Gs = Qs + np * kWaLd;     // dO
   float* Ls = Gs + np * kWaLd;     // log-sum-exp per query (+1e30 on pad rows -> p = 0)
   float* Ds = Ls + np;             // delta[q] = sum_dim dO * O
   int* rid = reinterpret_cast<int*>(Ds + np);
@@ -204,8 +205,6 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_qkv_kernel(const f
   const float* dob = dout + (long)b_ * g.n * C + h * 16;
   const float* ob = out + (long)b_ * g.n * C + h * 16;
   wa_stage_rows(Qs, base, rs, g.n, np, g.scale);
-  wa_stage_rows(Ks, base + C, rs, g.n, np, 1.f);
-  wa_stage_rows(Vs, base + 2 * C, rs, g.n, np, 1.f);
   wa_stage_rows(Gs, dob, C, g.n, np, 1.f);
   const bool masked = regions != nullptr;
   for (int i = threadIdx.x; i < np; i += blockDim.x) {
@@ -225,45 +224,12 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_qkv_kernel(const f
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
-
-  // ---- pass 1: waves own query blocks (S^T layout) -> dQ
-  for (int qb = wid; qb < nkb; qb += kWaWaves) {
-    const int query = qb * 16 + lr, qc = query < g.n ? query : g.n - 1;
-    const float4 q4 = *reinterpret_cast<const float4*>(Qs + query * kWaLd + lg * 4);
-    const float4 g4 = *reinterpret_cast<const float4*>(Gs + query * kWaLd + lg * 4);
-    const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
-    const float lq = Ls[query], dq_ = Ds[query];
-    const int rq = rid[qc];
-    const float* brow = bias + ((long)h * g.n + qc) * np;
-    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int kb = 0; kb < nkb; ++kb) {
-      const f32x4 s = wa_scores_t(Ks, kb, lr, lg, qv, brow, rid, rq, masked);
-      f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-      const float4 v4 = *reinterpret_cast<const float4*>(Vs + (kb * 16 + lr) * kWaLd + lg * 4);
-      dp = icl_mfma_16x16x4(v4.x, g4.x, dp);
-      dp = icl_mfma_16x16x4(v4.y, g4.y, dp);
-      dp = icl_mfma_16x16x4(v4.z, g4.z, dp);
-      dp = icl_mfma_16x16x4(v4.w, g4.w, dp);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ds = wa_exp(s[r] - lq) * (dp[r] - dq_);
-        dq = icl_mfma_16x16x4(ds, Ks[(kb * 16 + lg * 4 + r) * kWaLd + lr], dq);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = qb * 16 + lg * 4 + r;
-      if (q < g.n) dqkv[((long)b_ * g.n + q) * rs + h * 16 + lr] = dq[r] * g.scale;
-    }
-  }
-
-  // ---- pass 2: waves own key blocks (S layout: lane -> query 4*lg + r of the block, key lr) -> dK, dV
   for (int kb = wid; kb < nkb; kb += kWaWaves) {
-    const int key = kb * 16 + lr;
-    const float4 k4 = *reinterpret_cast<const float4*>(Ks + key * kWaLd + lg * 4);
-    const float4 v4 = *reinterpret_cast<const float4*>(Vs + key * kWaLd + lg * 4);
-    const int rk = rid[key];
+    const int key = kb * 16 + lr, kc = key < g.n ? key : g.n - 1;
+    float4 k4 = *reinterpret_cast<const float4*>(base + C + (long)kc * rs + lg * 4);
+    float4 v4 = *reinterpret_cast<const float4*>(base + 2 * C + (long)kc * rs + lg * 4);
+    if (key >= g.n) { k4 = make_float4(0.f, 0.f, 0.f, 0.f); v4 = k4; }
+    const int rk = rid[kc];
     f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
     for (int qb = 0; qb < nkb; ++qb) {
@@ -301,12 +267,15 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_qkv_kernel(const f
   }
 }
 
-// grid (ceil(nkb/kWaWaves), heads, chunks); LDS = (2 * npad * 20 + npad) * 4 bytes.  dbias [heads, n, npad] must be zeroed.
+// dQ and d(bias).  Waves own a (head, query block) and walk over a slice of the windows: for every window K and V are staged
+// in LDS, dS is recomputed (S^T layout), dQ of the 16 queries is written, and dS is added to a register-resident 16 x n slab
+// of d(bias), which is summed over all windows of the batch and added to HBM once at the end.
+// grid (ceil(nkb/kWaWaves), heads, chunks); LDS = (2 * npad * 20 + npad) * 4 bytes.  dbias [heads, n, npad] zeroed (may be NULL).
 template <int NKB>
-__global__ __launch_bounds__(kWaThreads) void window_attn_bwd_bias_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
-                                                                   const int* __restrict__ regions, const float* __restrict__ out,
-                                                                   const float* __restrict__ lse, const float* __restrict__ dout,
-                                                                   float* __restrict__ dbias, WinAttnGeom g) {
+__global__ __launch_bounds__(kWaThreads) void window_attn_bwd_q_bias_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                                     const int* __restrict__ regions, const float* __restrict__ out,
+                                                                     const float* __restrict__ lse, const float* __restrict__ dout,
+                                                                     float* __restrict__ dqkv, float* __restrict__ dbias, WinAttnGeom g) {
   ICL_DYN_LDS(float, lds);
   float* Ks = lds;
   float* Vs = Ks + g.npad * kWaLd;
@@ -342,6 +311,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_bias_kernel(const 
     dl += __shfl_xor(dl, 32, 64);
     const float lq = qvalid ? lse[((long)b_ * g.heads + h) * g.n + qc] : 1.0e30f;
     const int rq = rid[qc];
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       if (kb < nkb) {
@@ -353,11 +323,20 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_bias_kernel(const 
         dp = icl_mfma_16x16x4(v4.z, g4.z, dp);
         dp = icl_mfma_16x16x4(v4.w, g4.w, dp);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[kb][r] += wa_exp(s[r] - lq) * (dp[r] - dl);
+        for (int r = 0; r < 4; ++r) {
+          const float ds = wa_exp(s[r] - lq) * (dp[r] - dl);
+          acc[kb][r] += ds;
+          dq = icl_mfma_16x16x4(ds, Ks[(kb * 16 + lg * 4 + r) * kWaLd + lr], dq);
+        }
       }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = qb * 16 + lg * 4 + r;
+      if (q < g.n) dqkv[((long)b_ * g.n + q) * rs + h * 16 + lr] = dq[r] * g.scale;
+    }
   }
-  if (!qvalid) return;
+  if (!qvalid || !dbias) return;
   float* drow = dbias + ((long)h * g.n + query) * g.npad;
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
