@@ -10,6 +10,9 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
+import torch  # noqa: F401  — must be loaded BEFORE libicl_hip.so: both link libamdhip64, and the process must end up with
+#                       torch's copy of the HIP runtime only (two runtimes: "no ROCm-capable device is detected" at launch)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libicl_hip.so")
 
