@@ -204,21 +204,24 @@ struct WgradTileT {
 // groups split the x-rows of the tile between them and write separate slabs.  8 waves share one staged tile, so the
 // staging registers per thread halve and 16 waves per CU (4 per SIMD, <= 128 registers) hide the LDS latency that keeps a
 // 2-waves-per-SIMD launch at 63 % matrix-pipe utilisation (PMC, profiles/).
-template <class TC, int WV>
+// NCB = 16-cout blocks per workgroup (1..3): every staged x value (the B operand, one LDS read per tap) then feeds NCB MFMAs,
+// as the forward kernel does with NBT — (4 NCB + 28) LDS dwords per 28 NCB MFMAs, and the x halo tile is re-staged NCB times
+// less often.
+template <class TC, int WV, int NCB>
 __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                               float* __restrict__ gwp, ConvGeom g) {
-  constexpr int T = 27, NTW = 7, TG = 4, NT = 64 * WV, HALVES = WV / 4;
+  constexpr int T = 27, NTW = 7, TG = 4, NT = 64 * WV, HALVES = WV / 4, MB = 16 * NCB;
   constexpr int PS = TC::PS, PXL = TC::PXL, PY = TC::PY, PZ = TC::PZ, MT = TC::MT, MTP = TC::MTP;
   constexpr int NP = TC::NP, CPP = TC::CPP, Q = TC::Q;
   constexpr int JX = (CPP * TC::PER_CH + NT - 1) / NT;
-  constexpr int GX = (16 * (MT / 4) + NT - 1) / NT;
+  constexpr int GX = (MB * (MT / 4) + NT - 1) / NT;
   constexpr int ROWS = MT / 16, RPH = ROWS / HALVES;
   static_assert(ROWS % HALVES == 0, "tile rows must split evenly over the wave groups");
   ICL_DYN_LDS(float, lds);
   float* Xs = lds;
   float* Gs = lds + 16 * PS;
   const int ncin = (g.CinP + 15) / 16;
-  const int co0 = (blockIdx.y / ncin) * 16;
+  const int co0 = (blockIdx.y / ncin) * MB;
   const int c0 = (blockIdx.y % ncin) * 16;
   const long HW = (long)g.H * g.W, DHW = g.D * HW;
   const float* xb = x + (long)blockIdx.z * g.x_bstride;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kern
   for (int i = 0; i < GX; ++i) {
     const int it = threadIdx.x + i * NT;
     gvt[i] = (it % (MT / 4)) * 4;
-    gco[i] = it < 16 * (MT / 4) ? it / (MT / 4) : -1;
+    gco[i] = it < MB * (MT / 4) ? it / (MT / 4) : -1;
   }
   float4 xv[NP][JX];
   float4 gv[GX];
@@ -305,9 +308,11 @@ __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kern
     bb[t] = lr * PS + lq + (TC::HX - 1) + (dz * PY + dy) * PXL + dx;
   }
   const int ab = lr * MTP + lq;
-  f32x4 acc[NTW];
+  f32x4 acc[NCB][NTW];
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int bt = blockIdx.x;
   if (bt < ntiles) load_tile(bt);
@@ -321,11 +326,14 @@ __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kern
 #pragma unroll
     for (int rr = 0; rr < RPH; ++rr) {
       // rows of this wave group; (row / TY, row % TY) must be compile-time per unrolled step, so the half enters as an offset
-      int ai = ab + 16 * rr + half * (16 * RPH);
-      ICL_OPAQUE_INT(ai);
-      float a[4];
+      float a[NCB][4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) a[s] = Gs[ai + 4 * s];
+      for (int cb = 0; cb < NCB; ++cb) {
+        int ai = ab + cb * 16 * MTP + 16 * rr + half * (16 * RPH);
+        ICL_OPAQUE_INT(ai);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[cb][s] = Gs[ai + 4 * s];
+      }
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
         if (t < NTW - 1 || tg + t * TG < T) {
@@ -336,7 +344,9 @@ __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kern
 #pragma unroll
           for (int s = 0; s < 4; ++s) b[s] = Xs[bi + 4 * s];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc[t] = icl_mfma_16x16x4(a[s], b[s], acc[t]);
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][t] = icl_mfma_16x16x4(a[cb][s], b[s], acc[cb][t]);
         }
       }
     }
@@ -351,7 +361,10 @@ __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kern
       // reduce_unpack_wgrad_kernel adds the slabs in a fixed order (bitwise reproducible gradients)
       const long slab = ((long)blockIdx.z * gridDim.x + blockIdx.x) * HALVES + half;
       float* dst = gwp + slab * ((long)T * g.CinP * g.CoutP) + ((long)tap * g.CinP + ci) * g.CoutP + co0 + lq * 4;
-      *reinterpret_cast<float4*>(dst) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+        if (co0 + cb * 16 < g.CoutP)
+          *reinterpret_cast<float4*>(dst + cb * 16) = make_float4(acc[cb][t][0], acc[cb][t][1], acc[cb][t][2], acc[cb][t][3]);
     }
   }
 }
