@@ -69,6 +69,18 @@ def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
             "sample": f"one full ICL step of the same workload (2 volumes 96^3, nc={num_classes}) after a 32^3 conv warm-up: {t:.2f} s"}
 
 
+def hbm_traffic(kernel: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC run (profiles/r1_hbm_traffic.json: FETCH_SIZE and
+    WRITE_SIZE passes of rocprofv3 on one reference layer of that kernel, gfx950 correction applied) — counters cannot be
+    collected from inside this process, so the number is the one measured by that run, for the layer named in `shape`."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
+            k = json.load(f)["kernels"].get(kernel)
+        return {kk: k[kk] for kk in ("shape", "hbm_bytes", "algorithmic_bytes")} if k else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,8 +176,10 @@ def main():
             tot_ms = sum(v[1] for v in conv.values())
             tot_fl = sum(v[2] for v in conv.values())
             tot_by = sum(v[3] for v in conv.values())
+            traffic = hbm_traffic(name)
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": traffic["hbm_bytes"] if traffic else None, "traffic_detail": traffic,
                     "launches_per_step": n // 3, "avg_launch_us": round(ms * 1e3 / n, 2),
                     "all_conv": {"ms_per_step": round(tot_ms / 3, 3), "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 3),
                                  "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
