@@ -24,6 +24,9 @@ __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 // hide an integer from constant folding: keeps LDS offsets small enough for ds_read2_b32 pairing (8-bit dword offsets)
 #define ICL_OPAQUE_INT(x) asm volatile("" : "+v"(x))
 
+// tell the compiler a value is the same in every lane of the wave (lets it use SGPRs / scalar loads for what depends on it)
+#define ICL_WAVE_UNIFORM(x) ((x) = __builtin_amdgcn_readfirstlane(x))
+
 #define ICL_DYN_LDS(type, name)                                              \
   extern __shared__ __attribute__((aligned(16))) unsigned char icl_dyn_lds_raw[]; \
   type* name = reinterpret_cast<type*>(icl_dyn_lds_raw)

@@ -73,34 +73,35 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(SgdMulti t, flo
 // per matrix and the optimiser reads it straight back; data-parallel training would all-reduce 3 GB of it.  Here the
 // update is applied directly from the factors: one pass over p and m (16 B per parameter instead of 4 + 20), and ranks
 // exchange the factors (~1 MB) instead of the matrix.  x slices and g columns are staged in LDS in chunks of 32 rows.
-constexpr int kSfRows = 16, kSfCols = 256, kSfChunk = 32;
+constexpr int kSvRows = 16, kSvCols = 256, kSvChunk = 32;
 
+// Variant for M <= 32 factor rows (one rank): plain VALU FMAs, no transposition step.
 // grid (ceil(K/256), ceil(N/16)), block 256: thread = float4 column kq (0..63) x row lane rl (rows 4*rl .. 4*rl+3).  K % 4 == 0.
-__global__ __launch_bounds__(256) void sgd_factored_kernel(float* __restrict__ p, float* __restrict__ mom, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void sgd_factored_small_kernel(float* __restrict__ p, float* __restrict__ mom, const float* __restrict__ g,
                                                            const float* __restrict__ x, int M, int N, int K, float lr, float momentum,
                                                            float wd, int first, const float* __restrict__ lr_dev) {
-  __shared__ float4 xs[kSfChunk][kSfCols / 4];
-  __shared__ float gs[kSfChunk][kSfRows];
+  __shared__ float4 xs[kSvChunk][kSvCols / 4];
+  __shared__ float gs[kSvChunk][kSvRows];
   if (lr_dev) lr = *lr_dev;
-  const int n0 = blockIdx.y * kSfRows, k0 = blockIdx.x * kSfCols;
+  const int n0 = blockIdx.y * kSvRows, k0 = blockIdx.x * kSvCols;
   const int kq = threadIdx.x & 63, rl = threadIdx.x >> 6;
   float4 acc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int m0 = 0; m0 < M; m0 += kSfChunk) {
+  for (int m0 = 0; m0 < M; m0 += kSvChunk) {
     __syncthreads();
-    for (int it = threadIdx.x; it < kSfChunk * (kSfCols / 4); it += 256) {
-      const int m = it / (kSfCols / 4), q = it % (kSfCols / 4);
+    for (int it = threadIdx.x; it < kSvChunk * (kSvCols / 4); it += 256) {
+      const int m = it / (kSvCols / 4), q = it % (kSvCols / 4);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m0 + m < M && k0 + q * 4 < K) v = *reinterpret_cast<const float4*>(x + (long)(m0 + m) * K + k0 + q * 4);
       xs[m][q] = v;
     }
-    for (int it = threadIdx.x; it < kSfChunk * kSfRows; it += 256) {
-      const int m = it / kSfRows, r = it % kSfRows;
+    for (int it = threadIdx.x; it < kSvChunk * kSvRows; it += 256) {
+      const int m = it / kSvRows, r = it % kSvRows;
       gs[m][r] = (m0 + m < M && n0 + r < N) ? g[(long)(m0 + m) * N + n0 + r] : 0.f;
     }
     __syncthreads();
-    const int mc = (M - m0 < kSfChunk) ? M - m0 : kSfChunk;
+    const int mc = (M - m0 < kSvChunk) ? M - m0 : kSvChunk;
     for (int m = 0; m < mc; ++m) {
       const float4 xv = xs[m][kq];
 #pragma unroll
@@ -119,6 +120,83 @@ __global__ __launch_bounds__(256) void sgd_factored_kernel(float* __restrict__ p
     float4 pv = *reinterpret_cast<float4*>(p + idx);
     float4 mv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(mom + idx);
     sgd_update4(pv, acc[r], mv, lr, momentum, wd, first);
+    *reinterpret_cast<float4*>(p + idx) = pv;
+    *reinterpret_cast<float4*>(mom + idx) = mv;
+  }
+}
+
+constexpr int kSfRows = 64, kSfCols = 256, kSfChunk = 32;
+constexpr int kSfXp = kSfCols + 16, kSfGp = kSfRows + 16;   // LDS row pitches: the 4 factor rows of an MFMA k-step land 16 banks apart
+constexpr int kSfDp = kSfCols + 4;                            // pitch of the d tile: 16-byte aligned rows, conflict-free column writes
+constexpr int kSfLdsFloats = kSfRows * kSfDp;                 // 64 x 260 floats = 66.6 KB (the operand slices alias its start)
+static_assert(kSfChunk * (kSfXp + kSfGp) <= kSfLdsFloats, "operand slices must fit in the d-tile buffer");
+
+// grid (ceil(K/256), ceil(N/64)), block 256 = 4 waves, dynamic LDS = kSfLdsFloats floats.  The workgroup owns the 64 x 256 block
+// of the weight: wave w computes d = g^T x for columns 64 w .. 64 w + 63 on the fp32 MFMA (4 x 4 tiles, k-steps of 4 factor
+// rows; A[n][m] = g[m][n], B[m][k] = x[m][k] from the LDS slices of the current 32-row chunk: 8 ds_read_b32 per 16 MFMAs),
+// the block of d is transposed through LDS, and p / m are then updated with 16 bytes per lane and 1 KB per weight row and
+// wave — the same access pattern as the dense SGD kernel, so the update stays an HBM stream until M reaches a few hundred
+// (data-parallel ranks gather their factors: M = rows per rank x ranks).  K % 4 == 0.
+__global__ __launch_bounds__(256) void sgd_factored_kernel(float* __restrict__ p, float* __restrict__ mom, const float* __restrict__ g,
+                                                           const float* __restrict__ x, int M, int N, int K, float lr, float momentum,
+                                                           float wd, int first, const float* __restrict__ lr_dev) {
+  ICL_DYN_LDS(float, lds);
+  float* xs = lds;
+  float* gs = lds + kSfChunk * kSfXp;
+  if (lr_dev) lr = *lr_dev;
+  const int n0 = blockIdx.y * kSfRows, k0 = blockIdx.x * kSfCols;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr_ = lane & 15, lg = lane >> 4;
+  const int wc = wid * 64;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m0 = 0; m0 < M; m0 += kSfChunk) {
+    __syncthreads();
+    for (int it = threadIdx.x; it < kSfChunk * (kSfCols / 4); it += 256) {
+      const int m = it / (kSfCols / 4), q = it % (kSfCols / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + m < M && k0 + q * 4 < K) v = *reinterpret_cast<const float4*>(x + (long)(m0 + m) * K + k0 + q * 4);
+      *reinterpret_cast<float4*>(xs + m * kSfXp + q * 4) = v;
+    }
+    for (int it = threadIdx.x; it < kSfChunk * kSfRows; it += 256) {
+      const int m = it / kSfRows, r = it % kSfRows;
+      gs[m * kSfGp + r] = (m0 + m < M && n0 + r < N) ? g[(long)(m0 + m) * N + n0 + r] : 0.f;
+    }
+    __syncthreads();
+    const int steps = ((M - m0 < kSfChunk ? M - m0 : kSfChunk) + 3) / 4;   // rows past M are zero in LDS
+    for (int s = 0; s < steps; ++s) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = gs[(s * 4 + lg) * kSfGp + a * 16 + lr_];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = xs[(s * 4 + lg) * kSfXp + wc + b * 16 + lr_];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = icl_mfma_16x16x4(av[a], bv[b], acc[a][b]);
+    }
+  }
+  // d block -> LDS (row-major), then the streaming update
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[(a * 16 + lg * 4 + r) * kSfDp + wc + b * 16 + lr_] = acc[a][b][r];
+  __syncthreads();
+  const int kq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  if (k0 + kq * 4 >= K) return;
+  for (int row = rl; row < kSfRows; row += 4) {
+    const int n = n0 + row;
+    if (n >= N) break;
+    const long idx = (long)n * K + k0 + kq * 4;
+    const float4 d = *reinterpret_cast<const float4*>(lds + row * kSfDp + kq * 4);
+    float4 pv = *reinterpret_cast<float4*>(p + idx);
+    float4 mv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(mom + idx);
+    sgd_update4(pv, d, mv, lr, momentum, wd, first);
     *reinterpret_cast<float4*>(p + idx) = pv;
     *reinterpret_cast<float4*>(mom + idx) = mv;
   }

@@ -238,6 +238,7 @@ template <typename T> static inline T __shfl(T v, int src, int width = 64) {
 
 static inline float icl_fast_exp(float x) { return expf(x); }
 #define ICL_OPAQUE_INT(x) ((void)(x))
+#define ICL_WAVE_UNIFORM(x) ((void)(x))
 static inline float atomicAdd(float* p, float v) {
   uint32_t* ip = (uint32_t*)p;
   uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED), neu;

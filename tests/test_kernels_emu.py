@@ -239,10 +239,12 @@ def test_fused_sgd_matches_torch():
     assert torch.equal(skip.detach(), skip_ref)
 
 
-def test_factored_gradient_sgd_matches_dense(monkeypatch):
+@pytest.mark.parametrize("rows1", [19, 4, 70])
+def test_factored_gradient_sgd_matches_dense(monkeypatch, rows1):
     """ops.FactoredGrads: the weight gradient of a huge Linear stays (g, x); FusedSGD applies g^T x + wd*p without forming it.
     Three steps (first step initialises the momentum), two uses of the same weight in one backward (row blocks concatenate),
-    against F.linear + torch.optim.SGD with the dense gradient."""
+    against F.linear + torch.optim.SGD with the dense gradient.  2*rows1 + 5 factor rows: 43 and 145 take the MFMA kernel
+    (two and five 32-row chunks), 13 the small-M VALU kernel."""
     from icl_amd.networks.aligner import Linear
     from icl_amd.optim import FusedSGD
     monkeypatch.setattr(ops.FactoredGrads, "min_elems", 1000)
@@ -253,7 +255,7 @@ def test_factored_gradient_sgd_matches_dense(monkeypatch):
     a = FusedSGD(lin.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-2)
     b = torch.optim.SGD([ref_w, ref_b], lr=0.05, momentum=0.9, weight_decay=1e-2)
     for it in range(3):
-        x1, x2 = _rand((2, 19, 300), 90 + it), _rand((5, 300), 95 + it)
+        x1, x2 = _rand((2, rows1, 300), 90 + it), _rand((5, 300), 95 + it)
         a.zero_grad()
         b.zero_grad()
         with ops.FactoredGrads(True):
