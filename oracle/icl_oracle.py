@@ -145,23 +145,29 @@ def separable_conv3d(p: P, pre: str, x: torch.Tensor, training: bool) -> torch.T
 
 
 def inherent_consistent(p: P, pre: str, feats: Sequence[torch.Tensor], heads: Sequence[int],
-                        guided_q=None, modal: str = "labeled", training: bool = True, q_name: str = "guided_Q"):
+                        guided_q=None, modal: str = "labeled", training: bool = True, q_name: str = "guided_Q",
+                        token_dims: int = 0):
     """InherentConsistent.forward, networks/unet_3D_icl.py:202-242 (swinunetr_icl.py:406-446 is the same code with the
     learnable query named ``guide_Q``: pass ``q_name``).
 
     labeled: queries start from the learnable ``guided_Q`` and are handed down through
     ``query_convs`` (:208-221); unlabeled: each scale starts from ``guided_q[i]`` (:229).
+    ``token_dims`` = 2: the 2-D Swin-UNet variant (networks/vision_transformer.py:247-248) feeds decoder TOKENS [B, N, C]
+    straight into the class decoders — proj_layers / norm_layers exist as parameters but are never called.
     Returns (feat_maps[3], updated_Qs[3])."""
     bs = feats[0].shape[0]
     maps, upd = [], []
     nxt = p[f"{pre}.{q_name}"].expand(bs, -1, -1) if modal == "labeled" else None
     for i, f in enumerate(feats):
-        tok = _convnd(f, p[f"{pre}.proj_layers.{i}.weight"], p[f"{pre}.proj_layers.{i}.bias"])
-        tok = _ln(p, f"{pre}.norm_layers.{i}", tok.flatten(2).transpose(1, 2))
+        if token_dims:
+            tok = f
+        else:
+            tok = _convnd(f, p[f"{pre}.proj_layers.{i}.weight"], p[f"{pre}.proj_layers.{i}.bias"])
+            tok = _ln(p, f"{pre}.norm_layers.{i}", tok.flatten(2).transpose(1, 2))
         q_in = nxt if modal == "labeled" else guided_q[i].expand(bs, -1, -1)
         q_out, attn = class_decoder(p, f"{pre}.class_decoders.{i}", q_in, tok, heads[i])
         b, nc, h, n = attn.shape
-        dims = f.dim() - 2   # 3: int(np.cbrt(N)) (unet_3D_icl.py:215); 2: int(np.sqrt(N)) (unet_icl.py:311)
+        dims = token_dims or f.dim() - 2   # 3: int(np.cbrt(N)) (unet_3D_icl.py:215); 2: int(np.sqrt(N)) (unet_icl.py:311)
         r = int(round(n ** (1.0 / dims)))
         sp = (r,) * dims
         a = attn.contiguous().view(b * nc, h, *sp)

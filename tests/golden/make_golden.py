@@ -512,6 +512,113 @@ def gen_swin(R, out, nc=2):
     print("swin: losses", d["losses"], "grad_none", len(none), "params", sum(p.numel() for p in model.parameters()))
 
 
+# ---------------------------------------------------------------- 2D Swin-UNet ICL
+def install_timm_turtle_stubs():
+    """networks/vision_transformer.py imports `timm`, `timm.models.layers.{DropPath, to_2tuple, trunc_normal_}` and, by accident,
+    `from turtle import back` (needs tkinter).  None of them carries arithmetic of the path: DropPath is the per-sample
+    stochastic depth (forced to identity in parity mode), to_2tuple a tuple helper, trunc_normal_ an initialiser that the
+    hash fill overwrites."""
+    class DropPath(nn.Module):
+        def __init__(self, drop_prob=0.0):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            if self.drop_prob == 0.0 or not self.training:
+                return x
+            keep = 1.0 - self.drop_prob
+            mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+            return x.div(keep) * mask
+
+    timm = types.ModuleType("timm")
+    models = types.ModuleType("timm.models")
+    layers = types.ModuleType("timm.models.layers")
+    layers.DropPath = DropPath
+    layers.to_2tuple = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    layers.trunc_normal_ = lambda t, std=1.0, **kw: nn.init.trunc_normal_(t, std=std)
+    timm.models, models.layers = models, layers
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers})
+    turtle = types.ModuleType("turtle")
+    turtle.back = None
+    sys.modules["turtle"] = turtle
+
+
+def swinunet_config():
+    """configs/swin_tiny_patch4_window7_224_lite.yaml over the defaults of networks/config.py (yacs is not installed)."""
+    NS = types.SimpleNamespace
+    return NS(DATA=NS(IMG_SIZE=224),
+              MODEL=NS(DROP_RATE=0.0, DROP_PATH_RATE=0.2, PRETRAIN_CKPT=None,
+                       SWIN=NS(PATCH_SIZE=4, IN_CHANS=3, EMBED_DIM=96, DEPTHS=[2, 2, 2, 2], NUM_HEADS=[3, 6, 12, 24], WINDOW_SIZE=7,
+                               MLP_RATIO=4.0, QKV_BIAS=True, QK_SCALE=False, APE=False, PATCH_NORM=True)),
+              TRAIN=NS(USE_CHECKPOINT=False))
+
+
+def gen_swinunet2d(R, out, nc=4):
+    install_timm_turtle_stubs()
+    from networks.vision_transformer import SwinUnet
+    L = R["losses"]
+    model = SwinUnet(swinunet_config(), img_size=224, num_classes=nc)      # net_factory.py:85-86
+    parity_mode(model)
+    fill(model)
+    d = {}
+    d["keys"] = np.array(list(model.state_dict().keys()))
+    d["param_keys"] = np.array([k for k, _ in model.named_parameters()])
+    d["param_shapes"] = np.array([",".join(map(str, p.shape)) for _, p in model.named_parameters()])
+    img = synthetic_volume((4, 1, 224, 224), 3024)
+    lab = synthetic_labels((2, 224, 224), 3025, nc)
+    model.train()
+    with torch.no_grad():
+        x3 = img[:2].repeat(1, 3, 1, 1)
+        xe, skips = model.swin_unet.forward_features(x3)
+        d["enc_out"] = npy(xe)[:, ::7, ::32]
+        for i, t in enumerate(skips):
+            d[f"skip{i}_l2"] = npy(t.double().pow(2).sum().sqrt())
+        xl, feats = model.swin_unet.forward_up_features(xe, skips)
+        for i, t in enumerate(feats):
+            d[f"feat{i}_sub"] = npy(t)[:, ::13, ::16]
+    outs = model(img[:2], img[2:])
+    for name, t in (("out_lab", outs[0]), ("out_unlab", outs[1])):
+        d[name + "_sub"] = npy(t)[:, :, ::8, ::8]
+        d[name + "_l2"] = npy(t.double().pow(2).sum(dim=(0, 2, 3)).sqrt())
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            st = (1, 2, 4)[i]
+            d[f"{name}{i}_sub"] = npy(t)[:, :, ::st, ::st]
+            d[f"{name}{i}_l2"] = npy(t.double().pow(2).sum().sqrt())
+    l_ce = nn.CrossEntropyLoss()(outs[0], lab.long())
+    l_dice = L.DiceLoss(nc)(outs[0], lab.unsqueeze(1), softmax=True)
+    l_aux = L.AuxLoss(nc)(outs[2], lab)                       # resize default [224, 224]
+    l_pse = L.PseudoSoftLoss(nc)(outs[3], outs[1])
+    l_con = L.softmax_mse_loss(outs[3], outs[4])
+    loss = l_ce + l_dice + l_aux + l_pse + 50 * l_con         # train_inherent_consistent_swinunet_2D.py:148-155
+    d["losses"] = np.array([float(v.detach()) for v in (l_ce, l_dice, l_aux, l_pse, l_con, loss)])
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    opt.zero_grad()
+    loss.backward()
+    gn, none = {}, []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            none.append(k)
+        else:
+            gn[k] = float(p.grad.double().pow(2).sum().sqrt())
+    d["grad_none"] = np.array(none)
+    d["grad_norm_keys"] = np.array(list(gn.keys()))
+    d["grad_norms"] = np.array(list(gn.values()))
+    sd_ = dict(model.named_parameters())
+    for k in ("swin_unet.output.weight", "swin_unet.patch_embed.proj.weight", "swin_unet.layers.0.blocks.1.attn.relative_position_bias_table",
+              "swin_unet.layers_up.0.expand.weight", "swin_unet.concat_back_dim.1.weight", "sspa.guided_Q"):
+        g = npy(sd_[k].grad)
+        d["grad." + k] = g if g.size <= 8192 else g.reshape(-1)[::97].copy()
+    opt.step()
+    d["post_sgd_norms"] = np.array([float(p.detach().double().pow(2).sum().sqrt()) for _, p in model.named_parameters()])
+    model.eval()
+    with torch.no_grad():
+        y = model(img[:2], inference=True)
+    d["inf_logits_sub"] = npy(y)[:, :, ::8, ::8]
+    np.savez_compressed(os.path.join(out, f"model_swinunet2d_icl_nc{nc}.npz"), **d)
+    print("swinunet2d: losses", d["losses"], "grad_none", len(none), "params", sum(p.numel() for p in model.parameters()))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -528,3 +635,5 @@ if __name__ == "__main__":
         gen_model2d(R, HERE)
     if a.only in ("all", "swin"):
         gen_swin(R, HERE)
+    if a.only in ("all", "swinunet2d"):
+        gen_swinunet2d(R, HERE)

@@ -278,3 +278,54 @@ def test_swinunetr_icl_step_matches_reference():
     with torch.no_grad():             # the golden's inference logits are those of the model AFTER the SGD step
         y = S.swinunetr_icl_forward(p, vol[:1], inference=True)
     assert rel_err(y[:, :, ::8, ::8, ::8], g["inf_logits_sub"]) < 1e-4
+
+
+@pytest.mark.slow
+def test_swinunet2d_icl_step_matches_reference():
+    """2-D Swin-UNet ICL (224^2, nc=4, batch 2+2) — encoder output, decoder features handed to the
+    aligners, forward 5-tuple, losses, grad-None set (57: the aligners' unused proj/norm layers among them), gradient norms
+    and one SGD step against the reference golden."""
+    from oracle import swinunet2d_oracle as W
+    nc = 4
+    g = load_golden("model_swinunet2d_icl_nc4.npz")
+    shapes = W.swinunet_icl_shapes(nc)
+    assert [k for k, _ in shapes] == list(g["param_keys"])
+    assert [",".join(map(str, s)) for _, s in shapes] == list(g["param_shapes"])
+    p = W.make_params(nc, requires_grad=True)
+    assert set(p.keys()) == {k for k in g["keys"] if not k.endswith("num_batches_tracked")}
+    img = synthetic_volume((4, 1, 224, 224), 3024)
+    lab = synthetic_labels((2, 224, 224), 3025, nc)
+    with torch.no_grad():
+        xe, skips = W.forward_features(p, img[:2].repeat(1, 3, 1, 1))
+        assert rel_err(xe[:, ::7, ::32], g["enc_out"]) < 1e-4
+        _, feats = W.forward_up_features(p, xe, skips)
+        for i, t in enumerate(feats):
+            assert rel_err(t[:, ::13, ::16], g[f"feat{i}_sub"]) < 1e-4, i
+    outs = W.swinunet_icl_forward(p, img[:2], img[2:], training=True)
+    assert rel_err(outs[0].detach()[:, :, ::8, ::8], g["out_lab_sub"]) < 1e-4
+    assert rel_err(outs[1].detach()[:, :, ::8, ::8], g["out_unlab_sub"]) < 1e-4
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            st = (1, 2, 4)[i]
+            assert rel_err(t.detach()[:, :, ::st, ::st], g[f"{name}{i}_sub"]) < 2e-4, (name, i)
+    total, parts = W.icl_losses(outs, lab, nc)
+    got = [float(parts[k].detach()) for k in ("ce", "dice", "aux", "pse", "con")] + [float(total.detach())]
+    assert np.allclose(got, g["losses"], rtol=0, atol=2e-5), (got, g["losses"])
+    total.backward()
+    none = [k for k, _ in shapes if p[k].grad is None]
+    assert none == list(g["grad_none"]) and len(none) == 57
+    ref = dict(zip(g["grad_norm_keys"], g["grad_norms"]))
+    bad = []
+    for k, r in ref.items():
+        if "attn_convs1" in k and k.endswith("bias"):
+            continue
+        got_n = float(p[k].grad.double().norm())
+        if abs(got_n - r) > 3e-3 * max(r, 1e-7) + 1e-9:
+            bad.append((k, got_n, r))
+    assert not bad, bad[:10]
+    O.sgd_step(p, {k: p[k].grad for k, _ in shapes}, {}, lr=0.01)
+    post = np.array([float(p[k].detach().double().norm()) for k, _ in shapes])
+    assert np.allclose(post, g["post_sgd_norms"], rtol=1e-6)
+    with torch.no_grad():
+        y = W.swinunet_icl_forward(p, img[:2], inference=True)
+    assert rel_err(y[:, :, ::8, ::8], g["inf_logits_sub"]) < 1e-4
