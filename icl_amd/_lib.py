@@ -59,8 +59,8 @@ _SIGNATURES = {
     "icl_conv1x1_wgrad": (c_int, [P, P, P, P, P, I, I, I, L, L, L, P]),
     "icl_relpos_bias_fwd": (c_int, [P, P, P, I, I, I, P]),
     "icl_relpos_bias_bwd": (c_int, [P, P, P, L, I, I, I, P]),
-    "icl_window_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, F, P]),
-    "icl_window_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, F, P]),
+    "icl_window_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, F, P]),
+    "icl_window_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
     "icl_layernorm_fwd": (c_int, [P, P, P, P, P, P, L, I, F, P]),
     "icl_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, L, I, P]),
     "icl_gelu_fwd": (c_int, [P, P, L, P]),

@@ -2,7 +2,8 @@
 //
 // Reference: WindowAttention.forward, /root/reference/code/networks/swinunetr_icl.py:727-750 —
 //     attn = softmax((q * scale) @ k^T + relative_position_bias + shift_mask);   x = attn @ v
-// for every (window, head): n <= 343 tokens, head dim 16 in every stage of SwinUNETR (C / heads = 48/3 = ... = 16).
+// for every (window, head): n <= 343 tokens; head dim DH = 16 in every stage of SwinUNETR (C / heads = 48/3 = ... = 16) and
+// DH = 32 in the 2-D Swin-UNet (7x7 windows, n = 49, networks/swinunet_icl.py:120-155) — a template parameter.
 // Nothing of size n x n ever reaches HBM: one workgroup owns one (window, head), keeps K and V (n x 16 each) in LDS and
 // each wave keeps the full score row block of its 16 queries in registers (22 key blocks x 4 VGPRs).
 //
@@ -29,11 +30,13 @@
 
 namespace icl {
 
-constexpr int kWaLd = 20;          // LDS row stride in floats (16 dims + 4 pad): ds_read_b128 rows and ds_read_b32 columns conflict-free
 constexpr float kWaMaskAdd = -100.0f;
 constexpr int kWaThreads = 512;   // 8 waves per workgroup: two per SIMD hide the exp / LDS latency between MFMA chains
 constexpr int kWaWaves = kWaThreads / 64;
 constexpr float kWaPad = -1.0e30f; // bias value of the padded key columns
+
+// LDS row pitch in floats (DH dims + 4 pad): ds_read_b128 rows and ds_read_b32 columns are conflict-free for DH = 16 and 32
+template <int DH> struct WaCfg { static constexpr int LD = DH + 4, Q4 = DH / 4, DT = DH / 16; };
 
 struct WinAttnGeom {
   int B_, n, npad, heads, nW;      // B_ = batch * nW windows; window id of row b_ is b_ % nW (window_partition order)
@@ -43,28 +46,53 @@ struct WinAttnGeom {
 // exp via v_exp_f32 (2^x): relative error ~1e-6 for |x| < 20, far inside the 1e-3 parity budget
 __device__ __forceinline__ float wa_exp(float x) { return icl_fast_exp(x); }
 
-// rows [0, n) <- src[row * row_stride + 0..15] (optionally scaled), rows [n, npad) <- 0
+// rows [0, n) <- src[row * row_stride + 0..DH-1] (optionally scaled), rows [n, npad) <- 0
+template <int DH>
 __device__ __forceinline__ void wa_stage_rows(float* dst, const float* __restrict__ src, long row_stride, int n, int npad, float mul) {
-  for (int it = threadIdx.x; it < npad * 4; it += blockDim.x) {
-    const int row = it >> 2, q = it & 3;
+  constexpr int LD = WaCfg<DH>::LD, Q4 = WaCfg<DH>::Q4;
+  for (int it = threadIdx.x; it < npad * Q4; it += blockDim.x) {
+    const int row = it / Q4, q = it % Q4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < n) {
       v = *reinterpret_cast<const float4*>(src + row * row_stride + q * 4);
       v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
     }
-    *reinterpret_cast<float4*>(dst + row * kWaLd + q * 4) = v;
+    *reinterpret_cast<float4*>(dst + row * LD + q * 4) = v;
   }
 }
 
-// S^T block for (key block kb, the wave's query block): lane -> scores of query lr against keys kb*16 + 4*lg + r.
-__device__ __forceinline__ f32x4 wa_scores_t(const float* Ks, int kb, int lr, int lg, const float (&qv)[4], const float* brow,
-                                             const int* rid, int rq, bool masked) {
+// The DH values a lane contributes to a DH-deep contraction: dims 16*u + 4*lg + t (u < DH/16, t < 4) — MFMA step 4u + t.
+template <int DH> struct WaFrag {
+  float v[DH / 4];
+  __device__ __forceinline__ void load(const float* row, int lg, float mul = 1.f) {
+#pragma unroll
+    for (int u = 0; u < DH / 16; ++u) {
+      const float4 q = *reinterpret_cast<const float4*>(row + u * 16 + lg * 4);
+      v[4 * u] = q.x * mul; v[4 * u + 1] = q.y * mul; v[4 * u + 2] = q.z * mul; v[4 * u + 3] = q.w * mul;
+    }
+  }
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) v[i] = 0.f;
+  }
+};
+
+// acc += A . B over the DH dims held in two fragments (A rows = the lanes' lr of fragment a, B columns = lr of fragment b)
+template <int DH>
+__device__ __forceinline__ f32x4 wa_dot(const WaFrag<DH>& a, const WaFrag<DH>& b) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const float4 k4 = *reinterpret_cast<const float4*>(Ks + (kb * 16 + lr) * kWaLd + lg * 4);
-  acc = icl_mfma_16x16x4(k4.x, qv[0], acc);
-  acc = icl_mfma_16x16x4(k4.y, qv[1], acc);
-  acc = icl_mfma_16x16x4(k4.z, qv[2], acc);
-  acc = icl_mfma_16x16x4(k4.w, qv[3], acc);
+#pragma unroll
+  for (int i = 0; i < DH / 4; ++i) acc = icl_mfma_16x16x4(a.v[i], b.v[i], acc);
+  return acc;
+}
+
+// S^T block for (key block kb, the wave's query block): lane -> scores of query lr against keys kb*16 + 4*lg + r.
+template <int DH>
+__device__ __forceinline__ f32x4 wa_scores_t(const float* Ks, int kb, int lr, int lg, const WaFrag<DH>& qf, const float* brow,
+                                             const int* rid, int rq, bool masked) {
+  WaFrag<DH> kf;
+  kf.load(Ks + (kb * 16 + lr) * WaCfg<DH>::LD, lg);
+  f32x4 acc = wa_dot<DH>(kf, qf);
   const float4 b4 = *reinterpret_cast<const float4*>(brow + kb * 16 + lg * 4);
   acc[0] += b4.x; acc[1] += b4.y; acc[2] += b4.z; acc[3] += b4.w;
   if (masked) {
@@ -115,29 +143,30 @@ __global__ __launch_bounds__(256) void relpos_bias_scatter_kernel(const float* _
   }
 }
 
-// grid = B_ * heads workgroups of kWaThreads threads; LDS = (2 * npad * 20 + npad) * 4 bytes.
-template <int NKB>
+// grid = B_ * heads workgroups of kWaThreads threads; LDS = (2 * npad * (DH + 4) + npad) * 4 bytes.
+template <int NKB, int DH>
 __global__ __launch_bounds__(kWaThreads) void window_attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
                                                               const int* __restrict__ regions, float* __restrict__ out,
                                                               float* __restrict__ lse, WinAttnGeom g) {
+  constexpr int LD = WaCfg<DH>::LD, DT = WaCfg<DH>::DT;
   ICL_DYN_LDS(float, lds);
   float* Ks = lds;
-  float* Vs = Ks + g.npad * kWaLd;
-  int* rid = reinterpret_cast<int*>(Vs + g.npad * kWaLd);
+  float* Vs = Ks + g.npad * LD;
+  int* rid = reinterpret_cast<int*>(Vs + g.npad * LD);
   const int b_ = blockIdx.x / g.heads, h = blockIdx.x % g.heads;
-  const int C = g.heads * 16, nkb = g.npad / 16;
+  const int C = g.heads * DH, nkb = g.npad / 16;
   const long rs = 3L * C;
-  const float* base = qkv + (long)b_ * g.n * rs + h * 16;
-  wa_stage_rows(Ks, base + C, rs, g.n, g.npad, 1.f);
-  wa_stage_rows(Vs, base + 2 * C, rs, g.n, g.npad, 1.f);
+  const float* base = qkv + (long)b_ * g.n * rs + h * DH;
+  wa_stage_rows<DH>(Ks, base + C, rs, g.n, g.npad, 1.f);
+  wa_stage_rows<DH>(Vs, base + 2 * C, rs, g.n, g.npad, 1.f);
   const bool masked = regions != nullptr;
   for (int i = threadIdx.x; i < g.npad; i += blockDim.x) rid[i] = (masked && i < g.n) ? regions[(long)(b_ % g.nW) * g.n + i] : 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   for (int qb = wid; qb < nkb; qb += kWaWaves) {
     const int query = qb * 16 + lr, qc = query < g.n ? query : g.n - 1;
-    const float4 q4 = *reinterpret_cast<const float4*>(base + (long)qc * rs + lg * 4);
-    const float qv[4] = {q4.x * g.scale, q4.y * g.scale, q4.z * g.scale, q4.w * g.scale};
+    WaFrag<DH> qf;
+    qf.load(base + (long)qc * rs, lg, g.scale);
     const int rq = rid[qc];
     const float* brow = bias + ((long)h * g.n + qc) * g.npad;
     f32x4 s[NKB];
@@ -145,7 +174,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_fwd_kernel(const float
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       if (kb < nkb) {
-        s[kb] = wa_scores_t(Ks, kb, lr, lg, qv, brow, rid, rq, masked);
+        s[kb] = wa_scores_t<DH>(Ks, kb, lr, lg, qf, brow, rid, rq, masked);
         m = fmaxf(m, fmaxf(fmaxf(s[kb][0], s[kb][1]), fmaxf(s[kb][2], s[kb][3])));
       }
     }
@@ -167,45 +196,54 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_fwd_kernel(const float
     l += __shfl_xor(l, 32, 64);
     if (lg == 0 && query < g.n) lse[((long)b_ * g.heads + h) * g.n + query] = m + logf(l);
     const float inv = 1.0f / l;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    f32x4 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       if (kb < nkb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o = icl_mfma_16x16x4(s[kb][r], Vs[(kb * 16 + lg * 4 + r) * kWaLd + lr], o);
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < DT; ++t) o[t] = icl_mfma_16x16x4(s[kb][r], Vs[(kb * 16 + lg * 4 + r) * LD + t * 16 + lr], o[t]);
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int q = qb * 16 + lg * 4 + r;
       const float iv = __shfl(inv, lg * 4 + r, 64);   // lane (lr = 4*lg + r, lg = 0) holds 1/l of that query
-      if (q < g.n) out[((long)b_ * g.n + q) * C + h * 16 + lr] = o[r] * iv;
+      if (q < g.n) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) out[((long)b_ * g.n + q) * C + h * DH + t * 16 + lr] = o[t][r] * iv;
+      }
     }
   }
 }
 
-// dK and dV.  grid = B_ * heads; LDS = (2 * npad * 20 + 3 * npad) * 4 bytes (scale*Q, dO, log-sum-exp, delta, region ids of every
-// query of the window); waves own key blocks, their K / V rows come straight from HBM as MFMA operands.
+// dK and dV.  grid = B_ * heads; LDS = (2 * npad * (DH + 4) + 3 * npad) * 4 bytes (scale*Q, dO, log-sum-exp, delta, region ids of
+// every query of the window); waves own key blocks, their K / V rows come straight from HBM as MFMA operands.
 // S layout: lane -> query 4*lg + r of the block, key lr.  dqkv has the layout of qkv; only the k and v thirds are written here.
+template <int DH>
 __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
                                                                  const int* __restrict__ regions, const float* __restrict__ out,
                                                                  const float* __restrict__ lse, const float* __restrict__ dout,
                                                                  float* __restrict__ dqkv, WinAttnGeom g) {
+  constexpr int LD = WaCfg<DH>::LD, DT = WaCfg<DH>::DT, Q4 = WaCfg<DH>::Q4;
   ICL_DYN_LDS(float, lds);
   const int np = g.npad;
   float* Qs = lds;                 // scale * Q
-  float* Gs = Qs + np * kWaLd;     // dO
-  float* Ls = Gs + np * kWaLd;     // log-sum-exp per query (+1e30 on pad rows -> p = 0)
+  float* Gs = Qs + np * LD;        // dO
+  float* Ls = Gs + np * LD;        // log-sum-exp per query (+1e30 on pad rows -> p = 0)
   float* Ds = Ls + np;             // delta[q] = sum_dim dO * O
   int* rid = reinterpret_cast<int*>(Ds + np);
   const int b_ = blockIdx.x / g.heads, h = blockIdx.x % g.heads;
-  const int C = g.heads * 16, nkb = np / 16;
+  const int C = g.heads * DH, nkb = np / 16;
   const long rs = 3L * C;
-  const float* base = qkv + (long)b_ * g.n * rs + h * 16;
-  const float* dob = dout + (long)b_ * g.n * C + h * 16;
-  const float* ob = out + (long)b_ * g.n * C + h * 16;
-  wa_stage_rows(Qs, base, rs, g.n, np, g.scale);
-  wa_stage_rows(Gs, dob, C, g.n, np, 1.f);
+  const float* base = qkv + (long)b_ * g.n * rs + h * DH;
+  const float* dob = dout + (long)b_ * g.n * C + h * DH;
+  const float* ob = out + (long)b_ * g.n * C + h * DH;
+  wa_stage_rows<DH>(Qs, base, rs, g.n, np, g.scale);
+  wa_stage_rows<DH>(Gs, dob, C, g.n, np, 1.f);
   const bool masked = regions != nullptr;
   for (int i = threadIdx.x; i < np; i += blockDim.x) {
     rid[i] = (masked && i < g.n) ? regions[(long)(b_ % g.nW) * g.n + i] : 0;
@@ -213,7 +251,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_kv_kernel(const fl
     if (i < g.n) {
       ls = lse[((long)b_ * g.heads + h) * g.n + i];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < Q4; ++q) {
         const float4 a = *reinterpret_cast<const float4*>(dob + (long)i * C + q * 4);
         const float4 b = *reinterpret_cast<const float4*>(ob + (long)i * C + q * 4);
         dl += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
@@ -226,24 +264,21 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_kv_kernel(const fl
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   for (int kb = wid; kb < nkb; kb += kWaWaves) {
     const int key = kb * 16 + lr, kc = key < g.n ? key : g.n - 1;
-    float4 k4 = *reinterpret_cast<const float4*>(base + C + (long)kc * rs + lg * 4);
-    float4 v4 = *reinterpret_cast<const float4*>(base + 2 * C + (long)kc * rs + lg * 4);
-    if (key >= g.n) { k4 = make_float4(0.f, 0.f, 0.f, 0.f); v4 = k4; }
+    WaFrag<DH> kf, vf;
+    kf.load(base + C + (long)kc * rs, lg);
+    vf.load(base + 2 * C + (long)kc * rs, lg);
+    if (key >= g.n) { kf.zero(); vf.zero(); }
     const int rk = rid[kc];
-    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dk[DT], dv[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) { dk[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 2
     for (int qb = 0; qb < nkb; ++qb) {
-      const float4 q4 = *reinterpret_cast<const float4*>(Qs + (qb * 16 + lr) * kWaLd + lg * 4);
-      const float4 g4 = *reinterpret_cast<const float4*>(Gs + (qb * 16 + lr) * kWaLd + lg * 4);
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-      s = icl_mfma_16x16x4(q4.x, k4.x, s);
-      s = icl_mfma_16x16x4(q4.y, k4.y, s);
-      s = icl_mfma_16x16x4(q4.z, k4.z, s);
-      s = icl_mfma_16x16x4(q4.w, k4.w, s);
-      dp = icl_mfma_16x16x4(g4.x, v4.x, dp);
-      dp = icl_mfma_16x16x4(g4.y, v4.y, dp);
-      dp = icl_mfma_16x16x4(g4.z, v4.z, dp);
-      dp = icl_mfma_16x16x4(g4.w, v4.w, dp);
+      WaFrag<DH> qf, gf;
+      qf.load(Qs + (qb * 16 + lr) * LD, lg);
+      gf.load(Gs + (qb * 16 + lr) * LD, lg);
+      const f32x4 s = wa_dot<DH>(qf, kf);
+      const f32x4 dp = wa_dot<DH>(gf, vf);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int q = qb * 16 + lg * 4 + r, qc = q < g.n ? q : g.n - 1;
@@ -251,17 +286,23 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_kv_kernel(const fl
         if (masked && rid[qc] != rk) sv += kWaMaskAdd;
         const float p = wa_exp(sv - Ls[q]);
         const float ds = p * (dp[r] - Ds[q]);
-        dv = icl_mfma_16x16x4(p, Gs[q * kWaLd + lr], dv);
-        dk = icl_mfma_16x16x4(ds, Qs[q * kWaLd + lr], dk);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          dv[t] = icl_mfma_16x16x4(p, Gs[q * LD + t * 16 + lr], dv[t]);
+          dk[t] = icl_mfma_16x16x4(ds, Qs[q * LD + t * 16 + lr], dk[t]);
+        }
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = kb * 16 + lg * 4 + r;
       if (k < g.n) {
-        float* row = dqkv + ((long)b_ * g.n + k) * rs + h * 16 + lr;
-        row[C] = dk[r];
-        row[2 * C] = dv[r];
+        float* row = dqkv + ((long)b_ * g.n + k) * rs + h * DH + lr;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          row[C + t * 16] = dk[t][r];
+          row[2 * C + t * 16] = dv[t][r];
+        }
       }
     }
   }
@@ -270,17 +311,18 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_kv_kernel(const fl
 // dQ and d(bias).  Waves own a (head, query block) and walk over a slice of the windows: for every window K and V are staged
 // in LDS, dS is recomputed (S^T layout), dQ of the 16 queries is written, and dS is added to a register-resident 16 x n slab
 // of d(bias), which is summed over all windows of the batch and added to HBM once at the end.
-// grid (ceil(nkb/kWaWaves), heads, chunks); LDS = (2 * npad * 20 + npad) * 4 bytes.  dbias [heads, n, npad] zeroed (may be NULL).
-template <int NKB>
+// grid (ceil(nkb/kWaWaves), heads, chunks); LDS = (2 * npad * (DH + 4) + npad) * 4 bytes.  dbias [heads, n, npad] zeroed (may be NULL).
+template <int NKB, int DH>
 __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_q_bias_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
                                                                      const int* __restrict__ regions, const float* __restrict__ out,
                                                                      const float* __restrict__ lse, const float* __restrict__ dout,
                                                                      float* __restrict__ dqkv, float* __restrict__ dbias, WinAttnGeom g) {
+  constexpr int LD = WaCfg<DH>::LD, DT = WaCfg<DH>::DT;
   ICL_DYN_LDS(float, lds);
   float* Ks = lds;
-  float* Vs = Ks + g.npad * kWaLd;
-  int* rid = reinterpret_cast<int*>(Vs + g.npad * kWaLd);
-  const int h = blockIdx.y, C = g.heads * 16, nkb = g.npad / 16;
+  float* Vs = Ks + g.npad * LD;
+  int* rid = reinterpret_cast<int*>(Vs + g.npad * LD);
+  const int h = blockIdx.y, C = g.heads * DH, nkb = g.npad / 16;
   const long rs = 3L * C;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int qb = blockIdx.x * kWaWaves + wid;
@@ -295,45 +337,50 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_q_bias_kernel(cons
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) acc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int b_ = b0; b_ < b1; ++b_) {
-    const float* base = qkv + (long)b_ * g.n * rs + h * 16;
+    const float* base = qkv + (long)b_ * g.n * rs + h * DH;
     __syncthreads();
-    wa_stage_rows(Ks, base + C, rs, g.n, g.npad, 1.f);
-    wa_stage_rows(Vs, base + 2 * C, rs, g.n, g.npad, 1.f);
+    wa_stage_rows<DH>(Ks, base + C, rs, g.n, g.npad, 1.f);
+    wa_stage_rows<DH>(Vs, base + 2 * C, rs, g.n, g.npad, 1.f);
     for (int i = threadIdx.x; i < g.npad; i += blockDim.x) rid[i] = (masked && i < g.n) ? regions[(long)(b_ % g.nW) * g.n + i] : 0;
     __syncthreads();
     if (!active) continue;
-    const float4 q4 = *reinterpret_cast<const float4*>(base + (long)qc * rs + lg * 4);
-    const float4 g4 = *reinterpret_cast<const float4*>(dout + ((long)b_ * g.n + qc) * C + h * 16 + lg * 4);
-    const float4 o4 = *reinterpret_cast<const float4*>(out + ((long)b_ * g.n + qc) * C + h * 16 + lg * 4);
-    const float qv[4] = {q4.x * g.scale, q4.y * g.scale, q4.z * g.scale, q4.w * g.scale};
-    float dl = g4.x * o4.x + g4.y * o4.y + g4.z * o4.z + g4.w * o4.w;
+    WaFrag<DH> qf, gf, of;
+    qf.load(base + (long)qc * rs, lg, g.scale);
+    gf.load(dout + ((long)b_ * g.n + qc) * C + h * DH, lg);
+    of.load(out + ((long)b_ * g.n + qc) * C + h * DH, lg);
+    float dl = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) dl += gf.v[i] * of.v[i];
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
     const float lq = qvalid ? lse[((long)b_ * g.heads + h) * g.n + qc] : 1.0e30f;
     const int rq = rid[qc];
-    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dq[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       if (kb < nkb) {
-        const f32x4 s = wa_scores_t(Ks, kb, lr, lg, qv, brow, rid, rq, masked);
-        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-        const float4 v4 = *reinterpret_cast<const float4*>(Vs + (kb * 16 + lr) * kWaLd + lg * 4);
-        dp = icl_mfma_16x16x4(v4.x, g4.x, dp);
-        dp = icl_mfma_16x16x4(v4.y, g4.y, dp);
-        dp = icl_mfma_16x16x4(v4.z, g4.z, dp);
-        dp = icl_mfma_16x16x4(v4.w, g4.w, dp);
+        const f32x4 s = wa_scores_t<DH>(Ks, kb, lr, lg, qf, brow, rid, rq, masked);
+        WaFrag<DH> vf;
+        vf.load(Vs + (kb * 16 + lr) * LD, lg);
+        const f32x4 dp = wa_dot<DH>(vf, gf);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float ds = wa_exp(s[r] - lq) * (dp[r] - dl);
           acc[kb][r] += ds;
-          dq = icl_mfma_16x16x4(ds, Ks[(kb * 16 + lg * 4 + r) * kWaLd + lr], dq);
+#pragma unroll
+          for (int t = 0; t < DT; ++t) dq[t] = icl_mfma_16x16x4(ds, Ks[(kb * 16 + lg * 4 + r) * LD + t * 16 + lr], dq[t]);
         }
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int q = qb * 16 + lg * 4 + r;
-      if (q < g.n) dqkv[((long)b_ * g.n + q) * rs + h * 16 + lr] = dq[r] * g.scale;
+      if (q < g.n) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) dqkv[((long)b_ * g.n + q) * rs + h * DH + t * 16 + lr] = dq[t][r] * g.scale;
+      }
     }
   }
   if (!qvalid || !dbias) return;

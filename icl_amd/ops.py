@@ -857,8 +857,9 @@ class _WindowAttention(torch.autograd.Function):
         qkv = qkv.contiguous()
         b_, n, c3 = qkv.shape
         c = c3 // 3
-        if c != heads * 16:
-            raise ValueError("icl_amd window attention: head dim must be 16 (every SwinUNETR stage has C / heads = 16)")
+        dh = c // heads
+        if c != heads * dh or dh not in (16, 32):
+            raise ValueError("icl_amd window attention: head dim must be 16 (SwinUNETR) or 32 (2-D Swin-UNet)")
         if table.shape[1] != heads or index.dim() != 2 or index.shape[0] != index.shape[1] or n > index.shape[0]:
             raise ValueError("icl_amd window attention: table [T, heads] / index [N, N] with n <= N expected")
         table, index = table.contiguous(), index.contiguous()
@@ -868,28 +869,28 @@ class _WindowAttention(torch.autograd.Function):
         nw = regions.shape[0] if regions is not None else 1
         out = torch.empty((b_, n, c), dtype=torch.float32, device=qkv.device)
         lse = torch.empty((b_, heads, n), dtype=torch.float32, device=qkv.device)
-        flops = 4.0 * b_ * heads * n * n * 16
+        flops = 4.0 * b_ * heads * n * n * dh
         with _timed("window_attn_fwd_kernel", flops, 4.0 * (qkv.numel() + out.numel()), qkv):
-            _lib.check(L.icl_window_attn_fwd(_ptr(qkv), _ptr(bias_pad), _ptr(regions), _ptr(out), _ptr(lse), b_, n, heads, nw,
+            _lib.check(L.icl_window_attn_fwd(_ptr(qkv), _ptr(bias_pad), _ptr(regions), _ptr(out), _ptr(lse), b_, n, heads, nw, dh,
                                              scale, _stream(qkv)), "window_attn_fwd")
         ctx.save_for_backward(qkv, bias_pad, index, regions, out, lse)
-        ctx.cfg = (heads, scale, nw, table.shape[0])
+        ctx.cfg = (heads, scale, nw, table.shape[0], dh)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         qkv, bias_pad, index, regions, out, lse = ctx.saved_tensors
-        heads, scale, nw, trows = ctx.cfg
+        heads, scale, nw, trows, dh = ctx.cfg
         L = _lib.lib()
         gout = gout.contiguous()
         b_, n, _ = qkv.shape
         dqkv = torch.empty_like(qkv)
         need_table = ctx.needs_input_grad[1]
         dbias = torch.empty_like(bias_pad) if need_table else None
-        flops = 14.0 * b_ * heads * n * n * 16
+        flops = 14.0 * b_ * heads * n * n * dh
         with _timed("window_attn_bwd_kernel", flops, 4.0 * (2 * qkv.numel() + 2 * out.numel()), qkv):
             _lib.check(L.icl_window_attn_bwd(_ptr(qkv), _ptr(bias_pad), _ptr(regions), _ptr(out), _ptr(lse), _ptr(gout), _ptr(dqkv),
-                                             _ptr(dbias), b_, n, heads, nw, scale, _stream(qkv)), "window_attn_bwd")
+                                             _ptr(dbias), b_, n, heads, nw, dh, scale, _stream(qkv)), "window_attn_bwd")
         dtable = None
         if need_table:
             dtable = torch.empty((trows, heads), dtype=torch.float32, device=qkv.device)

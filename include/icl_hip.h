@@ -153,13 +153,14 @@ int icl_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* gbias, 
                       int64_t x_bstride, int64_t gy_bstride, void* stream);
 
 /* ---- Swin window attention: WindowAttention.forward core, networks/swinunetr_icl.py:728-747 —
- *   attn = softmax((q*scale) @ k^T + relative_position_bias [+ shift mask]);  out = attn @ v   per (window, head), head dim 16.
- * qkv  [B_, n, 3, heads, 16]  output of the qkv Linear (B_ = batch * nW windows, window id of row b_ = b_ % nW);  n <= 352
+ *   attn = softmax((q*scale) @ k^T + relative_position_bias [+ shift mask]);  out = attn @ v   per (window, head).
+ * head_dim 16 (3-D SwinUNETR, n <= 352) or 32 (2-D Swin-UNet 7x7 windows, networks/swinunet_icl.py:120-155, n <= 96).
+ * qkv  [B_, n, 3, heads, head_dim]  output of the qkv Linear (B_ = batch * nW windows, window id of row b_ = b_ % nW)
  * bias [heads, n, npad], npad = n rounded up to 16, pad columns = -1e30 (icl_window_attn_bias_elems floats; the caller gathers
  *      relative_position_bias_table[relative_position_index[:n,:n]] into it, :733-737)
  * regions int32 [nW, n] or NULL: region id of every token of the rolled volume; query/key pairs with different ids get -100
  *      (the dense attn_mask of compute_mask, :979-1016, is exactly -100 * (id_i != id_j))
- * out [B_, n, heads*16];  lse [B_, heads, n] = log-sum-exp of every score row (saved for backward).
+ * out [B_, n, heads*head_dim];  lse [B_, heads, n] = log-sum-exp of every score row (saved for backward).
  * Backward: dqkv (layout of qkv) and, if dbias != NULL, dbias [heads, n, npad] summed over all B_ windows (zeroed by the callee). */
 int64_t icl_window_attn_bias_elems(int n, int heads);
 /* bias[h][i][j] = table[index[i*idx_stride + j]][h] (j < n), -1e30 (n <= j < npad): the gather of :733-737 into the padded layout;
@@ -169,9 +170,10 @@ int icl_relpos_bias_fwd(const float* table, const int64_t* index, float* bias, i
 int icl_relpos_bias_bwd(const float* dbias, const int64_t* index, float* dtable, int64_t table_rows, int n, int heads, int idx_stride,
                         void* stream);
 int icl_window_attn_fwd(const float* qkv, const float* bias, const int32_t* regions, float* out, float* lse, int b_, int n, int heads,
-                        int nw, float scale, void* stream);
+                        int nw, int head_dim, float scale, void* stream);
 int icl_window_attn_bwd(const float* qkv, const float* bias, const int32_t* regions, const float* out, const float* lse,
-                        const float* dout, float* dqkv, float* dbias, int b_, int n, int heads, int nw, float scale, void* stream);
+                        const float* dout, float* dqkv, float* dbias, int b_, int n, int heads, int nw, int head_dim, float scale,
+                        void* stream);
 
 /* ---- fused SGD(momentum, weight decay) step, torch.optim.SGD semantics (train_inherent_consistent_unet_3D_BraTS.py:85-86,115):
  * d = g + wd*p; m = first ? d : momentum*m + d; p -= lr*m.  The multi form takes HOST arrays of device pointers.

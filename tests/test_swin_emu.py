@@ -178,6 +178,37 @@ def test_window_attention_kernel_fwd_bwd(dims, shifted, batch, heads):
     assert rel_err(table.grad, tr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("heads,batch,masked", [(2, 3, True), (1, 2, False)])
+def test_window_attention_kernel_head_dim_32(heads, batch, masked):
+    """2-D Swin-UNet windows (networks/swinunet_icl.py:120-155): 7 x 7 tokens (n = 49, 15 padded keys), head dim 32, 169-row
+    bias table, with and without a shift mask (4 windows of a 14 x 14 image) — output, dqkv and table gradient."""
+    from oracle import swinunet2d_oracle as W
+    n, c, nw = 49, heads * 32, 4
+    qkv = (_rand((batch * nw, n, 3 * c), 171) * 1.5).requires_grad_()
+    table = _rand((169, heads), 172).requires_grad_()
+    index = W.relative_position_index()
+    mask = W.attn_mask(14, 7, 3)
+    regions = None
+    if masked:   # region ids whose pairwise (in)equality reproduces the reference's 0 / -100 mask
+        img = torch.zeros((1, 14, 14, 1))
+        cnt = 0
+        for hs in (slice(0, -7), slice(-7, -3), slice(-3, None)):
+            for ws in (slice(0, -7), slice(-7, -3), slice(-3, None)):
+                img[:, hs, ws, :] = cnt
+                cnt += 1
+        regions = W.window_partition(img, 7).view(-1, 49).to(torch.int32).contiguous()
+        assert torch.equal((regions.unsqueeze(1) != regions.unsqueeze(2)).float() * -100.0, mask)
+    gy = _rand((batch * nw, n, c), 173)
+    y = ops.window_attention(qkv, table, index, regions, heads, 32 ** -0.5)
+    y.backward(gy)
+    qr, tr = qkv.detach().clone().requires_grad_(), table.detach().clone().requires_grad_()
+    yr = _window_attention_torch(qr, tr, index, regions, heads, 32 ** -0.5)
+    yr.backward(gy)
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    assert rel_err(qkv.grad, qr.grad) < 1e-4
+    assert rel_err(table.grad, tr.grad) < 1e-4
+
+
 @pytest.mark.parametrize("grid", [(8, 8, 8), (5, 9, 5), (2, 2, 2)])
 def test_swin_stage_matches_oracle(grid):
     """One BasicLayer (two blocks + patch merging) on small token grids: 8^3 (padded to 14^3, shifted 7^3 windows with the
