@@ -178,9 +178,13 @@ class InherentConsistent(nn.Module):
     def __init__(self, in_chans: Sequence[int], depths=(2, 2, 2), patch_size=(2, 2, 2),
                  input_resolution: Sequence[int] = (6, 12, 24), num_classes: int = 2,
                  num_heads: Sequence[int] = (16, 8, 4), norm_layer=None, patch_norm=False,
-                 spatial_dims: int = 3, drop_path_rate: float = 0.1, device=None, query_name: str = "guided_Q"):
+                 spatial_dims: int = 3, drop_path_rate: float = 0.1, device=None, query_name: str = "guided_Q",
+                 tokenized_input: bool = False):
         super().__init__()
         self._qname = query_name   # "guided_Q" in the U-Net files, "guide_Q" in swinunetr_icl.py:403
+        # 2-D Swin-UNet (networks/vision_transformer.py:247-248): the decoder hands over TOKENS [B, N, C]; proj_layers and
+        # norm_layers exist as parameters (state_dict parity, grad None) but are never called
+        self.tokenized_input = tokenized_input
         self.in_chans, self.depth = tuple(in_chans), tuple(depths)
         self.resolutions = tuple(input_resolution)
         self.dims = spatial_dims   # 3: unet_3D_icl.py:155-242; 2: unet_icl.py:253-340 (r^2 tokens, Conv2d/BatchNorm2d)
@@ -203,10 +207,13 @@ class InherentConsistent(nn.Module):
         self.register_parameter(query_name, nn.Parameter(torch.zeros(1, num_classes, in_chans[0], device=device)))
 
     def _tokens(self, i, feat):
-        """``proj_layers[i](feat).flatten(2).transpose(1, 2)`` (:212): a 1x1x1 convolution followed by the token transpose is
-        one GEMM on the channel axis, ``feat^T W^T + b`` -> [B, N, C] — a plain library GEMM (rocBLAS), no transpose copy."""
+        """``norm_layers[i](proj_layers[i](feat).flatten(2).transpose(1, 2))`` (:212): a 1x1x1 convolution followed by the token
+        transpose is one GEMM on the channel axis, ``feat^T W^T + b`` -> [B, N, C] — a plain library GEMM (rocBLAS), no
+        transpose copy."""
+        if self.tokenized_input:
+            return feat
         p = self.proj_layers[i]
-        return ops.linear(feat.flatten(2).transpose(1, 2), p.weight.flatten(1), p.bias)
+        return self.norm_layers[i](ops.linear(feat.flatten(2).transpose(1, 2), p.weight.flatten(1), p.bias))
 
     def forward_labeled_pair(self, feats_a, feats_b):
         """``self(feats_a, 'labeled')`` and ``self(feats_b, 'labeled')`` in lock step (the two ``sspa`` calls of
@@ -221,7 +228,7 @@ class InherentConsistent(nn.Module):
         nxt = getattr(self, self._qname).expand(bs, -1, -1)
         for i in range(len(self.depth)):
             f = torch.cat([feats_a[i], feats_b[i]], 0)
-            tok = self.norm_layers[i](self._tokens(i, f))
+            tok = self._tokens(i, f)
             q_out, attn = self.class_decoders[i](nxt, tok)
             b, nc, h, n = attn.shape
             r = self.resolutions[i]
@@ -242,7 +249,6 @@ class InherentConsistent(nn.Module):
         nxt = getattr(self, self._qname).expand(bs, -1, -1) if modal == "labeled" else None
         for i in range(len(self.depth)):
             tok = self._tokens(i, feats[i])
-            tok = self.norm_layers[i](tok)
             q_in = nxt if modal == "labeled" else guided_Q[i].expand(bs, -1, -1)
             q_out, attn = self.class_decoders[i](q_in, tok)
             b, nc, h, n = attn.shape

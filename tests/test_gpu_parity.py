@@ -431,6 +431,77 @@ def test_2d_unet_icl_step_matches_reference_golden(dev):
     assert rel_err(y[:, :, ::8, ::8].cpu(), g["inf_logits_sub"]) < 1e-3
 
 
+def test_swinunet2d_icl_step_matches_reference_golden(dev):
+    """2-D Swin-UNet ICL (224^2, nc=4, batch 2+2; 7x7 window attention with head dim 32 on the fused MFMA
+    kernels) — encoder output, decoder features, forward 5-tuple, losses, grad-None set, gradient norms, one SGD step and the
+    post-step inference logits against the reference golden; then the same step through ICLTrainer (factored mlp2 gradients)."""
+    from icl_amd.networks.net_factory import net_factory
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    nc = 4
+    g = load_golden("model_swinunet2d_icl_nc4.npz")
+    model = net_factory("icl_swinunet", in_chns=1, class_num=nc)
+    assert list(model.state_dict().keys()) == list(g["keys"])
+    assert [k for k, _ in model.named_parameters()] == list(g["param_keys"])
+    fill_like_reference_init(list(model.named_parameters()))
+    _parity_mode(model)
+    img = synthetic_volume((4, 1, 224, 224), 3024).to(dev)
+    lab = synthetic_labels((2, 224, 224), 3025, nc).to(dev)
+    model.train()
+    with torch.no_grad():
+        xe, skips = model.swin_unet.forward_features(img[:2].repeat(1, 3, 1, 1))
+        assert rel_err(xe[:, ::7, ::32].cpu(), g["enc_out"]) < 1e-3
+        _, feats = model.swin_unet.forward_up_features(xe, skips)
+        for i, t in enumerate(feats):
+            assert rel_err(t[:, ::13, ::16].cpu(), g[f"feat{i}_sub"]) < 1e-3, i
+    cfg = ICLConfig(num_classes=nc, labeled_bs=2, w_con=50.0, patch_size=(224, 224))
+    tr = ICLTrainer(model, cfg)
+    outs = model(img[:2], img[2:])
+    assert rel_err(outs[0].detach()[:, :, ::8, ::8].cpu(), g["out_lab_sub"]) < 1e-3
+    assert rel_err(outs[1].detach()[:, :, ::8, ::8].cpu(), g["out_unlab_sub"]) < 1e-3
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            st = (1, 2, 4)[i]
+            assert rel_err(t.detach()[:, :, ::st, ::st].cpu(), g[f"{name}{i}_sub"]) < 1e-3, (name, i)
+    loss, parts = tr.compute_loss(outs, lab)
+    got = [float(parts[k].detach()) for k in ("ce", "dice", "aux", "pse", "con")] + [float(loss.detach())]
+    assert np.allclose(got, g["losses"], rtol=0, atol=2e-4), (got, g["losses"])
+    tr.optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    none = [k for k, p in model.named_parameters() if p.grad is None]
+    assert none == list(g["grad_none"])
+    ref = dict(zip(g["grad_norm_keys"], g["grad_norms"]))
+    bad = []
+    for k, p in model.named_parameters():
+        if p.grad is None or ("attn_convs1" in k and k.endswith("bias")):
+            continue
+        got_n = float(p.grad.double().norm())
+        if abs(got_n - ref[k]) > 1e-2 * max(ref[k], 1e-7) + 1e-9:
+            bad.append((k, got_n, ref[k]))
+    assert not bad, bad[:10]
+    sd = dict(model.named_parameters())
+    for k in ("swin_unet.output.weight", "swin_unet.patch_embed.proj.weight", "swin_unet.layers.0.blocks.1.attn.relative_position_bias_table",
+              "swin_unet.layers_up.0.expand.weight", "swin_unet.concat_back_dim.1.weight", "sspa.guided_Q"):
+        gg = sd[k].grad.cpu()
+        gg = gg if gg.numel() <= 8192 else gg.reshape(-1)[::97]
+        assert rel_err(gg, g["grad." + k]) < 1e-2, k
+    tr.optimizer.step()
+    post = np.array([float(p.detach().double().norm()) for _, p in model.named_parameters()])
+    assert np.allclose(post, g["post_sgd_norms"], rtol=1e-4)
+    model.eval()
+    with torch.no_grad():
+        y = model(img[:2], inference=True)
+    assert rel_err(y[:, :, ::8, ::8].cpu(), g["inf_logits_sub"]) < 1e-3
+    # the same first step through the trainer (3136^2 mlp2 weights take the factored-gradient path)
+    model2 = net_factory("icl_swinunet", in_chns=1, class_num=nc)
+    fill_like_reference_init(list(model2.named_parameters()))
+    _parity_mode(model2)
+    model2.train()
+    parts2 = ICLTrainer(model2, cfg).step(img, lab)
+    assert abs(float(parts2["loss"]) - float(g["losses"][5])) < 2e-4
+    post2 = np.array([float(p.detach().double().norm()) for _, p in model2.named_parameters()])
+    assert np.allclose(post2, g["post_sgd_norms"], rtol=1e-4)
+
+
 def test_sliding_window_validation_and_checkpoint_interop(dev):
     """Rows f1 + f3: the on-device batched sliding window reproduces the reference procedure (val_3D.py:15-83) window by
     window; the filtered checkpoint of the ICL model loads into the plain backbone (…BraTS.py:158-162, test_3D_BraTS.py)."""

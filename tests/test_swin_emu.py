@@ -277,3 +277,65 @@ def test_state_dict_keys_match_reference():
     assert list(m.state_dict().keys()) == list(g["keys"])
     assert [k for k, _ in m.named_parameters()] == list(g["param_keys"])
     assert [",".join(map(str, t.shape)) for _, t in m.named_parameters()] == list(g["param_shapes"])
+
+
+# ------------------------------------------------------------------------------------------ 2-D Swin-UNet (row f4)
+def test_swinunet2d_state_dict_keys_match_reference():
+    from conftest import load_golden
+    from icl_amd.networks.vision_transformer import SwinUnet
+    g = load_golden("model_swinunet2d_icl_nc4.npz")
+    m = SwinUnet(None, 224, 4, device="meta")
+    assert list(m.state_dict().keys()) == list(g["keys"])            # incl. attn_mask / relative_position_index buffers
+    assert [k for k, _ in m.named_parameters()] == list(g["param_keys"])
+    assert [",".join(map(str, t.shape)) for _, t in m.named_parameters()] == list(g["param_shapes"])
+    plain = SwinUnet(None, 224, 4, device="meta", icl=False)
+    assert all(k.startswith("swin_unet.") for k in plain.state_dict())
+
+
+def test_swinunet2d_blocks_match_oracle():
+    """Shifted 7x7-window block on a 14^2 token grid (head dim 32, region mask), patch embedding, merging and both patch
+    expansions of the 2-D Swin-UNet against oracle/swinunet2d_oracle.py (the whole 224^2 model is checked on the GPU)."""
+    from icl_amd.networks import swinunet_icl as M
+    from oracle import swinunet2d_oracle as W
+    c, heads, res = 64, 2, 14
+    shapes = W._block_shapes("b.", c, heads)
+    p = O.make_params(shapes, requires_grad=True)
+    p["b.attn.relative_position_index"] = W.relative_position_index()
+    p["b.attn_mask"] = W.attn_mask(res, 7, 3)
+    blk = M.SwinTransformerBlock(c, (res, res), heads, 7, 3)
+    assert torch.equal(blk.attn_mask, p["b.attn_mask"])
+    _load(blk, p, "b.")
+    x = _rand((2, res * res, c), 201)
+    want = W.swin_block(p, "b", x, res, heads, 3)
+    got = blk(x)
+    assert rel_err(got.detach(), want.detach()) < 2e-5
+    gy = _rand(want.shape, 202)
+    (got * gy).sum().backward()
+    (want * gy).sum().backward()
+    for k, t in blk.named_parameters():
+        assert rel_err(t.grad, p["b." + k].grad) < 1e-3, k
+    # patch embed / merging / expansions
+    pe = O.make_params([("patch_embed.proj.weight", (96, 3, 4, 4)), ("patch_embed.proj.bias", (96,)),
+                        ("patch_embed.norm.weight", (96,)), ("patch_embed.norm.bias", (96,)),
+                        ("m.reduction.weight", (32, 64)), ("m.norm.weight", (64,)), ("m.norm.bias", (64,)),
+                        ("e.expand.weight", (64, 32)), ("e.norm.weight", (16,)), ("e.norm.bias", (16,)),
+                        ("u.expand.weight", (256, 16)), ("u.norm.weight", (16,)), ("u.norm.bias", (16,))])
+    with torch.no_grad():
+        emb = M.PatchEmbed(224, 4, 3, 96)
+        _load(emb, pe, "patch_embed.")
+        img = _rand((1, 3, 224, 224), 203)
+        ref = F.conv2d(img, pe["patch_embed.proj.weight"], pe["patch_embed.proj.bias"], stride=4).flatten(2).transpose(1, 2)
+        ref = F.layer_norm(ref, (96,), pe["patch_embed.norm.weight"], pe["patch_embed.norm.bias"])
+        assert rel_err(emb(img), ref) < 1e-5
+        t = _rand((2, 64, 16), 204)
+        mg = M.PatchMerging((8, 8), 16)
+        _load(mg, pe, "m.")
+        assert rel_err(mg(t), W.patch_merging(pe, "m", t, 8)) < 1e-5
+        t2 = _rand((2, 16, 32), 205)
+        ex = M.PatchExpand((4, 4), 32, 2)
+        _load(ex, pe, "e.")
+        assert rel_err(ex(t2), W.patch_expand(pe, "e", t2, 4)) < 1e-5
+        t3 = _rand((2, 16, 16), 206)
+        up = M.PatchExpand((4, 4), 16, 4)
+        _load(up, pe, "u.")
+        assert rel_err(up(t3), W.patch_expand(pe, "u", t3, 4, 4)) < 1e-5
