@@ -7,7 +7,8 @@ Same usage rule as oracle/icl_oracle.py: only tests/, __graft_entry__.smoke() an
 Pinning
   * S1-S4 (window attention, shifted-window block, patch merging, stage wiring), the model wiring and the aligners (S6)
     are the reference's OWN vendored code; tests/golden/make_golden.py --only swin imports it and stores outputs in
-    tests/golden/model_swinunetr_icl_nc2.npz, which tests/test_oracle_golden.py checks this file against.
+    tests/golden/model_swinunetr_icl_64_nc2.npz (64^3 volumes, the vector tests/test_oracle_golden.py checks this file
+    against) and model_swinunetr_icl_nc2.npz (96^3, the BASELINE shape, used by the GPU parity test).
   * S5 — the MONAI 1.0.1 blocks the reference imports (:22-23: MLPBlock, PatchEmbed, UnetrBasicBlock, UnetrUpBlock,
     UnetOutBlock) are a third-party dependency that is NOT in /root/reference and not installed here.  They are
     restated from MONAI 1.0.1's published definitions (monai/networks/blocks/{mlp,patchembedding,dynunet_block,
@@ -267,11 +268,12 @@ def swinunetr_shapes(nc: int, in_ch: int = 1, f: int = FEATURE):
     return out
 
 
-def swinunetr_icl_shapes(nc: int, in_ch: int = 1, f: int = FEATURE):
+def swinunetr_icl_shapes(nc: int, in_ch: int = 1, f: int = FEATURE, res=ICL_RES):
+    """``res``: aligner token grids = (img/16, img/8, img/4) (swinunetr_icl.py:235): (6, 12, 24) for 96^3 volumes."""
     ch = (8 * f, 4 * f, 2 * f)
     return (swinunetr_shapes(nc, in_ch, f)
-            + O.aligner_shapes("sspa.", ch, ICL_RES, nc, ICL_HEADS, q_name="guide_Q")
-            + O.aligner_shapes("uscl.", ch, ICL_RES, nc, ICL_HEADS, q_name="guide_Q"))
+            + O.aligner_shapes("sspa.", ch, res, nc, ICL_HEADS, q_name="guide_Q")
+            + O.aligner_shapes("uscl.", ch, res, nc, ICL_HEADS, q_name="guide_Q"))
 
 
 def swin_buffers(pre: str = "swinViT."):
@@ -280,8 +282,8 @@ def swin_buffers(pre: str = "swinViT."):
             for i in range(4) for b in range(DEPTHS[i])}
 
 
-def make_swin_params(nc: int, requires_grad: bool = False, icl: bool = True) -> P:
-    p = O.make_params(swinunetr_icl_shapes(nc) if icl else swinunetr_shapes(nc), requires_grad=requires_grad)
+def make_swin_params(nc: int, requires_grad: bool = False, icl: bool = True, res=ICL_RES) -> P:
+    p = O.make_params(swinunetr_icl_shapes(nc, res=res) if icl else swinunetr_shapes(nc), requires_grad=requires_grad)
     p.update(swin_buffers())
     if icl:
         p.update(O.aligner_buffers("sspa.", ICL_HEADS))

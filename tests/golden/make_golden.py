@@ -450,11 +450,13 @@ def gen_model2d(R, out, nc=4):
 
 
 # ---------------------------------------------------------------- SwinUNETR-ICL (BASELINE config 4)
-def gen_swin(R, out, nc=2):
+def gen_swin(R, out, nc=2, side=96):
+    """side = 96: the BASELINE configs[3] shape (GPU parity tests); side = 64: the same model class on 64^3 volumes (aligner
+    grids 4^3 / 8^3 / 16^3, 141 M parameters) — the vector the CPU oracle is pinned against in the default test run."""
     install_monai_block_stubs()
     from networks.swinunetr_icl import SwinUNETR_icl
     L = R["losses"]
-    model = SwinUNETR_icl(img_size=(96, 96, 96), in_channels=1, out_channels=nc, feature_size=48, drop_rate=0.0,
+    model = SwinUNETR_icl(img_size=(side, side, side), in_channels=1, out_channels=nc, feature_size=48, drop_rate=0.0,
                           attn_drop_rate=0.0, dropout_path_rate=0.0, use_checkpoint=False)   # net_factory_3d.py:54-63
     parity_mode(model)
     fill(model)
@@ -462,8 +464,8 @@ def gen_swin(R, out, nc=2):
     d["keys"] = np.array(list(model.state_dict().keys()))
     d["param_keys"] = np.array([k for k, _ in model.named_parameters()])
     d["param_shapes"] = np.array([",".join(map(str, p.shape)) for _, p in model.named_parameters()])
-    vol = synthetic_volume((2, 1, 96, 96, 96), 1337)
-    lab = synthetic_labels((1, 96, 96, 96), 4242, nc)
+    vol = synthetic_volume((2, 1, side, side, side), 1337)
+    lab = synthetic_labels((1, side, side, side), 4242, nc)
     model.train()
     with torch.no_grad():
         hs = model.swinViT(vol[:1], True)
@@ -480,8 +482,13 @@ def gen_swin(R, out, nc=2):
     soft = torch.softmax(outs[0], 1)
     l_ce = nn.CrossEntropyLoss()(outs[0], lab)
     l_dice = L.DiceLoss(nc)(soft, lab.unsqueeze(1))
-    l_aux = L.AuxLoss3D(nc)(outs[2], lab)
-    l_pse = L.PseudoSoftLoss3D(nc)(outs[3], outs[1])
+    if side == 96:
+        l_aux = L.AuxLoss3D(nc)(outs[2], lab)
+        l_pse = L.PseudoSoftLoss3D(nc)(outs[3], outs[1])
+    else:   # AuxLoss3D / PseudoSoftLoss3D resize to a hard-coded 96^3 (utils/losses.py:263,292): plain quadratics drive the
+        #     same gradient paths through the aligners here; the losses themselves are pinned by the unit and 96^3 vectors
+        l_aux = sum(t.pow(2).mean() for t in outs[2])
+        l_pse = sum(t.pow(2).mean() for t in outs[3])
     l_con = L.softmax_mse_loss(outs[3], outs[4])
     loss = l_dice + l_ce + l_aux + l_pse + 10 * l_con     # train_inherent_consistent_swinunetr_3D_BraTS.py
     d["losses"] = np.array([float(v.detach()) for v in (l_dice, l_ce, l_aux, l_pse, l_con, loss)])
@@ -508,7 +515,7 @@ def gen_swin(R, out, nc=2):
     with torch.no_grad():
         y = model(vol[:1], inference=True)
     d["inf_logits_sub"] = npy(y)[:, :, ::8, ::8, ::8]
-    np.savez_compressed(os.path.join(out, f"model_swinunetr_icl_nc{nc}.npz"), **d)
+    np.savez_compressed(os.path.join(out, f"model_swinunetr_icl_nc{nc}.npz" if side == 96 else f"model_swinunetr_icl_{side}_nc{nc}.npz"), **d)
     print("swin: losses", d["losses"], "grad_none", len(none), "params", sum(p.numel() for p in model.parameters()))
 
 
@@ -635,5 +642,7 @@ if __name__ == "__main__":
         gen_model2d(R, HERE)
     if a.only in ("all", "swin"):
         gen_swin(R, HERE)
+    if a.only in ("all", "swin64"):
+        gen_swin(R, HERE, side=64)
     if a.only in ("all", "swinunet2d"):
         gen_swinunet2d(R, HERE)

@@ -226,20 +226,25 @@ def test_2d_unet_icl_step_matches_reference():
 
 @pytest.mark.slow
 def test_swinunetr_icl_step_matches_reference():
-    """BASELINE config 4: SwinUNETR-ICL 96^3, nc=2 — hidden states of the vendored Swin
-    encoder, forward 5-tuple, losses, grad-None set, grad norms and one SGD step of the 844 M parameter model.
-    (The five MONAI blocks are a restatement on both sides: "parity unpinned" for row S5, see oracle/swin_oracle.py.)"""
+    """SwinUNETR-ICL, nc=2, on 64^3 volumes (the reference class with img_size 64: token grids 32^3 ..
+    2^3 — padded + shifted and clipped windows —, aligner grids 4^3 / 8^3 / 16^3, 136 M parameters): hidden states of the vendored
+    Swin encoder, forward 5-tuple, grad-None set, gradient norms, sampled gradients, one SGD step and the post-step inference
+    logits.  (The 96^3 BASELINE shape of the same model is checked against its own reference golden on the GPU,
+    tests/test_gpu_parity.py; a 96^3 oracle pass costs 1.5-5 minutes of CPU.)  AuxLoss3D / PseudoSoftLoss3D resize to a
+    hard-coded 96^3, so the golden drives the aligner paths with plain quadratics instead (tests/golden/make_golden.py).
+    The five MONAI blocks are a restatement on both sides: "parity unpinned" for row S5, see oracle/swin_oracle.py."""
     from oracle import swin_oracle as S
-    nc = 2
-    g = load_golden("model_swinunetr_icl_nc2.npz")
-    shapes = S.swinunetr_icl_shapes(nc)
+    nc, side = 2, 64
+    g = load_golden("model_swinunetr_icl_64_nc2.npz")
+    res = (side // 16, side // 8, side // 4)
+    shapes = S.swinunetr_icl_shapes(nc, res=res)
     assert [k for k, _ in shapes] == list(g["param_keys"])
     assert [",".join(map(str, s)) for _, s in shapes] == list(g["param_shapes"])
-    p = S.make_swin_params(nc, requires_grad=True)
+    p = S.make_swin_params(nc, requires_grad=True, res=res)
     # parameters + relative_position_index + BatchNorm running stats
     assert set(p.keys()) == {k for k in g["keys"] if not k.endswith("num_batches_tracked")}
-    vol = synthetic_volume((2, 1, 96, 96, 96), 1337)
-    lab = synthetic_labels((1, 96, 96, 96), 4242, nc)
+    vol = synthetic_volume((2, 1, side, side, side), 1337)
+    lab = synthetic_labels((1, side, side, side), 4242, nc)
     with torch.no_grad():
         hs = S.swin_vit(p, vol[:1])
         for i, h in enumerate(hs):
@@ -251,9 +256,15 @@ def test_swinunetr_icl_step_matches_reference():
     for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
         for i, t in enumerate(lst):
             assert rel_err(t.detach(), g[f"{name}{i}"]) < 2e-4, (name, i)
-    total, parts = O.icl_losses(outs, lab, nc)
-    got = [float(parts[k]) for k in ("dice", "ce", "aux", "pse", "con")] + [float(total)]
-    assert np.allclose(got, g["losses"], rtol=0, atol=1e-5), (got, g["losses"])
+    soft = torch.softmax(outs[0], 1)
+    l_ce = torch.nn.functional.cross_entropy(outs[0], lab)
+    l_dice = O.dice_loss(soft, lab.unsqueeze(1), nc)
+    l_aux = sum(t.pow(2).mean() for t in outs[2])
+    l_pse = sum(t.pow(2).mean() for t in outs[3])
+    l_con = O.softmax_mse_loss(outs[3], outs[4])
+    total = l_dice + l_ce + l_aux + l_pse + 10 * l_con
+    got = [float(v.detach()) for v in (l_dice, l_ce, l_aux, l_pse, l_con, total)]
+    assert np.allclose(got, g["losses"], rtol=0, atol=2e-5), (got, g["losses"])
     total.backward()
     none = [k for k, _ in shapes if p[k].grad is None]
     assert none == list(g["grad_none"])
@@ -266,12 +277,11 @@ def test_swinunetr_icl_step_matches_reference():
         if abs(got_n - r) > 2e-3 * max(r, 1e-7) + 1e-9:
             bad.append((k, got_n, r))
     assert not bad, bad[:10]
-    for k in ("out.conv.conv.weight", "swinViT.patch_embed.proj.weight", "swinViT.layers4.0.blocks.0.attn.qkv.bias"):
-        assert rel_err(p[k].grad, g["grad." + k]) < 2e-4, k
-    assert rel_err(p["swinViT.layers1.0.blocks.1.attn.relative_position_bias_table"].grad.reshape(-1)[::97] if
-                   p["swinViT.layers1.0.blocks.1.attn.relative_position_bias_table"].numel() > 8192 else
-                   p["swinViT.layers1.0.blocks.1.attn.relative_position_bias_table"].grad,
-                   g["grad.swinViT.layers1.0.blocks.1.attn.relative_position_bias_table"]) < 2e-4
+    for k in ("out.conv.conv.weight", "swinViT.patch_embed.proj.weight", "swinViT.layers4.0.blocks.0.attn.qkv.bias",
+              "decoder5.transp_conv.conv.weight", "swinViT.layers1.0.blocks.1.attn.relative_position_bias_table"):
+        gg = p[k].grad
+        gg = gg if gg.numel() <= 8192 else gg.reshape(-1)[::97]
+        assert rel_err(gg, g["grad." + k]) < 2e-4, k
     O.sgd_step(p, {k: p[k].grad for k, _ in shapes}, {}, lr=0.01)
     post = np.array([float(p[k].detach().double().norm()) for k, _ in shapes])
     assert np.allclose(post, g["post_sgd_norms"], rtol=1e-6)
