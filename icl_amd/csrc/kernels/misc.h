@@ -82,6 +82,25 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restr
   }
 }
 
+// ---- row gather: out[b][m][:] = idx[m] >= 0 ? src[b][idx[m]][:] : 0   (rows of C floats, C % 4 == 0).
+// The Swin blocks move tokens between the volume order and the (rolled, zero-padded) window order
+// (zero pad -> torch.roll -> window_partition and window_reverse -> roll back -> crop, networks/swinunetr_icl.py:825-866): both
+// directions, and both of their gradients, are ONE gather with a precomputed index (every token has exactly one window slot;
+// padded slots carry -1) instead of three full-tensor copies each.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ out,
+                                                          long B, long S, long M, int C4) {
+  const long total = B * M * C4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C4);
+    const long r = e / C4;
+    const long m = r % M, b = r / M;
+    const int s = idx[m];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s >= 0) v = reinterpret_cast<const float4*>(src)[(b * S + s) * C4 + c];
+    reinterpret_cast<float4*>(out)[e] = v;
+  }
+}
+
 // ---- im2col / col2im for 3^3 convolutions on TINY volumes (<= 6^3: the 384/768-channel bottleneck blocks of SwinUNETR and the
 // 256-channel centre of the U-Net).  There the convolution is a skinny GEMM that streams up to 64 MB of weights for 27..432
 // output voxels, so it runs as  colsT [N*S, Cin*27] x W[Cout, Cin*27]^T  on the library GEMM; these two kernels only move

@@ -86,6 +86,15 @@ class SwinTransformerBlock(nn.Module):
         if min(self.input_resolution) <= self.window_size:      # :203-206
             self.shift_size = 0
             self.window_size = min(self.input_resolution)
+        h0 = self.input_resolution[0]
+        ids = torch.arange(h0 * h0, dtype=torch.int32).view(1, h0, h0, 1)
+        if self.shift_size > 0:
+            ids = torch.roll(ids, shifts=(-self.shift_size, -self.shift_size), dims=(1, 2))
+        to_win = window_partition(ids, self.window_size).reshape(-1).contiguous()
+        to_tok = torch.empty_like(to_win)
+        to_tok[to_win.long()] = torch.arange(to_win.numel(), dtype=torch.int32)
+        self.register_buffer("_to_win", to_win.to(device), persistent=False)   # roll + window_partition as one row gather
+        self.register_buffer("_to_tok", to_tok.to(device), persistent=False)   # window_reverse + roll back
         attn_mask, regions = None, None
         if self.shift_size > 0:                                  # :222-245
             h = self.input_resolution[0]
@@ -105,14 +114,10 @@ class SwinTransformerBlock(nn.Module):
         h, w = self.input_resolution
         b, l, c = x.shape
         ws, ss = self.window_size, self.shift_size
-        y = self.norm1(x).view(b, h, w, c)
-        if ss > 0:
-            y = torch.roll(y, shifts=(-ss, -ss), dims=(1, 2))
-        win = self.attn(window_partition(y, ws), self._regions if ss > 0 else None)
-        y = window_reverse(win, ws, h, w)
-        if ss > 0:
-            y = torch.roll(y, shifts=(ss, ss), dims=(1, 2))
-        x = x + self.drop_path(y.reshape(b, l, c))
+        win = ops.gather_rows(self.norm1(x), self._to_win, self._to_tok)             # [b, nW*n, c] in window order
+        win = self.attn(win.view(-1, ws * ws, c), self._regions if ss > 0 else None)
+        y = ops.gather_rows(win.view(b, l, c), self._to_tok, self._to_win)
+        x = x + self.drop_path(y)
         return x + self.drop_path(self.mlp(self.norm2(x)))
 
 

@@ -77,6 +77,29 @@ def window_regions(dims, ws, ss, device):
     return _REGION_CACHE[key]
 
 
+_WINDOW_INDEX_CACHE = {}
+
+
+def window_index(dims, ws, ss, device):
+    """(to_windows [nW*n], to_tokens [D*H*W]) int32: slot m of the (zero-padded, rolled by -ss, window-partitioned) order holds
+    token to_windows[m] of the volume (-1 for padding), and token s sits in slot to_tokens[s] — the composition of F.pad,
+    torch.roll and window_partition of swinunetr_icl.py:825-845 (and its inverse :849-866) as one index each."""
+    key = (tuple(dims), tuple(ws), tuple(ss), str(device))
+    if key not in _WINDOW_INDEX_CACHE:
+        d, h, w = dims
+        pd, ph, pw = [(ws[a] - s % ws[a]) % ws[a] for a, s in enumerate(dims)]
+        ids = torch.arange(d * h * w, dtype=torch.int32).view(1, d, h, w, 1)
+        ids = torch.nn.functional.pad(ids, (0, 0, 0, pw, 0, ph, 0, pd), value=-1)
+        if any(s > 0 for s in ss):
+            ids = torch.roll(ids, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+        to_win = window_partition(ids, ws).reshape(-1).contiguous()
+        to_tok = torch.empty(d * h * w, dtype=torch.int32)
+        valid = to_win >= 0
+        to_tok[to_win[valid].long()] = torch.nonzero(valid).squeeze(1).to(torch.int32)
+        _WINDOW_INDEX_CACHE[key] = (to_win.to(device), to_tok.to(device))
+    return _WINDOW_INDEX_CACHE[key]
+
+
 class WindowAttention(nn.Module):
     """swinunetr_icl.py:644-750."""
 
@@ -132,20 +155,13 @@ class SwinTransformerBlock(nn.Module):
         b, d, h, w, c = x.shape
         ws, ss = get_window_size((d, h, w), self.window_size, self.shift_size)
         y = self.norm1(x)
-        pd, ph, pw = [(ws[a] - s % ws[a]) % ws[a] for a, s in enumerate((d, h, w))]
-        if pd or ph or pw:
-            y = torch.nn.functional.pad(y, (0, 0, 0, pw, 0, ph, 0, pd))
-        dims = (b, d + pd, h + ph, w + pw)
         shifted = any(s > 0 for s in ss)
-        if shifted:
-            y = torch.roll(y, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
-        win = self.attn(window_partition(y, ws), regions if shifted else None)
-        y = window_reverse(win, ws, dims)
-        if shifted:
-            y = torch.roll(y, shifts=ss, dims=(1, 2, 3))
-        if pd or ph or pw:
-            y = y[:, :d, :h, :w, :]
-        return y
+        n = ws[0] * ws[1] * ws[2]
+        # pad -> roll -> window_partition as ONE row gather (and window_reverse -> roll -> crop as its inverse)
+        to_win, to_tok = window_index((d, h, w), ws, ss if shifted else (0, 0, 0), x.device)
+        win = ops.gather_rows(y.view(b, d * h * w, c), to_win, to_tok)               # [b, nW*n, c]
+        win = self.attn(win.view(-1, n, c), regions if shifted else None)
+        return ops.gather_rows(win.view(b, -1, c), to_tok, to_win).view(b, d, h, w, c)
 
     def forward(self, x, regions):
         x = x + self.forward_part1(x, regions)

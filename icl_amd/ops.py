@@ -845,6 +845,40 @@ def conv_transpose3d_k2s2(x: torch.Tensor, weight: torch.Tensor, skip: Optional[
     return _DepthToSpaceCat.apply(y, skip, (b, d, h, w, cout))
 
 
+class _GatherRows(torch.autograd.Function):
+    """out[b, m] = src[b, idx[m]] (zero row for idx[m] < 0); ``idx_back`` is the index that undoes it (gradient = gather again)."""
+
+    @staticmethod
+    def forward(ctx, src, idx, idx_back):
+        _require(src, idx, idx_back)
+        L = _lib.lib()
+        src = src.contiguous()
+        b, s, c = src.shape
+        m = idx.shape[0]
+        assert idx_back.shape[0] == s
+        out = torch.empty((b, m, c), dtype=torch.float32, device=src.device)
+        _lib.check(L.icl_gather_rows(_ptr(src), _ptr(idx), _ptr(out), b, s, m, c, _stream(src)), "gather_rows")
+        ctx.save_for_backward(idx, idx_back)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, idx_back = ctx.saved_tensors
+        L = _lib.lib()
+        g = g.contiguous()
+        b, m, c = g.shape
+        s = idx_back.shape[0]
+        gs = torch.empty((b, s, c), dtype=torch.float32, device=g.device)
+        _lib.check(L.icl_gather_rows(_ptr(g), _ptr(idx_back), _ptr(gs), b, m, s, c, _stream(g)), "gather_rows")
+        return gs, None, None
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, idx_back: torch.Tensor) -> torch.Tensor:
+    """src [B, S, C] -> [B, M, C] with out[:, m] = src[:, idx[m]] (zeros where idx[m] < 0).  ``idx`` must reference every source
+    row exactly once (a permutation with optional padding slots) and ``idx_back`` [S] must be its inverse."""
+    return _GatherRows.apply(src, idx, idx_back)
+
+
 class _WindowAttention(torch.autograd.Function):
     """One fused MFMA kernel per direction (csrc/kernels/winattn.h): scores, bias, shift mask, softmax and P@V never leave
     the CU; backward recomputes the scores from the saved log-sum-exp.  The relative-position bias is gathered from the

@@ -125,6 +125,11 @@ int icl_attn_fwd(const float* q, const float* kv, float* logits, float* out, flo
 int icl_attn_bwd(const float* q, const float* kv, const float* logits, const float* stats, const float* out, const float* gout,
                  const float* glog, float* gq, float* gkv, int b, int h, int nc, int n, int d, float scale, void* stream);
 
+/* ---- token <-> window order of the Swin blocks (pad + roll + window_partition, window_reverse + roll + crop:
+ * networks/swinunetr_icl.py:825-866, networks/swinunet_icl.py:256-283): out[b][m][0..c) = idx[m] >= 0 ? src[b][idx[m]][0..c) : 0,
+ * src [b, s, c], out [b, m, c], c % 4 == 0.  The inverse direction and both gradients are gathers with the inverse index. */
+int icl_gather_rows(const float* src, const int32_t* idx, float* out, int64_t b, int64_t s, int64_t m, int c, void* stream);
+
 /* ---- 3^3 convolutions on tiny volumes (<= 6^3 voxels, hundreds of channels: `encoder10`/`decoder5` of SwinUNETR,
  * networks/swinunetr_icl.py:163-183, and the U-Net `center`, networks/unet_3D_icl.py:54) are skinny GEMMs over the weights:
  * cols [n*S, c*27] with cols[b*S+v][ci*27+tap] = x[b][ci][v+offset(tap)] (zero padded), y = cols * W[cout, c*27]^T on the
