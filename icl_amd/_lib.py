@@ -28,6 +28,7 @@ _SIGNATURES = {
     "icl_last_kernel_name": (c_char_p, []),
     "icl_conv3d_packed_elems": (c_int64, [I, I, I, I]),
     "icl_conv3d_pack_weights": (c_int, [P, P, I, I, I, I, P]),
+    "icl_conv3d_pack_weights_both": (c_int, [P, P, P, I, I, I, P]),
     "icl_conv3d_fwd_ws_bytes": (c_int64, [I, I, I, I, I, I, I]),
     "icl_conv3d_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, L, L, P]),
     "icl_conv3d_wgrad_ws_bytes": (c_int64, [I, I, I, I]),
@@ -47,6 +48,7 @@ _SIGNATURES = {
     "icl_dwconv3_fwd": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "icl_dwconv3_wgrad": (c_int, [P, P, P, I, I, I, I, I, P]),
     "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P, P]),
+    "icl_drop_path": (c_int, [P, P, L, L, ctypes.c_uint32, F, P, P]),
     "icl_loss_fwd": (c_int, [P, P, P, P, P, P, I, I, L, I, I, P]),
     "icl_window_attn_bias_elems": (c_int64, [I, I]),
     "icl_depth_to_space2": (c_int, [P, P, I, I, I, I, I, L, P]),

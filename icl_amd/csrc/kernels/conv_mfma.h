@@ -68,6 +68,25 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
   }
 }
 
+// Both packings in one launch (forward layout into wp0, dgrad layout into wp1): a training step needs both of every weight.
+__global__ __launch_bounds__(256) void pack_weights_both_kernel(const float* __restrict__ w, float* __restrict__ wp0, float* __restrict__ wp1,
+                                                                int Cout, int Cin, int T, int KP0, int NP0, int KP1, int NP1) {
+  const long t0 = (long)T * KP0 * NP0, t1 = (long)T * KP1 * NP1;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < t0 + t1; e += (long)gridDim.x * blockDim.x) {
+    const bool dg = e >= t0;
+    const long f = dg ? e - t0 : e;
+    const int NP = dg ? NP1 : NP0, KP = dg ? KP1 : KP0;
+    const int n = (int)(f % NP);
+    const long t = f / NP;
+    const int k = (int)(t % KP);
+    const int tap = (int)(t / KP);
+    const int K = dg ? Cout : Cin, N = dg ? Cin : Cout;
+    float v = 0.f;
+    if (k < K && n < N) v = dg ? w[((long)k * Cin + n) * T + (T - 1 - tap)] : w[((long)n * Cin + k) * T + tap];
+    (dg ? wp1 : wp0)[f] = v;
+  }
+}
+
 // gW[co][ci][tap] = sum over slabs s of gWp[s][tap][ci][co]  (fixed summation order -> reproducible).
 // A workgroup owns 64 consecutive packed elements; its 4 waves take slabs s = wave, wave+4, ... so every slab
 // read is a coalesced 256-byte row, then the four partial sums are combined through LDS in wave order.

@@ -69,9 +69,7 @@ class DropPath(nn.Module):
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
             return x
-        keep = 1.0 - self.drop_prob
-        mask = torch.empty((x.shape[0],) + (1,) * (x.ndim - 1), device=x.device).bernoulli_(keep)
-        return x * (mask / keep)
+        return ops.drop_path(x, self.drop_prob)
 
 
 class MLP(nn.Module):

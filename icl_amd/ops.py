@@ -131,6 +131,17 @@ def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_b
                                     x_bstride, y_bstride, _stream(x)), "conv3d_fwd")
 
 
+_ZERO_CACHE = {}
+
+
+def _cached_zeros(n: int, device) -> torch.Tensor:
+    key = (n, str(device))
+    z = _ZERO_CACHE.get(key)
+    if z is None:
+        z = _ZERO_CACHE[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return z
+
+
 CONV1X1_WGRAD_MIN_VOXELS = 4096
 CONV1X1_GEMM_MIN_VOXELS = 65536
 
@@ -158,7 +169,15 @@ class _Conv3d(torch.autograd.Function):
             y = torch.bmm(wb, x3) if bias is None else torch.baddbmm(bias.view(1, cout, 1), wb, x3)
             return y.view(n, cout, d, h, w)
         y = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
-        wp = pack_weights(weight, 0)
+        ctx.wpt = None
+        if x.requires_grad and torch.is_grad_enabled():
+            # the input gradient will need the flipped/transposed packing too: one launch for both, kept for backward
+            L = _lib.lib()
+            wp = torch.empty(L.icl_conv3d_packed_elems(cout, cin, ks, 0), dtype=torch.float32, device=x.device)
+            ctx.wpt = torch.empty(L.icl_conv3d_packed_elems(cout, cin, ks, 1), dtype=torch.float32, device=x.device)
+            _lib.check(L.icl_conv3d_pack_weights_both(_ptr(weight), _ptr(wp), _ptr(ctx.wpt), cout, cin, ks, _stream(x)), "pack_weights_both")
+        else:
+            wp = pack_weights(weight, 0)
         conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, cin * s, y, cout * s)
         return y
 
@@ -176,7 +195,7 @@ class _Conv3d(torch.autograd.Function):
                 gx = torch.bmm(weight.view(cout, cin).t().unsqueeze(0).expand(n, cin, cout), gy.view(n, cout, s)).view(n, cin, d, h, w)
             else:
                 gx = torch.empty_like(x)
-                wpt = pack_weights(weight, 1)
+                wpt = ctx.wpt if ctx.wpt is not None else pack_weights(weight, 1)
                 conv3d_forward_raw(gy, wpt, None, n, cout, cin, d, h, w, ks, cout * s, gx, cin * s)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw = torch.empty_like(weight)
@@ -184,8 +203,9 @@ class _Conv3d(torch.autograd.Function):
             gb_arg = gb
             if ctx.has_bias and ctx.zero_bias_grad:
                 # the conv feeds an InstanceNorm: its output is invariant to the bias, so dL/dbias == 0 exactly
-                # (the reference holds ~1e-8 rounding noise there); skip the reduction pass over dY.
-                gb.zero_()
+                # (the reference holds ~1e-8 rounding noise there); skip the reduction pass over dY.  The zero vector is a
+                # cached constant (nothing ever writes a non-zero into it), not a fill kernel per layer and step.
+                gb = _cached_zeros(cout, x.device)
                 gb_arg = None
             flops = 2.0 * ks ** 3 * cin * cout * s * n
             nbytes = 4.0 * (n * s * (cin + cout) + 2 * ks ** 3 * cin * cout)
@@ -575,24 +595,24 @@ class StepRNG:
 
 class _Dropout(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, seed, seed_dev):
+    def forward(ctx, x, p, seed, seed_dev, group=1):
         _require(x)
         L = _lib.lib()
         x = x.contiguous()
         y = torch.empty_like(x)
-        _lib.check(L.icl_dropout(_ptr(x), _ptr(y), x.numel(), seed, p, _ptr(seed_dev), _stream(x)), "dropout")
-        ctx.cfg = (p, seed)
+        _lib.check(L.icl_drop_path(_ptr(x), _ptr(y), x.numel(), group, seed, p, _ptr(seed_dev), _stream(x)), "dropout")
+        ctx.cfg = (p, seed, group)
         ctx.seed_dev = seed_dev
         return y
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.lib()
-        p, seed = ctx.cfg
+        p, seed, group = ctx.cfg
         gy = gy.contiguous()
         gx = torch.empty_like(gy)
-        _lib.check(L.icl_dropout(_ptr(gy), _ptr(gx), gy.numel(), seed, p, _ptr(ctx.seed_dev), _stream(gy)), "dropout_bwd")
-        return gx, None, None, None
+        _lib.check(L.icl_drop_path(_ptr(gy), _ptr(gx), gy.numel(), group, seed, p, _ptr(ctx.seed_dev), _stream(gy)), "dropout_bwd")
+        return gx, None, None, None, None
 
 
 def dropout(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Tensor:
@@ -607,6 +627,20 @@ def dropout(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Tens
         else:
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
     return _Dropout.apply(x, float(p), int(seed) & 0xFFFFFFFF, seed_dev)
+
+
+def drop_path(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Tensor:
+    """Per-sample stochastic depth (timm / MONAI DropPath): each sample of the batch keeps its branch with probability 1-p (scaled
+    by 1/(1-p)) or drops it entirely — one kernel instead of empty + bernoulli_ + div + mul; same seeding scheme as ``dropout``."""
+    seed_dev = None
+    if seed is None:
+        if StepRNG.tensor is not None and StepRNG.tensor.device == x.device:
+            seed = 0x2545F491 + 7919 * StepRNG.calls
+            StepRNG.calls += 1
+            seed_dev = StepRNG.tensor
+        else:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return _Dropout.apply(x, float(p), int(seed) & 0xFFFFFFFF, seed_dev, x.numel() // x.shape[0])
 
 
 # --------------------------------------------------------------------------------------
@@ -755,8 +789,10 @@ class _LayerNorm(torch.autograd.Function):
         c = x.shape[-1]
         rows = x.numel() // c
         gx = torch.empty_like(x)
-        dg = torch.empty_like(weight) if weight is not None else None   # no-affine: F.layer_norm(x, [C]) (swinunetr_icl.py:1214)
-        db = torch.empty_like(weight) if weight is not None else None
+        dg = db = None       # no-affine: F.layer_norm(x, [C]) (swinunetr_icl.py:1214)
+        if weight is not None:
+            dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)   # [dgamma | dbeta] contiguous: zeroed by one memset
+            dg, db = dgb[0], dgb[1]
         _lib.check(L.icl_layernorm_bwd(_ptr(gy), _ptr(x), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dg), _ptr(db), rows, c,
                                        _stream(x)), "layernorm_bwd")
         return gx, dg, db, None

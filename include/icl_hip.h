@@ -30,6 +30,8 @@ const char* icl_last_kernel_name(void);
  * with taps flipped.  KP = round_up(K,4), NP = round_up(N,16). */
 int64_t icl_conv3d_packed_elems(int cout, int cin, int ks, int mode);
 int icl_conv3d_pack_weights(const float* w, float* wp, int cout, int cin, int ks, int mode, void* stream);
+/* both packings (mode 0 into wp_fwd, mode 1 into wp_dgrad) in one launch — a training step needs both of every weight */
+int icl_conv3d_pack_weights_both(const float* w, float* wp_fwd, float* wp_dgrad, int cout, int cin, int ks, void* stream);
 /* y[n, 0:cout] = conv(x[n, 0:cin], Wp) + bias (bias may be NULL).  dgrad: call with Wp packed in mode 1,
  * x = dY, cin/cout swapped, bias NULL.  Batch strides in elements; channel stride is D*H*W.
  * ws: icl_conv3d_fwd_ws_bytes(...) bytes (0 for most shapes): launches with too few output tiles to fill the chip
@@ -93,6 +95,9 @@ int icl_dwconv3_wgrad(const float* x, const float* gy, float* gw, int n, int c, 
  * mask keyed by (seed, element index); calling it again with the same seed on dY is the backward.  seed_dev (may be
  * NULL) is a device-resident counter folded into the seed so that replays of a captured hipGraph draw fresh masks. */
 int icl_dropout(const float* x, float* y, int64_t n, uint32_t seed, float p, const uint32_t* seed_dev, void* stream);
+/* DropPath / stochastic depth (timm, MONAI; networks/unet_3D_icl.py:253, swinunet_icl.py:215): one keep/drop decision per `group`
+ * consecutive elements (group = elements per sample), kept samples scaled by 1/(1-p).  Same counter-based mask as icl_dropout. */
+int icl_drop_path(const float* x, float* y, int64_t n, int64_t group, uint32_t seed, float p, const uint32_t* seed_dev, void* stream);
 
 /* ---- fused softmax + Dice / CE / soft-Dice / MSE reductions (utils/losses.py:22-59,68-90,200-231 and the
  * CrossEntropyLoss at train_inherent_consistent_unet_3D_BraTS.py:107).  a is [B,nc,S] logits (or probabilities when

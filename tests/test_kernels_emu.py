@@ -214,6 +214,18 @@ def test_depthwise_and_dropout():
     assert torch.equal(xo.grad != 0, yo.detach() != 0)
 
 
+def test_drop_path_is_per_sample_and_consistent_in_backward():
+    x = torch.ones(256, 3, 5, requires_grad=True)
+    y = ops.drop_path(x, 0.25, seed=77)
+    flat = y.detach().reshape(256, -1)
+    assert bool((flat.max(dim=1).values == flat.min(dim=1).values).all())          # one decision per sample
+    kept = flat[:, 0] != 0
+    assert 0.65 < float(kept.float().mean()) < 0.85 and abs(float(flat[kept][0, 0]) - 1 / 0.75) < 1e-6
+    y.sum().backward()
+    assert torch.equal(x.grad != 0, y.detach() != 0)                               # same mask in backward
+    assert not torch.equal(ops.drop_path(x.detach(), 0.25, seed=78) != 0, y.detach() != 0)
+
+
 def test_fused_sgd_matches_torch():
     from icl_amd.optim import FusedSGD
     torch.manual_seed(0)
