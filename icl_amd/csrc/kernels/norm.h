@@ -7,8 +7,8 @@
 // A tensor is R = N*C rows of S contiguous floats.  Row r belongs to group r (instance norm)
 // or r % C (batch norm).  All kernels are HBM-bound: rows are cut into chunks of kChunk
 // elements so that even R = 16 rows (the 96^3 layers) fill the chip with workgroups.
-//   forward : stats pass (read x) -> finalize (tiny) -> apply pass (read x, write y)
-//   backward: partial sums pass (read gy, x) -> group reduce (tiny) -> apply (read gy, x, write gx)
+//   forward : stats pass (read x) -> apply pass (merges the chunk summaries of its group, reads x, writes y)
+//   backward: partial sums pass (read gy, x) -> apply (merges the partial sums of its group, reads gy, x, writes gx)
 // Algorithmic HBM bytes per element: 12 B forward, 20 B backward.
 #pragma once
 
@@ -61,57 +61,71 @@ __global__ __launch_bounds__(kNormThreads) void rowstats_partial_kernel(
   }
 }
 
-// One WAVE per group: lanes merge the chunk summaries of every row in the group, then a shuffle tree.
-// groups = R (instance) or C (batch).  Optionally updates BatchNorm running stats.  grid = ceil(groups/4), block 256.
-__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean,
-                                                             float* __restrict__ rstd, int R, int C, int nchunks, int batch_mode,
-                                                             float eps, float* running_mean, float* running_var, float momentum) {
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int groups = batch_mode ? C : R;
-  if (g >= groups) return;
-  float n = 0.f, m = 0.f, q = 0.f;
-  const int step = batch_mode ? C : R;
-  const int nrows = (R - g + step - 1) / step;
-  const long items = (long)nrows * nchunks;
-  for (long it = lane; it < items; it += 64) {
-    const int r = g + (int)(it / nchunks) * step;
-    const float* p = part + ((long)r * nchunks + it % nchunks) * 3;
-    welford_merge(n, m, q, p[0], p[1], p[2]);
-  }
-#pragma unroll
-  for (int sh = 32; sh >= 1; sh >>= 1) {
-    const float nb = __shfl_xor(n, sh, 64), mb = __shfl_xor(m, sh, 64), qb = __shfl_xor(q, sh, 64);
-    welford_merge(n, m, q, nb, mb, qb);
-  }
-  if (lane != 0) return;
-  const float var = q / n;  // biased, as the normalisation uses
-  mean[g] = m;
-  rstd[g] = 1.0f / sqrtf(var + eps);
-  if (running_mean) {
-    const float unbiased = n > 1.f ? q / (n - 1.f) : var;
-    running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * m;
-    running_var[g] = (1.f - momentum) * running_var[g] + momentum * unbiased;
-  }
-}
-
 // rstd from given variances (eval-mode BatchNorm): rstd[c] = 1/sqrt(var[c]+eps)
 __global__ void rstd_from_var_kernel(const float* __restrict__ var, float* __restrict__ rstd, int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) rstd[c] = 1.0f / sqrtf(var[c] + eps);
 }
 
+// Group statistics from the (count, mean, M2) chunk summaries, computed by EVERY workgroup that needs them (the summaries of a
+// group are a few hundred floats): wave 0 merges them, LDS broadcasts the result.  Saves a separate finalize launch per
+// normalisation layer (66 launches per U-Net step).  Returns (mean, M2/n, n) of group g in all threads.
+__device__ __forceinline__ void norm_group_stats(const float* __restrict__ part, int g, int R, int C, int nchunks, int batch_mode,
+                                                 float& mean_out, float& var_out, float& n_out) {
+  __shared__ float bc[3];
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    float n = 0.f, m = 0.f, q = 0.f;
+    const int step = batch_mode ? C : R;
+    const int nrows = (R - g + step - 1) / step;
+    const long items = (long)nrows * nchunks;
+    for (long it = lane; it < items; it += 64) {
+      const int r = g + (int)(it / nchunks) * step;
+      const float* p = part + ((long)r * nchunks + it % nchunks) * 3;
+      welford_merge(n, m, q, p[0], p[1], p[2]);
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+      const float nb = __shfl_xor(n, sh, 64), mb = __shfl_xor(m, sh, 64), qb = __shfl_xor(q, sh, 64);
+      welford_merge(n, m, q, nb, mb, qb);
+    }
+    if (lane == 0) { bc[0] = m; bc[1] = q / n; bc[2] = n; }
+  }
+  __syncthreads();
+  mean_out = bc[0]; var_out = bc[1]; n_out = bc[2];
+}
+
 // y = act(((x-mean[g])*rstd[g]) * gamma[c] + beta[c] [+ res]); act 0 = identity, 1 = ReLU, 2 = LeakyReLU(0.01)
 // (nn.LeakyReLU default).  `res` (optional, same shape as x) is the residual branch of MONAI's UnetResBlock:
 // lrelu(norm2(conv2(.)) + residual) in one pass.   grid (nchunks, R)
+// part != nullptr: batch statistics — merged here from the chunk summaries; the first workgroup of a group stores mean / rstd
+// for the backward pass and updates the BatchNorm running statistics.
 __global__ __launch_bounds__(kNormThreads) void norm_act_fwd_kernel(
-    const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
-    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    long S, int C, int batch_mode, int act, const float* __restrict__ res) {
+    const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mean,
+    float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    long S, int C, int batch_mode, int act, const float* __restrict__ res, const float* __restrict__ part, int R, int nchunks,
+    float eps, float* running_mean, float* running_var, float momentum) {
   const long r = blockIdx.y;
   const int c = (int)(r % C);
   const int g = batch_mode ? c : (int)r;
-  const float m = mean[g], rs = rstd[g];
+  float m, rs;
+  if (part) {
+    float var, n;
+    norm_group_stats(part, g, R, C, nchunks, batch_mode, m, var, n);
+    rs = 1.0f / sqrtf(var + eps);
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (!batch_mode || r < C)) {
+      mean[g] = m;
+      rstd[g] = rs;
+      if (running_mean) {
+        const float unbiased = n > 1.f ? var * n / (n - 1.f) : var;
+        running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * m;
+        running_var[g] = (1.f - momentum) * running_var[g] + momentum * unbiased;
+      }
+    }
+  } else {
+    m = mean[g];
+    rs = rstd[g];
+  }
   const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   const float sc = rs * ga, sh = be - m * rs * ga;
   const long lo = (long)blockIdx.x * kNormChunk;
@@ -172,38 +186,43 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_partial_kernel(
   }
 }
 
-// One thread per group: P1/P2 over all rows+chunks of the group -> gsum[g*2..]; optional dgamma/dbeta
-// (per channel, summed over the batch as well when instance mode has affine — unused by the reference).
-__global__ void norm_bwd_group_reduce_kernel(const float* __restrict__ part, float* __restrict__ gsum,
-                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int C,
-                                             int nchunks, int batch_mode) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const int groups = batch_mode ? C : R;
-  if (g >= groups) return;
-  const int step = batch_mode ? C : R;
-  float p1 = 0.f, p2 = 0.f;
-  for (int r = g; r < R; r += step) {
-    const float* p = part + (long)r * nchunks * 2;
-    for (int ch = 0; ch < nchunks; ++ch) { p1 += p[ch * 2]; p2 += p[ch * 2 + 1]; }
-  }
-  gsum[g * 2] = p1;
-  gsum[g * 2 + 1] = p2;
-  if (batch_mode && dgamma) { dgamma[g] = p2; dbeta[g] = p1; }
-}
-
-// gx = rstd*gamma*(h - (P1 + xhat*P2)/M)   (batch statistics)   or   rstd*gamma*h   (fixed statistics);  gres = h
+// gx = rstd*gamma*(h - (P1 + xhat*P2)/M)   (batch statistics)   or   rstd*gamma*h   (fixed statistics);  gres = h.
+// P1 / P2 of the group are summed here from the per-(row, chunk) partials of norm_act_bwd_partial_kernel (every workgroup of the
+// group does it: a few hundred floats; no separate reduction launch); the first workgroup of a channel also stores
+// dgamma = P2, dbeta = P1 in batch mode.
 __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_apply_kernel(
     const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ gsum, float* __restrict__ gx, long S, int C, int batch_mode, int act,
-    float inv_count, int use_batch_stats, const float* __restrict__ res, float* __restrict__ gres) {
+    const float* __restrict__ part, float* __restrict__ gx, long S, int C, int batch_mode, int act,
+    float inv_count, int use_batch_stats, const float* __restrict__ res, float* __restrict__ gres, int R, int nchunks,
+    float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const long r = blockIdx.y;
   const int c = (int)(r % C);
   const int g = batch_mode ? c : (int)r;
+  __shared__ float bc[2];
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const int step = batch_mode ? C : R;
+    const int nrows = (R - g + step - 1) / step;
+    const long items = (long)nrows * nchunks;
+    float p1 = 0.f, p2 = 0.f;
+    for (long it = lane; it < items; it += 64) {
+      const int rr_ = g + (int)(it / nchunks) * step;
+      const float* p = part + ((long)rr_ * nchunks + it % nchunks) * 2;
+      p1 += p[0];
+      p2 += p[1];
+    }
+    p1 = wave_sum(p1);
+    p2 = wave_sum(p2);
+    if (lane == 0) { bc[0] = p1; bc[1] = p2; }
+  }
+  __syncthreads();
+  const float P1 = bc[0], P2 = bc[1];
+  if (batch_mode && dgamma && threadIdx.x == 0 && blockIdx.x == 0 && r < C) { dgamma[g] = P2; dbeta[g] = P1; }
   const float m = mean[g], rs = rstd[g];
   const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-  const float a1 = use_batch_stats ? gsum[g * 2] * inv_count : 0.f;
-  const float a2 = use_batch_stats ? gsum[g * 2 + 1] * inv_count : 0.f;
+  const float a1 = use_batch_stats ? P1 * inv_count : 0.f;
+  const float a2 = use_batch_stats ? P2 * inv_count : 0.f;
   const float k = rs * ga;
   const long lo = (long)blockIdx.x * kNormChunk;
   const long hi = (lo + kNormChunk < S) ? lo + kNormChunk : S;
