@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from icl_amd.networks import swinunetr as SW  # noqa: E402
 from icl_amd.utils.hashfill import synthetic_volume  # noqa: E402
 from oracle import swin_oracle as S  # noqa: E402

@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from icl_amd.networks.swinunetr_icl import SwinUNETR_icl  # noqa: E402
 from icl_amd.networks.aligner import DropPath  # noqa: E402
 from icl_amd.trainer import ICLConfig, ICLTrainer  # noqa: E402
