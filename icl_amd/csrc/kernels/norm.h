@@ -27,13 +27,25 @@ __global__ __launch_bounds__(kNormThreads) void rowstats_partial_kernel(
   const float* xr = x + r * S;
   // shifted sums per thread (shift = first element seen) -> (n, mean, M2)
   float n = 0.f, shift = 0.f, s1 = 0.f, s2 = 0.f;
-  for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
-    const float v = xr[i];
-    if (n == 0.f) shift = v;
-    const float d = v - shift;
-    s1 += d;
-    s2 += d * d;
-    n += 1.f;
+  if ((S & 3) == 0) {   // 16 bytes per lane (chunk bounds are multiples of 4)
+    const float4* x4 = reinterpret_cast<const float4*>(xr);
+    for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += kNormThreads) {
+      const float4 v = x4[i];
+      if (n == 0.f) shift = v.x;
+      const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+      s1 += (d0 + d1) + (d2 + d3);
+      s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      n += 4.f;
+    }
+  } else {
+    for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
+      const float v = xr[i];
+      if (n == 0.f) shift = v;
+      const float d = v - shift;
+      s1 += d;
+      s2 += d * d;
+      n += 1.f;
+    }
   }
   float mean = 0.f, m2 = 0.f;
   if (n > 0.f) {
@@ -170,12 +182,31 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_partial_kernel(
   const float* gr = gy + r * S;
   const float* rr = res ? res + r * S : nullptr;
   float p1 = 0.f, p2 = 0.f;
-  for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
-    const float xh = (xr[i] - m) * rs;
-    float h = gr[i];
-    if (act && !(xh * ga + be + (rr ? rr[i] : 0.f) > 0.f)) h = (act == 2) ? 0.01f * h : 0.f;
-    p1 += h;
-    p2 += h * xh;
+  if ((S & 3) == 0) {   // 16 bytes per lane
+    const float4* x4 = reinterpret_cast<const float4*>(xr);
+    const float4* g4 = reinterpret_cast<const float4*>(gr);
+    const float4* r4 = reinterpret_cast<const float4*>(rr);
+    for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += kNormThreads) {
+      const float4 xv = x4[i], gv = g4[i];
+      const float4 rv = rr ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, rs4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (xs[k] - m) * rs;
+        float h = gs[k];
+        if (act && !(xh * ga + be + rs4[k] > 0.f)) h = (act == 2) ? 0.01f * h : 0.f;
+        p1 += h;
+        p2 += h * xh;
+      }
+    }
+  } else {
+    for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
+      const float xh = (xr[i] - m) * rs;
+      float h = gr[i];
+      if (act && !(xh * ga + be + (rr ? rr[i] : 0.f) > 0.f)) h = (act == 2) ? 0.01f * h : 0.f;
+      p1 += h;
+      p2 += h * xh;
+    }
   }
   __shared__ float red[kNormThreads / 64];
   p1 = block_sum<kNormThreads>(p1, red);
@@ -231,6 +262,30 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_apply_kernel(
   float* o = gx + r * S;
   const float* rr = res ? res + r * S : nullptr;
   float* go = gres ? gres + r * S : nullptr;
+  if ((S & 3) == 0) {   // 16 bytes per lane
+    const float4* x4 = reinterpret_cast<const float4*>(xr);
+    const float4* g4 = reinterpret_cast<const float4*>(gr);
+    const float4* r4 = reinterpret_cast<const float4*>(rr);
+    float4* o4 = reinterpret_cast<float4*>(o);
+    float4* go4 = reinterpret_cast<float4*>(go);
+    for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += kNormThreads) {
+      const float4 xv = x4[i], gv = g4[i];
+      const float4 rv = rr ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, rs4[4] = {rv.x, rv.y, rv.z, rv.w};
+      float ov[4], hv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = (xs[q] - m) * rs;
+        float h = gs[q];
+        if (act && !(xh * ga + be + rs4[q] > 0.f)) h = (act == 2) ? 0.01f * h : 0.f;
+        ov[q] = k * (h - a1 - xh * a2);
+        hv[q] = h;
+      }
+      o4[i] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      if (go) go4[i] = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    }
+    return;
+  }
   for (long i = lo + threadIdx.x; i < hi; i += kNormThreads) {
     const float xh = (xr[i] - m) * rs;
     float h = gr[i];
