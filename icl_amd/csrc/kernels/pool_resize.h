@@ -103,6 +103,41 @@ __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restr
   }
 }
 
+// Same interpolation, four adjacent ox per thread (Wo % 4 == 0, 16-byte aligned rows) and 32-bit index
+// arithmetic (host guarantees the quad count fits): the scalar kernel above spends most of its time in the
+// five 64-bit div/mod pairs per output voxel, here they are five 32-bit ones per four voxels and the store
+// is one float4.
+__global__ __launch_bounds__(256) void trilinear_fwd_quad_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C,
+                                                                 int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                                                 float rz, float ry, float rx, long y_bstride, int align) {
+  const unsigned wq = (unsigned)Wo >> 2;
+  const unsigned total = (unsigned)N * C * Do * Ho * wq;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const unsigned xq = e % wq;
+    unsigned t = e / wq;
+    const int oy = (int)(t % (unsigned)Ho);
+    t /= (unsigned)Ho;
+    const int oz = (int)(t % (unsigned)Do);
+    t /= (unsigned)Do;
+    const int c = (int)(t % (unsigned)C);
+    const int n = (int)(t / (unsigned)C);
+    const LinTap tz = lin_tap(oz, rz, Di, align), ty = lin_tap(oy, ry, Hi, align);
+    const float* p = x + ((long)n * C + c) * Di * Hi * Wi;
+    const float* p00 = p + (long)tz.i0 * Hi * Wi + (long)ty.i0 * Wi;
+    const float* p01 = p + (long)tz.i0 * Hi * Wi + (long)ty.i1 * Wi;
+    const float* p10 = p + (long)tz.i1 * Hi * Wi + (long)ty.i0 * Wi;
+    const float* p11 = p + (long)tz.i1 * Hi * Wi + (long)ty.i1 * Wi;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const LinTap tx = lin_tap((int)(xq * 4) + k, rx, Wi, align);
+      v[k] = tz.l0 * (ty.l0 * (tx.l0 * p00[tx.i0] + tx.l1 * p00[tx.i1]) + ty.l1 * (tx.l0 * p01[tx.i0] + tx.l1 * p01[tx.i1])) +
+             tz.l1 * (ty.l0 * (tx.l0 * p10[tx.i0] + tx.l1 * p10[tx.i1]) + ty.l1 * (tx.l0 * p11[tx.i0] + tx.l1 * p11[tx.i1]));
+    }
+    *reinterpret_cast<float4*>(y + (long)n * y_bstride + (((long)c * Do + oz) * Ho + oy) * Wo + xq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 // weight with which output index o contributes to input index i along one axis (exact transpose of lin_tap)
 __device__ __forceinline__ float lin_w(int o, int i, float rscale, int in_size, int align) {
   const LinTap t = lin_tap(o, rscale, in_size, align);
@@ -150,6 +185,64 @@ __global__ __launch_bounds__(256) void resize_bwd_axis_kernel(const float* __res
       if (w != 0.f) acc += w * p[(long)o * inner];
     }
     dst[e] = acc;
+  }
+}
+
+// resize_bwd_axis for the y / z passes (inner % 4 == 0, aligned): four adjacent t per thread share the taps,
+// 16-byte loads and stores, 32-bit index arithmetic (host guarantees the quad count fits).
+__global__ __launch_bounds__(256) void resize_bwd_axis_t4_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, unsigned rows,
+                                                                 int Li, int Lo, unsigned inner4, float rscale, long src_bstride, int align) {
+  const unsigned total = (unsigned)B * rows * Li * inner4;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const unsigned t4 = e % inner4;
+    unsigned r = e / inner4;
+    const int i = (int)(r % (unsigned)Li);
+    r /= (unsigned)Li;
+    const unsigned row = r % rows;
+    const unsigned b = r / rows;
+    int lo, hi;
+    lin_range(i, rscale, Lo, align, lo, hi);
+    const float4* p = reinterpret_cast<const float4*>(src + (long)b * src_bstride + ((long)row * Lo) * inner4 * 4) + t4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int o = lo; o <= hi; ++o) {
+      const float w = lin_w(o, i, rscale, Li, align);
+      if (w != 0.f) {
+        const float4 v = p[(long)o * inner4];
+        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+      }
+    }
+    reinterpret_cast<float4*>(dst)[e] = acc;
+  }
+}
+
+// resize_bwd_axis for the x pass (inner == 1, Li % 4 == 0): four adjacent i per thread walk the union of their
+// source ranges once, computing each source tap once; one float4 store.
+__global__ __launch_bounds__(256) void resize_bwd_axis_i4_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, unsigned rows,
+                                                                 int Li, int Lo, float rscale, long src_bstride, int align) {
+  const unsigned li4 = (unsigned)Li >> 2;
+  const unsigned total = (unsigned)B * rows * li4;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const unsigned iq = e % li4;
+    const unsigned r = e / li4;
+    const unsigned row = r % rows;
+    const unsigned b = r / rows;
+    const int i = (int)(iq * 4);
+    int lo, hi, lo3, hi3;
+    lin_range(i, rscale, Lo, align, lo, hi);
+    lin_range(i + 3, rscale, Lo, align, lo3, hi3);  // both ends are monotone in i: the union is [lo, hi3]
+    (void)hi; (void)lo3;
+    const float* p = src + (long)b * src_bstride + (long)row * Lo;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int o = lo; o <= hi3; ++o) {
+      const LinTap t = lin_tap(o, rscale, Li, align);
+      const float v = p[o];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float w = (t.i0 == i + k ? t.l0 : 0.f) + (t.i1 == i + k ? t.l1 : 0.f);
+        if (w != 0.f) acc[k] += w * v;
+      }
+    }
+    reinterpret_cast<float4*>(dst)[e] = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
 }
 

@@ -119,7 +119,8 @@ def test_maxpool_ties_and_grad():
     assert torch.equal(x.grad, xr.grad)
 
 
-@pytest.mark.parametrize("ins,outs", [((3, 4, 5), (6, 8, 10)), ((2, 2, 2), (12, 12, 12)), ((6, 6, 6), (24, 24, 24))])
+@pytest.mark.parametrize("ins,outs", [((3, 4, 5), (6, 8, 10)), ((2, 2, 2), (12, 12, 12)), ((6, 6, 6), (24, 24, 24)),
+                                      ((4, 4, 8), (8, 12, 16)), ((5, 3, 12), (7, 6, 20))])
 def test_trilinear(ins, outs):
     x = _rand((2, 2) + ins, 15, True)
     y = ops.trilinear_resize(x, outs)
