@@ -54,6 +54,7 @@ _SIGNATURES = {
     "icl_depth_to_space2": (c_int, [P, P, I, I, I, I, I, L, P]),
     "icl_space_to_depth2": (c_int, [P, P, I, I, I, I, I, L, P]),
     "icl_gather_rows": (c_int, [P, P, P, L, L, L, I, P]),
+    "icl_gather_rows_sum2": (c_int, [P, P, P, L, L, L, I, P]),
     "icl_im2col3": (c_int, [P, P, I, I, I, I, I, P]),
     "icl_col2im3": (c_int, [P, P, I, I, I, I, I, P]),
     "icl_linear_wgrad_ws_bytes": (c_int64, [L, I, I]),

@@ -33,10 +33,10 @@ __device__ __forceinline__ void softmax_vec(float* v, int nc, float& lse) {
   lse = m + logf(s);
 }
 
-// grid-stride over the B*S voxels; stats (3*nc+1 floats, pre-zeroed) accumulated with one atomic per block per slot
+// grid-stride over the B*S voxels; every block writes its 3*nc+1 partial sums to part[blockIdx.x][...]
 template <int NCMAX>
 __global__ __launch_bounds__(256) void loss_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                         const long long* __restrict__ labels, float* __restrict__ stats,
+                                                         const long long* __restrict__ labels, float* __restrict__ part,
                                                          int B, int nc, long S, int a_is_prob) {
   float s0[NCMAX], s1[NCMAX], s2[NCMAX];
   float sx = 0.f;
@@ -104,15 +104,26 @@ __global__ __launch_bounds__(256) void loss_stats_kernel(const float* __restrict
     if (t == 3 * NCMAX || c < nc) {
       const float v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
       const int slot = (t == 3 * NCMAX) ? 3 * nc : grp * nc + c;
-      atomicAdd(stats + slot, v);
+      part[(long)blockIdx.x * (3 * nc + 1) + slot] = v;
     }
   }
 }
 
-// out[0], out[1] from stats (one thread).  weight may be NULL.
-__global__ void loss_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ weight, float* __restrict__ out,
-                                     int nc, float inv_vox, float inv_elems, int mode) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// One block: stats[slot] = sum over the nblk per-block partials in a fixed order (bit-reproducible, no atomics, nothing to
+// pre-zero), then out[0], out[1] from the reduced stats.  weight may be NULL.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ stats,
+                                                            const float* __restrict__ weight, float* __restrict__ out, int nc,
+                                                            float inv_vox, float inv_elems, int mode) {
+  const int nslot = 3 * nc + 1;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int slot = wid; slot < nslot; slot += 4) {
+    float v = 0.f;
+    for (int b = lane; b < nblk; b += 64) v += part[(long)b * nslot + slot];
+    v = wave_sum(v);
+    if (lane == 0) stats[slot] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   float dice = 0.f;
   for (int c = 0; c < nc; ++c) {
     const float num = 2.f * stats[c] + kDiceEps;
@@ -123,37 +134,30 @@ __global__ void loss_finalize_kernel(const float* __restrict__ stats, const floa
   out[0] = (mode == 1) ? stats[3 * nc] * inv_vox : (mode == 3 ? stats[3 * nc] * inv_elems : 0.f);
 }
 
-// coef = [alpha_c | beta_c | gamma_c | kappa]:  dL/dp_c(v) = alpha_c*T_c(v) + beta_c*p_c(v) + gamma_c, T = one-hot | q;
-// kappa scales the cross-entropy logit gradient (p - t).  g = upstream grads of (out[0], out[1]).
-__global__ void loss_coef_kernel(const float* __restrict__ stats, const float* __restrict__ weight, const float* __restrict__ g,
-                                 float* __restrict__ coef, int nc, float inv_vox, float inv_elems, int mode) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  const float g0 = g[0], g1 = g[1];
-  for (int c = 0; c < nc; ++c) {
-    const float num = 2.f * stats[c] + kDiceEps;
-    const float den = stats[nc + c] + stats[2 * nc + c] + kDiceEps;
-    const float w = (weight ? weight[c] : 1.f) * g1 / (float)nc;
-    float al = 0.f, be = 0.f, ga = 0.f;
-    if (mode == 0 || mode == 1) { al = -2.f * w / den; be = 2.f * w * num / (den * den); }
-    else if (mode == 2) { al = -2.f * w / den; ga = w * num / (den * den); }
-    else { al = -2.f * g0 * inv_elems; be = 2.f * g0 * inv_elems; }
-    coef[c] = al; coef[nc + c] = be; coef[2 * nc + c] = ga;
-  }
-  coef[3 * nc] = (mode == 1) ? g0 * inv_vox : 0.f;
-}
-
+// Per-class coefficients of the gradient, recomputed by every thread from the (3*nc+1) reduced statistics:
+//   dL/dp_c(v) = alpha_c*T_c(v) + beta_c*p_c(v) + gamma_c, T = one-hot | q;  kappa scales the cross-entropy logit gradient
+//   (p - t).  g0 / g1 = upstream gradients of out[0] / out[1] (NULL = that output is unused).
 template <int NCMAX>
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                        const long long* __restrict__ labels, const float* __restrict__ coef,
-                                                        float* __restrict__ ga, int B, int nc, long S, int a_is_prob) {
+                                                        const long long* __restrict__ labels, const float* __restrict__ stats,
+                                                        const float* __restrict__ weight, const float* __restrict__ gout0,
+                                                        const float* __restrict__ gout1, float* __restrict__ ga, int B, int nc,
+                                                        long S, int mode, float inv_vox, float inv_elems, int a_is_prob) {
   float al[NCMAX], be[NCMAX], gm[NCMAX];
+  const float g0 = gout0 ? gout0[0] : 0.f, g1 = gout1 ? gout1[0] : 0.f;
 #pragma unroll
   for (int c = 0; c < NCMAX; ++c) {
-    al[c] = c < nc ? coef[c] : 0.f;
-    be[c] = c < nc ? coef[nc + c] : 0.f;
-    gm[c] = c < nc ? coef[2 * nc + c] : 0.f;
+    al[c] = be[c] = gm[c] = 0.f;
+    if (c < nc) {
+      const float num = 2.f * stats[c] + kDiceEps;
+      const float den = stats[nc + c] + stats[2 * nc + c] + kDiceEps;
+      const float w = (weight ? weight[c] : 1.f) * g1 / (float)nc;
+      if (mode == 0 || mode == 1) { al[c] = -2.f * w / den; be[c] = 2.f * w * num / (den * den); }
+      else if (mode == 2) { al[c] = -2.f * w / den; gm[c] = w * num / (den * den); }
+      else { al[c] = -2.f * g0 * inv_elems; be[c] = 2.f * g0 * inv_elems; }
+    }
   }
-  const float kappa = coef[3 * nc];
+  const float kappa = (mode == 1) ? g0 * inv_vox : 0.f;
   const long total = (long)B * S;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long bi = e / S, s = e - bi * S;

@@ -101,6 +101,27 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
 }
 
+// out[b][m][:] = src[b][idx2[m][0]][:] + src[b][idx2[m][1]][:]  (either index may be -1 = absent).  Gradient of a row gather whose
+// index lists some source rows twice and some never: the reference's PatchMerging concatenates eight strided slices of which two
+// are repeated and two missing (networks/swinunetr_icl.py:953-961), so a token's gradient is the sum of 0, 1 or 2 gathered rows.
+__global__ __launch_bounds__(256) void gather_rows_sum2_kernel(const float* __restrict__ src, const int* __restrict__ idx2,
+                                                               float* __restrict__ out, long B, long S, long M, int C4) {
+  const long total = B * M * C4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C4);
+    const long r = e / C4;
+    const long m = r % M, b = r / M;
+    const int s0 = idx2[2 * m], s1 = idx2[2 * m + 1];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s0 >= 0) v = reinterpret_cast<const float4*>(src)[(b * S + s0) * C4 + c];
+    if (s1 >= 0) {
+      const float4 u = reinterpret_cast<const float4*>(src)[(b * S + s1) * C4 + c];
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    reinterpret_cast<float4*>(out)[e] = v;
+  }
+}
+
 // ---- im2col / col2im for 3^3 convolutions on TINY volumes (<= 6^3: the 384/768-channel bottleneck blocks of SwinUNETR and the
 // 256-channel centre of the U-Net).  There the convolution is a skinny GEMM that streams up to 64 MB of weights for 27..432
 // output voxels, so it runs as  colsT [N*S, Cin*27] x W[Cout, Cin*27]^T  on the library GEMM; these two kernels only move

@@ -39,8 +39,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 template <bool BLOCKROW>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ gx, long rows, int C) {
+                                                            const float* __restrict__ rstd, float* __restrict__ gx, long rows, int C,
+                                                            float* __restrict__ zero0, float* __restrict__ zero1) {
   __shared__ float red[4];
+  // block 0 also clears the dgamma / dbeta accumulators of the layernorm_wgrad launch that follows on the same stream
+  // (saves a memset launch per LayerNorm backward; the step has dozens of them on tiny token tensors)
+  if (blockIdx.x == 0 && zero0) {
+    for (int c = threadIdx.x; c < C; c += 256) { zero0[c] = 0.f; zero1[c] = 0.f; }
+  }
   const int lane = BLOCKROW ? threadIdx.x : (threadIdx.x & 63);
   const int stride = BLOCKROW ? 256 : 64;
   const long r = BLOCKROW ? (long)blockIdx.x : (long)blockIdx.x * 4 + (threadIdx.x >> 6);

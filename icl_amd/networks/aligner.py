@@ -169,6 +169,11 @@ class Conv1d(nn.Module):
         return ops.linear(q, self.weight.squeeze(-1), self.bias)
 
 
+def _batch_mean(t):
+    """t.mean(dim=0, keepdim=True); the mean over a single sample is the sample itself (sum / 1, exact)."""
+    return t if t.shape[0] == 1 else t.mean(dim=0, keepdim=True)
+
+
 class InherentConsistent(nn.Module):
     """unet_3D_icl.py:155-242.  ``forward(feats, guided_Q=None, modal='labeled')`` keeps the reference
     call convention, including ``sspa(feats, 'labeled')`` passing the string positionally (:144-145)."""
@@ -213,32 +218,32 @@ class InherentConsistent(nn.Module):
         p = self.proj_layers[i]
         return self.norm_layers[i](ops.linear(feat.flatten(2).transpose(1, 2), p.weight.flatten(1), p.bias))
 
-    def forward_labeled_pair(self, feats_a, feats_b):
-        """``self(feats_a, 'labeled')`` and ``self(feats_b, 'labeled')`` in lock step (the two ``sspa`` calls of
-        unet_3D_icl.py:144-145 share their weights).  Everything up to the attention maps is per-sample, so both inputs
-        go through the token projection / Class_Decoder as ONE batch: the 13,824^2 ``mlp2`` weights (1.5 GB per call)
-        are streamed twice per step instead of three times and their gradient is produced by one GEMM instead of two
-        plus an accumulation.  The BatchNorm layers of ``attn_convs0`` (batch statistics) and the per-call batch means
-        ``updated_Qs`` are still evaluated per input, in the reference order (a, then b)."""
-        ba = feats_a[0].shape[0]
-        bs = ba + feats_b[0].shape[0]
+    def forward_labeled_pair(self, feats, ba):
+        """``self(feats[:ba], 'labeled')`` and ``self(feats[ba:], 'labeled')`` in lock step (the two ``sspa`` calls of
+        unet_3D_icl.py:144-145 share their weights); ``feats`` hold both inputs as one batch, first ``ba`` samples = input a.
+        Everything up to the attention maps is per-sample, so both inputs go through the token projection / Class_Decoder
+        as ONE batch: the 13,824^2 ``mlp2`` weights (1.5 GB per call) are streamed twice per step instead of three times
+        and their gradient is produced by one GEMM instead of two plus an accumulation.  The BatchNorm layers of
+        ``attn_convs0`` (batch statistics) and the per-call batch means ``updated_Qs`` are still evaluated per input, in
+        the reference order (a, then b)."""
+        bs = feats[0].shape[0]
         maps_a, maps_b, qs_a, qs_b = [], [], [], []
         nxt = getattr(self, self._qname).expand(bs, -1, -1)
         for i in range(len(self.depth)):
-            f = torch.cat([feats_a[i], feats_b[i]], 0)
-            tok = self._tokens(i, f)
+            tok = self._tokens(i, feats[i])
             q_out, attn = self.class_decoders[i](nxt, tok)
             b, nc, h, n = attn.shape
             r = self.resolutions[i]
             sp = (r,) * self.dims
             a = attn.contiguous().view(b, nc, h, *sp)
-            for part, maps, qs in ((a[:ba], maps_a, qs_a), (a[ba:], maps_b, qs_b)):
+            for part, maps in zip(ops.split_batch(a, ba), (maps_a, maps_b)):
                 pb = part.shape[0]
                 m = self.attn_convs1[i](self.attn_convs0[i](part.reshape(pb * nc, h, *sp)))
                 maps.append(m.reshape(pb, nc, *sp))
             nxt = self.query_convs[i](q_out)
-            qs_a.append(q_out[:ba].mean(dim=0, keepdim=True))
-            qs_b.append(q_out[ba:].mean(dim=0, keepdim=True))
+            qa, qb = ops.split_batch(q_out, ba)
+            qs_a.append(_batch_mean(qa))
+            qs_b.append(_batch_mean(qb))
         return (maps_a, qs_a), (maps_b, qs_b)
 
     def forward(self, feats, guided_Q=None, modal="labeled"):
@@ -256,5 +261,5 @@ class InherentConsistent(nn.Module):
             a = self.attn_convs1[i](self.attn_convs0[i](a))
             feat_maps.append(a.reshape(b, nc, *sp))
             nxt = self.query_convs[i](q_out)
-            updated_qs.append(q_out.mean(dim=0, keepdim=True))
+            updated_qs.append(_batch_mean(q_out))
         return feat_maps, updated_qs

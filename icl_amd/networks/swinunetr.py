@@ -100,6 +100,31 @@ def window_index(dims, ws, ss, device):
     return _WINDOW_INDEX_CACHE[key]
 
 
+_MERGE_INDEX_CACHE = {}
+
+
+def merge_index(dims, slices, device):
+    """(idx [S], back [S, 2]) int32 for PatchMerging on an even (d, h, w) grid: output row ((d2*H2 + h2)*W2 + w2)*8 + slot reads
+    token (2*d2 + i, 2*h2 + j, 2*w2 + k) with (i, j, k) = slices[slot] — the channel concatenation of swinunetr_icl.py:953-961
+    written as a row gather.  ``back`` lists the (at most two) output rows reading each token, -1 where none does."""
+    key = (tuple(dims), tuple(slices), str(device))
+    if key not in _MERGE_INDEX_CACHE:
+        d, h, w = dims
+        ids = torch.arange(d * h * w, dtype=torch.int64).view(d, h, w)
+        idx = torch.stack([ids[i::2, j::2, k::2] for i, j, k in slices], -1).reshape(-1)
+        back = torch.full((d * h * w, 2), -1, dtype=torch.int64)
+        order = torch.argsort(idx, stable=True)
+        src = idx[order]
+        first = torch.ones_like(src, dtype=torch.bool)
+        first[1:] = src[1:] != src[:-1]
+        back[src[first], 0] = order[first]
+        second = ~first
+        assert not (second[1:] & second[:-1]).any(), "a token is read by more than two merge slots"
+        back[src[second], 1] = order[second]
+        _MERGE_INDEX_CACHE[key] = (idx.to(torch.int32).to(device), back.to(torch.int32).contiguous().to(device))
+    return _MERGE_INDEX_CACHE[key]
+
+
 class WindowAttention(nn.Module):
     """swinunetr_icl.py:644-750."""
 
@@ -191,7 +216,12 @@ class PatchMerging(nn.Module):
         b, d, h, w, c = x.shape
         if d % 2 or h % 2 or w % 2:   # :950-951, argument order as written (W padded by d%2, H by w%2, D by h%2)
             x = torch.nn.functional.pad(x, (0, 0, 0, d % 2, 0, w % 2, 0, h % 2))
-        x = torch.cat([x[:, i::2, j::2, k::2, :] for i, j, k in self.SLICES], -1)
+        b, d, h, w, c = x.shape
+        if c % 4:
+            x = torch.cat([x[:, i::2, j::2, k::2, :] for i, j, k in self.SLICES], -1)
+        else:   # the same concatenation as one row gather (and one gather-sum for its gradient)
+            idx, back = merge_index((d, h, w), self.SLICES, x.device)
+            x = ops.gather_rows_dup(x.reshape(b, d * h * w, c), idx, back).view(b, d // 2, h // 2, w // 2, 8 * c)
         return self.reduction(self.norm(x))
 
 

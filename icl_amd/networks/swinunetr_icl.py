@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import torch
 
+from .. import ops
 from .aligner import InherentConsistent
 from .swinunetr import SwinUNETRBackbone
 
@@ -36,8 +37,7 @@ class SwinUNETR_icl(SwinUNETRBackbone):  # noqa: N801 — reference class name
         # passes (:313-347) with half the launches and one weight-gradient product per layer.
         bl = x_lab.shape[0]
         logits, feats = self.run_backbone(torch.cat([x_lab, x_unlab], 0))
-        feats_lab = [t[:bl] for t in feats[:3]]
-        feats_unlab = [t[bl:] for t in feats[:3]]
-        (maps_lab, qs_lab), (maps_con, _) = self.sspa.forward_labeled_pair(feats_lab, feats_unlab)
-        maps_unlab, _ = self.uscl(feats_unlab, qs_lab, "unlabeled")
-        return logits[:bl], logits[bl:], maps_lab, maps_unlab, maps_con
+        (maps_lab, qs_lab), (maps_con, _) = self.sspa.forward_labeled_pair(feats[:3], bl)
+        maps_unlab, _ = self.uscl([t[bl:] for t in feats[:3]], qs_lab, "unlabeled")
+        logits_lab, logits_unlab = ops.split_batch(logits, bl)
+        return logits_lab, logits_unlab, maps_lab, maps_unlab, maps_con

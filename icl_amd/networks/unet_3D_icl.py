@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import torch
 
+from .. import ops
 from .aligner import InherentConsistent
 from .unet_3D import UNet3DBackbone
 
@@ -33,11 +34,9 @@ class unet_3D_icl(UNet3DBackbone):  # noqa: N801 — reference class name
         # layers; the weight gradients of both streams come out of one wgrad launch instead of two plus an add.
         bl = x_lab.shape[0]
         final, feats = self.run_backbone(torch.cat([x_lab, x_unlab], 0))
-        final_lab, final_unlab = final[:bl], final[bl:]
-        feats_lab = [f[:bl] for f in feats]
-        feats_unlab = [f[bl:] for f in feats]
-        (feat_maps_lab, updated_qs_lab), (feat_maps_consis, _) = self.sspa.forward_labeled_pair(feats_lab, feats_unlab)
-        feat_maps_unlab, _ = self.uscl(feats_unlab, updated_qs_lab, "unlabeled")
+        final_lab, final_unlab = ops.split_batch(final, bl)
+        (feat_maps_lab, updated_qs_lab), (feat_maps_consis, _) = self.sspa.forward_labeled_pair(feats, bl)
+        feat_maps_unlab, _ = self.uscl([f[bl:] for f in feats], updated_qs_lab, "unlabeled")
         return final_lab, final_unlab, feat_maps_lab, feat_maps_unlab, feat_maps_consis
 
     @staticmethod

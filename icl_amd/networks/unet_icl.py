@@ -6,6 +6,7 @@ so the labeled and the unlabeled half must see their own statistics exactly as i
 Appendix A.10).  The two ``sspa`` calls still run in lock step (their BatchNorms are evaluated per input)."""
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 
 from .aligner import InherentConsistent
@@ -30,6 +31,7 @@ class UNet_icl(nn.Module):  # noqa: N801 — reference class name
         if inference:
             return output_lab
         output_unlab, feats_unlab = self.decoder(self.encoder(x_unlab))
-        (maps_lab, qs_lab), (maps_consis, _) = self.sspa.forward_labeled_pair(feats_lab, feats_unlab)
+        both = [torch.cat([a, b], 0) for a, b in zip(feats_lab, feats_unlab)]
+        (maps_lab, qs_lab), (maps_consis, _) = self.sspa.forward_labeled_pair(both, feats_lab[0].shape[0])
         maps_unlab, _ = self.uscl(feats_unlab, qs_lab, "unlabeled")
         return output_lab, output_unlab, maps_lab, maps_unlab, maps_consis

@@ -15,6 +15,7 @@ import types
 import torch
 import torch.nn as nn
 
+from .. import ops
 from .aligner import InherentConsistent
 from .swinunet_icl import SwinTransformerSys
 
@@ -56,10 +57,10 @@ class SwinUnet(nn.Module):
             return self.swin_unet.run(self._rgb(x_lab))[0]
         bl = x_lab.shape[0]
         out, feats = self.swin_unet.run(torch.cat([self._rgb(x_lab), self._rgb(x_unlab)], 0))
-        feats_lab, feats_unlab = [f[:bl] for f in feats], [f[bl:] for f in feats]
-        (maps_lab, qs_lab), (maps_con, _) = self.sspa.forward_labeled_pair(feats_lab, feats_unlab)
-        maps_unlab, _ = self.uscl(feats_unlab, qs_lab, "unlabeled")
-        return out[:bl], out[bl:], maps_lab, maps_unlab, maps_con
+        (maps_lab, qs_lab), (maps_con, _) = self.sspa.forward_labeled_pair(feats, bl)
+        maps_unlab, _ = self.uscl([f[bl:] for f in feats], qs_lab, "unlabeled")
+        out_lab, out_unlab = ops.split_batch(out, bl)
+        return out_lab, out_unlab, maps_lab, maps_unlab, maps_con
 
     def load_from(self, config):
         """vision_transformer.py:110-146: ImageNet Swin-T checkpoint -> encoder, mirrored into the decoder stages."""

@@ -204,8 +204,9 @@ class _Conv3d(torch.autograd.Function):
             if ctx.has_bias and ctx.zero_bias_grad:
                 # the conv feeds an InstanceNorm: its output is invariant to the bias, so dL/dbias == 0 exactly
                 # (the reference holds ~1e-8 rounding noise there); skip the reduction pass over dY.  The zero vector is a
-                # cached constant (nothing ever writes a non-zero into it), not a fill kernel per layer and step.
-                gb = _cached_zeros(cout, x.device)
+                # cached constant (nothing ever writes a non-zero into it), not a fill kernel per layer and step; returned as a
+                # fresh view so that AccumulateGrad adopts it instead of cloning a tensor it sees other references to.
+                gb = _cached_zeros(cout, x.device).view(cout)
                 gb_arg = None
             flops = 2.0 * ks ** 3 * cin * cout * s * n
             nbytes = 4.0 * (n * s * (cin + cout) + 2 * ks ** 3 * cin * cout)
@@ -915,6 +916,68 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, idx_back: torch.Tensor) ->
     return _GatherRows.apply(src, idx, idx_back)
 
 
+class _SplitBatch(torch.autograd.Function):
+    """(x[:k], x[k:]) whose gradient is ONE concatenation; two Python slices cost two zero fills, two copies and an add."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k, ctx.n = int(k), x.shape[0]
+        ctx.tail = tuple(x.shape[1:])
+        ctx.set_materialize_grads(False)
+        return x[:k], x[k:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        ref = ga if ga is not None else gb
+        if ga is None:
+            ga = ref.new_zeros((ctx.k,) + ctx.tail)
+        if gb is None:
+            gb = ref.new_zeros((ctx.n - ctx.k,) + ctx.tail)
+        return torch.cat([ga, gb], 0), None
+
+
+def split_batch(x: torch.Tensor, k: int):
+    """x[:k], x[k:] (views) with a single-kernel gradient."""
+    return _SplitBatch.apply(x, k)
+
+
+class _GatherRowsDup(torch.autograd.Function):
+    """Row gather whose index may repeat or omit source rows (PatchMerging); ``idx_back2`` [S, 2] lists for every source row the
+    (at most two) output rows that read it, -1 where absent, so the gradient is again a deterministic gather."""
+
+    @staticmethod
+    def forward(ctx, src, idx, idx_back2):
+        _require(src, idx, idx_back2)
+        L = _lib.lib()
+        src = src.contiguous()
+        b, s, c = src.shape
+        m = idx.shape[0]
+        assert tuple(idx_back2.shape) == (s, 2)
+        out = torch.empty((b, m, c), dtype=torch.float32, device=src.device)
+        _lib.check(L.icl_gather_rows(_ptr(src), _ptr(idx), _ptr(out), b, s, m, c, _stream(src)), "gather_rows")
+        ctx.save_for_backward(idx_back2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx_back2,) = ctx.saved_tensors
+        L = _lib.lib()
+        g = g.contiguous()
+        b, m, c = g.shape
+        s = idx_back2.shape[0]
+        gs = torch.empty((b, s, c), dtype=torch.float32, device=g.device)
+        _lib.check(L.icl_gather_rows_sum2(_ptr(g), _ptr(idx_back2), _ptr(gs), b, m, s, c, _stream(g)), "gather_rows_sum2")
+        return gs, None, None
+
+
+def gather_rows_dup(src: torch.Tensor, idx: torch.Tensor, idx_back2: torch.Tensor) -> torch.Tensor:
+    """src [B, S, C] -> [B, M, C], out[:, m] = src[:, idx[m]]; every source row is read by at most two output rows, listed in
+    ``idx_back2`` [S, 2] (int32, -1 = none)."""
+    return _GatherRowsDup.apply(src, idx, idx_back2)
+
+
 class _WindowAttention(torch.autograd.Function):
     """One fused MFMA kernel per direction (csrc/kernels/winattn.h): scores, bias, shift mask, softmax and P@V never leave
     the CU; backward recomputes the scores from the saved log-sum-exp.  The relative-position bias is gathered from the
@@ -1021,8 +1084,11 @@ def prototype_attention(qh: torch.Tensor, kv: torch.Tensor, heads: int, scale: f
 # Loss reductions (utils/losses.py L1-L5): one fused HIP pass per loss term, one more for its gradient
 # --------------------------------------------------------------------------------------
 
+LOSS_MAX_BLOCKS = 1024   # ICL_LOSS_MAX_BLOCKS (include/icl_hip.h)
+
+
 class _FusedLoss(torch.autograd.Function):
-    """out = [term0, term1] per icl_loss_fwd's mode table (include/icl_hip.h)."""
+    """(term0, term1) per icl_loss_fwd's mode table (include/icl_hip.h)."""
 
     @staticmethod
     def forward(ctx, a, target, weight, mode, a_is_prob):
@@ -1037,27 +1103,28 @@ class _FusedLoss(torch.autograd.Function):
             assert target.dtype == torch.int64 and target.numel() == B * S, "labels must be int64 [B, ...]"
         else:
             assert target.shape == a.shape and target.dtype == torch.float32
-        stats = torch.empty(3 * nc + 1, dtype=torch.float32, device=a.device)
+        stats = torch.empty((3 * nc + 1) * (1 + LOSS_MAX_BLOCKS), dtype=torch.float32, device=a.device)   # ICL_LOSS_STATS_FLOATS
         out = torch.empty(2, dtype=torch.float32, device=a.device)
         _lib.check(L.icl_loss_fwd(_ptr(a), None if hard else _ptr(target), _ptr(target) if hard else None, _ptr(weight),
                                   _ptr(stats), _ptr(out), B, nc, S, mode, int(a_is_prob), _stream(a)), "loss_fwd")
         ctx.save_for_backward(a, target, stats, weight)
         ctx.cfg = (mode, int(a_is_prob))
-        return out
+        ctx.set_materialize_grads(False)
+        return out[0], out[1]      # two scalars: an unused one costs nothing in backward (no select_backward / zero fill)
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, g0, g1):
         a, target, stats, weight = ctx.saved_tensors
         mode, aip = ctx.cfg
         L = _lib.lib()
         B, nc = a.shape[0], a.shape[1]
         S = a.numel() // (B * nc)
         hard = mode <= 1
-        gout = gout.contiguous()
-        coef = torch.empty(3 * nc + 1, dtype=torch.float32, device=a.device)
+        g0 = g0.contiguous() if g0 is not None else None
+        g1 = g1.contiguous() if g1 is not None else None
         ga = torch.empty_like(a)
         _lib.check(L.icl_loss_bwd(_ptr(a), None if hard else _ptr(target), _ptr(target) if hard else None, _ptr(weight),
-                                  _ptr(stats), _ptr(gout), _ptr(coef), _ptr(ga), B, nc, S, mode, aip, _stream(a)), "loss_bwd")
+                                  _ptr(stats), _ptr(g0), _ptr(g1), _ptr(ga), B, nc, S, mode, aip, _stream(a)), "loss_bwd")
         return ga, None, None, None, None
 
 
@@ -1076,8 +1143,7 @@ def dice_loss(inputs: torch.Tensor, labels: torch.Tensor, n_classes: int, softma
 def cross_entropy_dice_parts(logits: torch.Tensor, labels: torch.Tensor, n_classes: int):
     """(CrossEntropyLoss()(logits, labels), DiceLoss(softmax=True)(logits, labels)) from ONE pass over the logits."""
     assert logits.shape[1] == n_classes
-    out = _FusedLoss.apply(logits, labels.long(), None, 1, False)
-    return out[0], out[1]
+    return _FusedLoss.apply(logits, labels.long(), None, 1, False)
 
 
 def cross_entropy_dice(logits: torch.Tensor, labels: torch.Tensor, n_classes: int):

@@ -104,12 +104,15 @@ int icl_drop_path(const float* x, float* y, int64_t n, int64_t group, uint32_t s
  * a_is_prob); the target is int64 labels [B,S] (modes 0,1) or a second logit tensor b [B,nc,S] (modes 2,3):
  *   mode 0 hard Dice        out = {0, dice}          mode 1 CE + hard Dice   out = {ce, dice}
  *   mode 2 soft Dice        out = {0, dice}          mode 3 softmax MSE      out = {mse, 0}
- * stats: 3*nc+1 floats (kept for backward); coef: 3*nc+1 floats scratch; gout: upstream grads of out[0], out[1];
- * ga: gradient w.r.t. a.  weight (per-class Dice weights) may be NULL.  nc <= 16. */
+ * stats: ICL_LOSS_STATS_FLOATS(nc) floats — the 3*nc+1 reduced sums (kept for backward) followed by per-workgroup partials,
+ * summed in a fixed order (no atomics: the loss is bit-reproducible and nothing needs zeroing); gout0 / gout1: upstream grads of out[0] / out[1], one float each, NULL when
+ * that output does not reach the loss; ga: gradient w.r.t. a.  weight (per-class Dice weights) may be NULL.  nc <= 16. */
+#define ICL_LOSS_MAX_BLOCKS 1024
+#define ICL_LOSS_STATS_FLOATS(nc) ((3 * (nc) + 1) * (1 + ICL_LOSS_MAX_BLOCKS))
 int icl_loss_fwd(const float* a, const float* b, const int64_t* labels, const float* weight, float* stats, float* out,
                  int batch, int nc, int64_t s, int mode, int a_is_prob, void* stream);
 int icl_loss_bwd(const float* a, const float* b, const int64_t* labels, const float* weight, const float* stats,
-                 const float* gout, float* coef, float* ga, int batch, int nc, int64_t s, int mode, int a_is_prob,
+                 const float* gout0, const float* gout1, float* ga, int batch, int nc, int64_t s, int mode, int a_is_prob,
                  void* stream);
 
 /* ---- aligner token operators (networks/unet_3D_icl.py:244-315)
@@ -134,6 +137,10 @@ int icl_attn_bwd(const float* q, const float* kv, const float* logits, const flo
  * networks/swinunetr_icl.py:825-866, networks/swinunet_icl.py:256-283): out[b][m][0..c) = idx[m] >= 0 ? src[b][idx[m]][0..c) : 0,
  * src [b, s, c], out [b, m, c], c % 4 == 0.  The inverse direction and both gradients are gathers with the inverse index. */
 int icl_gather_rows(const float* src, const int32_t* idx, float* out, int64_t b, int64_t s, int64_t m, int c, void* stream);
+/* out[b][m] = src[b][idx2[m][0]] + src[b][idx2[m][1]] (an index of -1 is absent).  Gradient of icl_gather_rows when the
+ * index lists a source row up to twice or not at all: PatchMerging's eight strided slices repeat two and omit two
+ * (networks/swinunetr_icl.py:953-961; the 2-D merge networks/swinunet_icl.py:320-326 is a plain permutation). */
+int icl_gather_rows_sum2(const float* src, const int32_t* idx2, float* out, int64_t b, int64_t s, int64_t m, int c, void* stream);
 
 /* ---- 3^3 convolutions on tiny volumes (<= 6^3 voxels, hundreds of channels: `encoder10`/`decoder5` of SwinUNETR,
  * networks/swinunetr_icl.py:163-183, and the U-Net `center`, networks/unet_3D_icl.py:54) are skinny GEMMs over the weights:

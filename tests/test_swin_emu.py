@@ -256,6 +256,24 @@ def test_swin_stage_matches_oracle(grid):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("grid", [(4, 6, 2), (8, 8, 8)])
+def test_patch_merging_gather_matches_slices(grid):
+    """PatchMerging's concatenation of eight strided slices (two repeated, two missing) as one row gather; its gradient as one
+    gather-sum — against the slices themselves under autograd."""
+    d, h, w = grid
+    c = 12
+    x = _rand((2, d, h, w, c), 71, True)
+    idx, back = SW.merge_index(grid, SW.PatchMerging.SLICES, "cpu")
+    y = ops.gather_rows_dup(x.reshape(2, d * h * w, c), idx, back).view(2, d // 2, h // 2, w // 2, 8 * c)
+    xr = x.detach().clone().requires_grad_()
+    yr = torch.cat([xr[:, i::2, j::2, k::2, :] for i, j, k in SW.PatchMerging.SLICES], -1)
+    assert torch.equal(y.detach(), yr.detach())
+    gy = _rand(tuple(yr.shape), 72)
+    y.backward(gy)
+    yr.backward(gy)
+    assert rel_err(x.grad, xr.grad) < 1e-6
+
+
 def test_patch_embed_and_hidden_state_norm():
     p = O.make_params([("proj.weight", (48, 1, 2, 2, 2)), ("proj.bias", (48,))])
     m = SW.PatchEmbed(1, 48)
