@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--force-ddp", action="store_true", help="with --gpus 1: run the data-parallel step on a one-rank RCCL group")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,10 +112,16 @@ def main():
     from icl_amd.utils.hashfill import synthetic_labels, synthetic_volume
 
     ddp = None
-    if world > 1:
+    use_ddp = world > 1 or args.force_ddp
+    if use_ddp:
         import torch.distributed as dist
         from icl_amd.ddp import GradientReducer
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:   # --force-ddp: a one-rank RCCL group, to exercise the data-parallel step on a single GPU
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     torch.manual_seed(1337 + rank)
     nc = args.num_classes
@@ -124,8 +131,8 @@ def main():
     else:
         model = unet_3D_icl(n_classes=nc, in_channels=1, device=dev)
     model.train()
-    if world > 1:
-        ddp = GradientReducer(model, world)
+    if use_ddp:
+        ddp = GradientReducer(model, world, force=args.force_ddp)
         ddp.broadcast_parameters()
     cfg = ICLConfig(num_classes=nc, labeled_bs=1, base_lr=0.02 if nc == 16 else 0.01,
                     w_pse=0.1 if nc == 16 else 1.0)
@@ -135,13 +142,28 @@ def main():
     lab = synthetic_labels((1, 96, 96, 96), 4242 + rank, nc, device=dev)
 
     def barrier():
-        if world > 1:
+        if use_ddp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    graphed = world == 1 and not args.no_graph
+    graphed = not args.no_graph
     if graphed:
-        trainer.capture(vol, lab, warmup=max(args.warmup, 2))   # warm-up steps run eagerly inside capture()
+        # N > 1: forward/backward graph, eager RCCL collectives, optimiser graph (ICLTrainer.capture)
+        ok = 1
+        try:
+            trainer.capture(vol, lab, warmup=max(args.warmup, 2))   # warm-up steps run eagerly inside capture()
+        except Exception as e:   # noqa: BLE001 — a rank that cannot capture must not leave the others in a collective
+            if ddp is None:
+                raise
+            print(f"[bench] rank {rank}: graph capture failed ({e!r}); falling back to eager launches", file=sys.stderr, flush=True)
+            ok = 0
+        if ddp is not None:
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                trainer.graph = trainer.graph_update = None
+                ddp.static = False
+                graphed = False
         trainer.step(vol, lab)
     else:
         for _ in range(args.warmup):
@@ -152,7 +174,7 @@ def main():
         trainer.step(vol, lab)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -161,7 +183,8 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_kernel_timer:
-        trainer.graph = None   # per-kernel HIP-event timing needs eager launches
+        trainer.graph = trainer.graph_update = None   # per-kernel HIP-event timing needs eager launches ...
+        trainer.ddp = None                              # ... of this rank's step alone: the other ranks are done
         with ops.KernelTimer() as kt:
             for _ in range(3):
                 trainer.step(vol, lab)
@@ -202,7 +225,8 @@ def main():
             "config": {"workload": f"{'SwinUNETR' if args.model == 'swinunetr_icl' else '3D U-Net'} ICL BraTS-shape synthetic 96x96x96, num_classes={nc}, "
                                    f"batch=2 per GPU (1 labeled + 1 unlabeled), full ICL step incl. SGD",
                        "global_batch": 2 * world, "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay" if graphed else "eager"},
+                       "launch": ("eager" if not graphed else "hipGraph replay" if ddp is None else
+                                  "hipGraph replay (forward/backward, optimiser) + eager RCCL collectives")},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -210,7 +234,8 @@ def main():
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(nc, args.model)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_ddp:
+        torch.distributed.barrier()    # rank 0 may still have been timing kernels
         torch.distributed.destroy_process_group()
 
 

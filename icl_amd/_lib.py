@@ -49,6 +49,7 @@ _SIGNATURES = {
     "icl_dwconv3_wgrad": (c_int, [P, P, P, I, I, I, I, I, P]),
     "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P, P]),
     "icl_drop_path": (c_int, [P, P, L, L, ctypes.c_uint32, F, P, P]),
+    "icl_drop_path_add": (c_int, [P, P, P, L, L, ctypes.c_uint32, F, P, P]),
     "icl_loss_fwd": (c_int, [P, P, P, P, P, P, I, I, L, I, I, P]),
     "icl_window_attn_bias_elems": (c_int64, [I, I]),
     "icl_depth_to_space2": (c_int, [P, P, I, I, I, I, I, L, P]),

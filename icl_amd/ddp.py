@@ -23,18 +23,32 @@ import torch.distributed as dist
 
 
 class GradientReducer:
-    def __init__(self, model: torch.nn.Module, world_size: int, bucket_bytes: int = 256 << 20, overlap_min_elems: int = 1 << 22):
+    """``reduce_gradients()`` = ``pack()`` (device-side preparation) + ``communicate()`` (the collectives, nothing else) +
+    ``rebind()`` (Python-side: ``p.grad`` / ``p._icl_factors`` now name the reduced buffers).  ICLTrainer.capture() records
+    pack() at the end of the forward/backward hipGraph and the optimiser in a second graph, so that a data-parallel step is
+    two graph replays with only the collectives issued eagerly in between."""
+
+    def __init__(self, model: torch.nn.Module, world_size: int, bucket_bytes: int = 256 << 20, overlap_min_elems: int = 1 << 22,
+                 force: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         self.world = world_size
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap_min = overlap_min_elems
+        self.force = force       # run the collectives even with a single rank (exercises the captured path on one GPU)
+        self.static = False      # set by ICLTrainer.capture(): buffers persist, nothing is issued from autograd hooks
         self._handles = []
         self._early = set()
+        self._flat = []          # [(flat buffer, [params])]
+        self._fac = []           # [(param, g_scaled, x, G_all, X_all)]
         self._avg = dist.is_initialized() and dist.get_backend() == "nccl"   # RCCL averages in the collective
         if world_size > 1:
             for p in self.params:
                 if p.numel() >= overlap_min_elems:
                     p.register_post_accumulate_grad_hook(self._on_grad_ready)
+
+    @property
+    def active(self) -> bool:
+        return self.world > 1 or self.force
 
     def broadcast_parameters(self, src: int = 0):
         for p in self.params:
@@ -42,7 +56,7 @@ class GradientReducer:
 
     # -- large tensors: start the all-reduce as soon as the gradient is complete, overlap with the rest of backward
     def _on_grad_ready(self, p: torch.nn.Parameter):
-        if p.grad is None:
+        if p.grad is None or self.static:
             return
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._handles.append((dist.all_reduce(p.grad, op=op, async_op=True), p))
@@ -61,10 +75,19 @@ class GradientReducer:
         if cur:
             yield cur
 
-    def _gather_factored(self):
-        """Parameters whose gradient is still factored (ops.FactoredGrads: dW = g^T x with a few dozen rows): the mean over
-        ranks of g_r^T x_r is [g_1/W; ...; g_W/W]^T [x_1; ...; x_W], so the ranks all-gather the row blocks (~1 MB per
-        13,824^2 matrix) instead of all-reducing 764 MB.  Every rank must hold the same number of rows."""
+    def pack(self):
+        """Device-side preparation, no communication: the small gradients of a bucket are concatenated into one flat buffer;
+        factored gradients (ops.FactoredGrads: dW = g^T x with a few dozen rows) are scaled for the mean — the mean over ranks
+        of g_r^T x_r is [g_1/W; ...; g_W/W]^T [x_1; ...; x_W], so the ranks exchange the row blocks (~1 MB per 13,824^2
+        matrix) instead of all-reducing 764 MB — and the gather targets are allocated."""
+        self._flat, self._fac = [], []
+        if not self.active:
+            return
+        for bucket in self._buckets():
+            if len(bucket) == 1 and bucket[0].grad.is_contiguous():
+                self._flat.append((bucket[0].grad.view(-1), None))          # reduced in place
+            else:
+                self._flat.append((torch.cat([p.grad.reshape(-1) for p in bucket]), bucket))
         inv = 1.0 / self.world
         for p in self.params:
             fac = getattr(p, "_icl_factors", None)
@@ -74,39 +97,54 @@ class GradientReducer:
             x = fac[0][1] if len(fac) == 1 else torch.cat([f[1] for f in fac], 0)
             g = (g * inv).contiguous()
             x = x.contiguous()
-            gs = [torch.empty_like(g) for _ in range(self.world)]
-            xs = [torch.empty_like(x) for _ in range(self.world)]
-            dist.all_gather(gs, g)
-            dist.all_gather(xs, x)
-            p._icl_factors = [(torch.cat(gs, 0), torch.cat(xs, 0))]
+            G = torch.empty((self.world * g.shape[0], g.shape[1]), dtype=g.dtype, device=g.device)
+            X = torch.empty((self.world * x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+            self._fac.append((p, g, x, G, X))
 
-    def reduce_gradients(self):
-        """Call after ``loss.backward()``: reduces the remaining (small) gradients and waits for the overlapped ones.
-        Every rank must hold the same set of non-None grads (true for ICL: a property of the graph, not of the data)."""
-        if self.world == 1:
+    def communicate(self):
+        """The collectives on the packed buffers (every rank must hold the same set of non-None grads and the same number of
+        factor rows — true for ICL: a property of the graph, not of the data) and the wait for the overlapped ones."""
+        if not self.active:
             return
-        self._gather_factored()
         inv = 1.0 / self.world
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        for bucket in self._buckets():
-            if len(bucket) == 1:
-                g = bucket[0].grad
-                dist.all_reduce(g, op=op)
-                if not self._avg:
-                    g.mul_(inv)
-                continue
-            flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        for flat, _ in self._flat:
             dist.all_reduce(flat, op=op)
             if not self._avg:
                 flat.mul_(inv)
-            off = 0
-            for p in bucket:
-                n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+        for _, g, x, G, X in self._fac:
+            if self._avg:     # RCCL: one contiguous gather
+                dist.all_gather_into_tensor(G, g)
+                dist.all_gather_into_tensor(X, x)
+            else:
+                dist.all_gather(list(G.chunk(self.world, 0)), g)
+                dist.all_gather(list(X.chunk(self.world, 0)), x)
         for h, p in self._handles:
             h.wait()
             if not self._avg:
                 p.grad.mul_(inv)
         self._handles.clear()
         self._early.clear()
+
+    def rebind(self):
+        """``p.grad`` becomes a view into its bucket's reduced buffer (no copy back) and ``p._icl_factors`` the gathered rows."""
+        for flat, bucket in self._flat:
+            if bucket is None:
+                continue
+            off = 0
+            for p in bucket:
+                n = p.grad.numel()
+                p.grad = flat[off:off + n].view_as(p)
+                off += n
+        for p, _, _, G, X in self._fac:
+            p._icl_factors = [(G, X)]
+
+    def reduce_gradients(self):
+        """Call after ``loss.backward()``: averages every gradient over the ranks (parameters whose grad is None are skipped)."""
+        if not self.active:
+            return
+        self.pack()
+        self.communicate()
+        self.rebind()
+        if not self.static:
+            self._flat, self._fac = [], []

@@ -71,6 +71,10 @@ class DropPath(nn.Module):
             return x
         return ops.drop_path(x, self.drop_prob)
 
+    def add(self, res, x):
+        """res + self(x) as one kernel."""
+        return ops.drop_path_add(res, x, self.drop_prob, self.training)
+
 
 class MLP(nn.Module):
     """fc2(GELU_erf(fc1(x))) — unet_3D_icl.py:299-315."""
@@ -121,10 +125,10 @@ class Class_Decoder(nn.Module):  # noqa: N801
 
     def forward(self, query, feat):
         query, attn = self.attn(self.norm1_query(query), self.norm1(feat))
-        query = query + self.drop_path(query)
-        query = query + self.drop_path(self.mlp(self.norm2(query)))
-        attn = attn + self.drop_path(attn)
-        attn = attn + self.drop_path(self.mlp2(self.norm3(attn)))
+        query = self.drop_path.add(query, query)
+        query = self.drop_path.add(query, self.mlp(self.norm2(query)))
+        attn = self.drop_path.add(attn, attn)
+        attn = self.drop_path.add(attn, self.mlp2(self.norm3(attn)))
         return query, attn
 
 

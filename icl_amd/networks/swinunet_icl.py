@@ -117,8 +117,8 @@ class SwinTransformerBlock(nn.Module):
         win = ops.gather_rows(self.norm1(x), self._to_win, self._to_tok)             # [b, nW*n, c] in window order
         win = self.attn(win.view(-1, ws * ws, c), self._regions if ss > 0 else None)
         y = ops.gather_rows(win.view(b, l, c), self._to_tok, self._to_win)
-        x = x + self.drop_path(y)
-        return x + self.drop_path(self.mlp(self.norm2(x)))
+        x = self.drop_path.add(x, y)
+        return self.drop_path.add(x, self.mlp(self.norm2(x)))
 
 
 class PatchMerging(nn.Module):

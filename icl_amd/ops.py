@@ -616,6 +616,58 @@ class _Dropout(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+class _DropPathAdd(torch.autograd.Function):
+    """y = res + drop_path(x) in one kernel; ``res is x`` gives x + drop_path(x).  d/dres is the identity (the incoming gradient is
+    handed on as is), d/dx the same per-sample mask applied to the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, res, p, seed, seed_dev):
+        _require(x, res)
+        L = _lib.lib()
+        x = x.contiguous()
+        same = res is x or (res.data_ptr() == x.data_ptr() and res.shape == x.shape and res.is_contiguous())
+        res = x if same else res.contiguous()
+        assert res.shape == x.shape
+        group = x.numel() // x.shape[0]
+        y = torch.empty_like(x)
+        _lib.check(L.icl_drop_path_add(_ptr(x), _ptr(res), _ptr(y), x.numel(), group, seed, p, _ptr(seed_dev), _stream(x)), "drop_path_add")
+        ctx.cfg = (p, seed, group)
+        ctx.seed_dev = seed_dev
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        p, seed, group = ctx.cfg
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gy = gy.contiguous()
+            gx = torch.empty_like(gy)
+            _lib.check(L.icl_drop_path(_ptr(gy), _ptr(gx), gy.numel(), group, seed, p, _ptr(ctx.seed_dev), _stream(gy)), "drop_path_bwd")
+        return gx, (gy if ctx.needs_input_grad[1] else None), None, None, None
+
+
+def _step_seed(x, seed):
+    seed_dev = None
+    if seed is None:
+        if StepRNG.tensor is not None and StepRNG.tensor.device == x.device:
+            seed = 0x2545F491 + 7919 * StepRNG.calls
+            StepRNG.calls += 1
+            seed_dev = StepRNG.tensor
+        else:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return int(seed) & 0xFFFFFFFF, seed_dev
+
+
+def drop_path_add(res: torch.Tensor, x: torch.Tensor, p: float, training: bool = True, seed: Optional[int] = None) -> torch.Tensor:
+    """res + DropPath(p)(x) — the residual update of a transformer block — as one kernel in training (a plain add otherwise).
+    Same per-sample mask and seeding as ``drop_path``."""
+    if p == 0.0 or not training:
+        return res + x
+    seed, seed_dev = _step_seed(x, seed)
+    return _DropPathAdd.apply(x, res, float(p), seed, seed_dev)
+
+
 def dropout(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Tensor:
     """Training-mode dropout.  Eager: the seed advances with torch's CPU generator (reproducible under manual_seed).
     With StepRNG enabled (graph capture): seed = call index, varied per step by the device-resident counter."""

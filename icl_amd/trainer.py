@@ -52,6 +52,7 @@ class ICLTrainer:
             self.pse_loss = L.PseudoSoftLoss(cfg.num_classes, cfg.patch_size)
         self.iter_num = 0
         self.graph = None
+        self.graph_update = None
         self.lr_dev = None
 
     def compute_loss(self, outputs, label_batch):
@@ -65,7 +66,7 @@ class ICLTrainer:
         loss = loss_dice + loss_ce + loss_aux + cfg.w_pse * loss_pse + cfg.w_con * loss_con
         return loss, dict(dice=loss_dice, ce=loss_ce, aux=loss_aux, pse=loss_pse, con=loss_con)
 
-    def _step_body(self, volume_batch, label_batch):
+    def _forward_backward(self, volume_batch, label_batch):
         cfg = self.cfg
         ops.StepRNG.begin_step()
         self.optimizer.zero_grad(set_to_none=True)
@@ -73,12 +74,19 @@ class ICLTrainer:
             outputs = self.model(volume_batch[:cfg.labeled_bs], volume_batch[cfg.labeled_bs:])
             loss, parts = self.compute_loss(outputs, label_batch)
             loss.backward()
-        if self.ddp is not None:
-            self.ddp.reduce_gradients()
-        self.optimizer.step()
-        ops.StepRNG.end_step()
         parts = {k: v.detach() for k, v in parts.items()}
         parts["loss"] = loss.detach()
+        return parts
+
+    def _apply_update(self):
+        self.optimizer.step()
+        ops.StepRNG.end_step()
+
+    def _step_body(self, volume_batch, label_batch):
+        parts = self._forward_backward(volume_batch, label_batch)
+        if self.ddp is not None:
+            self.ddp.reduce_gradients()
+        self._apply_update()
         return parts
 
     def _advance_lr(self):
@@ -99,6 +107,9 @@ class ICLTrainer:
                 self.static_lab.copy_(label_batch)
             self.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
             self.graph.replay()
+            if self.graph_update is not None:    # data-parallel: collectives between the two graphs
+                self.ddp.communicate()
+                self.graph_update.replay()
             parts = self.static_out
         else:
             parts = self._step_body(volume_batch, label_batch)
@@ -108,26 +119,46 @@ class ICLTrainer:
     def capture(self, volume_batch: torch.Tensor, label_batch: torch.Tensor, warmup: int = 3):
         """Capture one full iteration into a hipGraph (torch.cuda.CUDAGraph).  Every per-step scalar the kernels need —
         the learning rate and the dropout seed — lives in device memory (FusedSGD.lr_dev, ops.StepRNG) so that a replay
-        is a real training step: new masks, scheduled lr, updated weights.  Not used with DDP (the all-reduce stays eager)."""
-        assert self.ddp is None, "graph capture of the DDP step is not supported yet"
+        is a real training step: new masks, scheduled lr, updated weights.
+
+        Data-parallel (``ddp`` given): two graphs.  The first holds forward, losses, backward and GradientReducer.pack()
+        (gradients concatenated into flat buffers, factor rows scaled); the RCCL collectives on those persistent buffers are
+        issued eagerly; the second graph holds the optimiser, reading the reduced buffers.  Nothing is captured while a
+        collective is in flight and no collective is captured."""
         dev = volume_batch.device
+        ddp = self.ddp if (self.ddp is not None and self.ddp.active) else None
         self.static_vol = volume_batch.clone()
         self.static_lab = label_batch.clone()
         self.lr_dev = torch.full((1,), float(self.optimizer.param_groups[0]["lr"]), dtype=torch.float32, device=dev)
         self.optimizer.lr_dev = self.lr_dev
         ops.StepRNG.enable(dev)
+        if ddp is not None:
+            ddp.static = True
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(warmup):   # allocator warm-up, momentum buffers, one-time kernel attributes
+            for _ in range(warmup):   # allocator warm-up, momentum buffers, one-time kernel attributes, RCCL communicators
                 self.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
                 self._step_body(self.static_vol, self.static_lab)
                 self._advance_lr()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        # RCCL's watchdog thread polls its events from another thread: keep its calls out of the capture's error scope
+        mode = dict(capture_error_mode="thread_local") if ddp is not None else {}
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self.static_out = self._step_body(self.static_vol, self.static_lab)
+        with torch.cuda.graph(graph, **mode):
+            if ddp is None:
+                self.static_out = self._step_body(self.static_vol, self.static_lab)
+            else:
+                self.static_out = self._forward_backward(self.static_vol, self.static_lab)
+                ddp.pack()
+        self.graph_update = None
+        if ddp is not None:
+            ddp.rebind()
+            update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(update, pool=graph.pool(), **mode):
+                self._apply_update()
+            self.graph_update = update
         self.graph = graph
         return self
 

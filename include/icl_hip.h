@@ -98,6 +98,10 @@ int icl_dropout(const float* x, float* y, int64_t n, uint32_t seed, float p, con
 /* DropPath / stochastic depth (timm, MONAI; networks/unet_3D_icl.py:253, swinunet_icl.py:215): one keep/drop decision per `group`
  * consecutive elements (group = elements per sample), kept samples scaled by 1/(1-p).  Same counter-based mask as icl_dropout. */
 int icl_drop_path(const float* x, float* y, int64_t n, int64_t group, uint32_t seed, float p, const uint32_t* seed_dev, void* stream);
+/* y = res + DropPath(x): the residual update  x + drop_path(branch)  of the Class_Decoder / Swin blocks (unet_3D_icl.py:262-267,
+ * swinunetr_icl.py:871-884) in one pass; res may be NULL (plain icl_drop_path) or alias x (x + drop_path(x), :263). */
+int icl_drop_path_add(const float* x, const float* res, float* y, int64_t n, int64_t group, uint32_t seed, float p,
+                      const uint32_t* seed_dev, void* stream);
 
 /* ---- fused softmax + Dice / CE / soft-Dice / MSE reductions (utils/losses.py:22-59,68-90,200-231 and the
  * CrossEntropyLoss at train_inherent_consistent_unet_3D_BraTS.py:107).  a is [B,nc,S] logits (or probabilities when

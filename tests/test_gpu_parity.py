@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on the MI355X box): HIP kernels through the C ABI vs the CPU oracle /
 the golden vectors captured from the reference.  Tolerances: 1e-3 relative on logits, 1e-4 on Dice
 (BASELINE.json north_star); kernel-level checks are much tighter (fp32 reassociation only)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -588,6 +590,49 @@ def test_trainer_step_with_factored_mlp2_gradients_matches_reference_golden(dev)
         w0 = torch.empty_like(a)
         fill_like_reference_init([(k, w0)])
         assert float(((a - w0) - (b - w0)).norm() / (b - w0).norm()) < 1e-3, k
+
+
+def test_data_parallel_graph_step_on_one_rank_group(dev):
+    """The data-parallel step as ICLTrainer.capture() records it — forward/backward graph with the gradients packed into flat
+    buffers, eager RCCL collectives, optimiser graph reading the reduced buffers — on a ONE-rank RCCL group (the mean over one
+    rank is the identity): 2 warm-up + 2 replayed steps must equal the single-GPU graph's."""
+    import torch.distributed as dist
+    from icl_amd import ops
+    from icl_amd.ddp import GradientReducer
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, 2).to(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        finals = []
+        for parallel in (False, True):
+            ops.StepRNG.tensor = None
+            model = unet_3D_icl(n_classes=2, in_channels=1, device=dev)
+            fill_like_reference_init(list(model.named_parameters()))
+            _parity_mode(model)
+            model.train()
+            red = GradientReducer(model, 1, force=True) if parallel else None
+            tr = ICLTrainer(model, ICLConfig(num_classes=2, labeled_bs=1, max_iterations=10), red)
+            tr.capture(vol, lab, warmup=2)
+            assert (tr.graph_update is not None) == parallel
+            losses = [tr.step(vol, lab)["loss"].clone() for _ in range(2)]
+            if parallel:
+                assert red._flat and len(red._fac) == 4           # one flat bucket, the four factored mlp2 gradients
+                small = [p for p in model.parameters() if p.grad is not None]
+                assert all(p.grad.data_ptr() >= red._flat[0][0].data_ptr() for p in small[:5])   # views into the bucket
+            finals.append((model.final.weight.detach().clone(), model.sspa.class_decoders[2].mlp2.fc1.weight.detach()[:64].clone(),
+                           [float(l) for l in losses]))
+            del tr, model, red
+            torch.cuda.empty_cache()
+        (w0, m0, l0), (w1, m1, l1) = finals
+        assert rel_err(w1.cpu(), w0.cpu()) < 1e-4 and rel_err(m1.cpu(), m0.cpu()) < 1e-4
+        assert np.allclose(l0, l1, rtol=5e-3), (l0, l1)
+    finally:
+        ops.StepRNG.tensor = None
+        dist.destroy_process_group()
 
 
 def test_graph_replay_equals_eager_steps(dev):

@@ -227,6 +227,28 @@ def test_drop_path_is_per_sample_and_consistent_in_backward():
     assert not torch.equal(ops.drop_path(x.detach(), 0.25, seed=78) != 0, y.detach() != 0)
 
 
+def test_drop_path_add_matches_separate_ops():
+    """res + drop_path(x) fused (also with res is x) equals the two-kernel form, forward and both gradients."""
+    x = _rand((6, 3, 5), 81, True)
+    r = _rand((6, 3, 5), 82, True)
+    gy = _rand((6, 3, 5), 83)
+    y = ops.drop_path_add(r, x, 0.4, seed=91)
+    y.backward(gy)
+    x2, r2 = x.detach().clone().requires_grad_(), r.detach().clone().requires_grad_()
+    y2 = r2 + ops.drop_path(x2, 0.4, seed=91)
+    y2.backward(gy)
+    assert torch.equal(y.detach(), y2.detach()) and torch.equal(x.grad, x2.grad) and torch.equal(r.grad, r2.grad)
+    assert 0 < int((x.grad == 0).all(dim=(1, 2)).sum()) < 6           # some samples dropped, some kept
+    q = _rand((6, 4), 84, True)
+    z = ops.drop_path_add(q, q, 0.4, seed=92)
+    z.backward(torch.ones_like(z))
+    q2 = q.detach().clone().requires_grad_()
+    z2 = q2 + ops.drop_path(q2, 0.4, seed=92)
+    z2.backward(torch.ones_like(z2))
+    assert torch.equal(z.detach(), z2.detach()) and torch.equal(q.grad, q2.grad)
+    assert torch.equal(ops.drop_path_add(r.detach(), x.detach(), 0.4, training=False), r.detach() + x.detach())
+
+
 def test_fused_sgd_matches_torch():
     from icl_amd.optim import FusedSGD
     torch.manual_seed(0)
