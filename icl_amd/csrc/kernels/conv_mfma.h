@@ -48,7 +48,14 @@ struct ConvGeom {
   int ksplit;  // Cin-chunk split across workgroups
   long x_bstride, y_bstride;  // batch strides in elements (channel stride is D*H*W)
   float* slab;  // ksplit > 1: partial outputs [ksplit][batch][Cout][D*H*W], summed (+bias) by splitk_reduce_kernel
+  int remap;    // 1: XCD-aware workgroup order (gridDim.x % 8 == 0), see xcd_chunked()
 };
+
+// Workgroups are handed to the eight XCDs round-robin (linear id % 8) and every XCD has its own L2: with tiles numbered in the
+// launch order, spatial neighbours — which share their halo — sit on different L2s.  This maps the physical blockIdx.x to a
+// logical index so that each XCD owns one contiguous eighth of the index range (valid when gridDim.x % 8 == 0, where
+// blockIdx.x % 8 is the XCD for every blockIdx.y/z).
+__device__ __forceinline__ int xcd_chunked(int bx, int nb) { return (bx & 7) * (nb >> 3) + (bx >> 3); }
 
 // Wp[tap'][k][n] (zero padded) from W[co][ci][tap]; mode 0 = forward (k=ci,n=co), 1 = dgrad (k=co,n=ci, tap flipped)
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,

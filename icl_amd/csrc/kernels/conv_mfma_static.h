@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma_fwd_static_kernel(const float
   float* Xs = lds;
   float* Ws = lds + KC * PS;
   const int ntiles = g.ntx * g.nty * g.ntz;
-  const int bt = blockIdx.x % ntiles;
-  const int ks = blockIdx.x / ntiles;
+  const int bx = g.remap ? xcd_chunked(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int bt = bx % ntiles;
+  const int ks = bx / ntiles;
   const int x0 = (bt % g.ntx) * TC::TX;
   const int y0 = ((bt / g.ntx) % g.nty) * TC::TY;
   const int z0 = (bt / (g.ntx * g.nty)) * TC::TZ;
@@ -314,13 +315,17 @@ __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kern
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int bt = blockIdx.x;
-  if (bt < ntiles) load_tile(bt);
-  for (; bt < ntiles; bt += gridDim.x) {
+  // each workgroup walks a contiguous run of tiles (x-neighbours back to back: their shared halo is still in L2), and with
+  // g.remap the runs of one XCD are contiguous too
+  const int lbx = g.remap ? xcd_chunked(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  int bt = (int)((long)lbx * ntiles / gridDim.x);
+  const int bt_end = (int)((long)(lbx + 1) * ntiles / gridDim.x);
+  if (bt < bt_end) load_tile(bt);
+  for (; bt < bt_end; ++bt) {
     __syncthreads();
     store_tile();
     __syncthreads();
-    if (bt + (int)gridDim.x < ntiles) load_tile(bt + gridDim.x);
+    if (bt + 1 < bt_end) load_tile(bt + 1);
     // one x-row of the tile (16 voxels = 4 k-steps) at a time: per operand ONE row base register and the four k-steps at
     // dword offsets 0/4/8/12, which the compiler pairs into ds_read2_b32 (8-bit dword offsets) — half the LDS instructions
 #pragma unroll

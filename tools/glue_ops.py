@@ -32,6 +32,7 @@ WATCH = ("aten::add", "aten::add_", "aten::sum", "aten::zeros", "aten::zero_", "
          "aten::uniform_", "aten::rand", "aten::rand_like", "aten::randn_like", "aten::normal_", "aten::cat", "aten::stack",
          "aten::sub", "aten::div", "aten::neg", "aten::index_select", "aten::to", "aten::_to_copy")
 counts = collections.Counter()
+times = collections.Counter()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for ev in prof.events():
     if ev.name not in WATCH or ev.device_type != torch.autograd.DeviceType.CPU:
@@ -57,9 +58,12 @@ for ev in prof.events():
         e2 = e2.cpu_parent
     shape = ""
     counts[(ev.name, frame)] += nk
+    def dev_time(e):
+        return sum(k.duration for k in e.kernels) + sum(dev_time(c) for c in e.cpu_children)
+    times[(ev.name, frame)] += dev_time(ev)
 tot = 0
 for (name, frame), n in counts.most_common(70):
     tot += n
-    print(f"{n:4d}  {name:18s} {frame}")
+    print(f"{n:4d}  {times[(name, frame)]:9.1f} us  {name:18s} {frame}")
 print("sample stack:", next((e.stack for e in prof.events() if e.stack), None))
 print("total launches from watched ops:", sum(counts.values()))
