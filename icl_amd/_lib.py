@@ -29,6 +29,7 @@ _SIGNATURES = {
     "icl_conv3d_packed_elems": (c_int64, [I, I, I, I]),
     "icl_conv3d_pack_weights": (c_int, [P, P, I, I, I, I, P]),
     "icl_conv3d_pack_weights_both": (c_int, [P, P, P, I, I, I, P]),
+    "icl_conv3d_pack_weights_multi": (c_int, [P, P, P, P, P, P, I, P]),
     "icl_conv3d_fwd_ws_bytes": (c_int64, [I, I, I, I, I, I, I]),
     "icl_conv3d_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, L, L, P]),
     "icl_conv3d_wgrad_ws_bytes": (c_int64, [I, I, I, I]),

@@ -94,6 +94,39 @@ __global__ __launch_bounds__(256) void pack_weights_both_kernel(const float* __r
   }
 }
 
+// Both packings of up to kPackMulti weights in ONE launch (grid.y = weight): the weights only change in the optimiser step, so a
+// training step packs every convolution weight once, up front, instead of one small launch per convolution call.
+constexpr int kPackMulti = 32;
+struct PackMulti {
+  const float* w[kPackMulti];
+  float* wp0[kPackMulti];
+  float* wp1[kPackMulti];
+  int cout[kPackMulti], cin[kPackMulti], taps[kPackMulti];
+};
+
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackMulti m) {
+  const int i = blockIdx.y;
+  const int Cout = m.cout[i], Cin = m.cin[i], T = m.taps[i];
+  const int KP0 = (Cin + 3) / 4 * 4, NP0 = (Cout + 15) / 16 * 16, KP1 = (Cout + 3) / 4 * 4, NP1 = (Cin + 15) / 16 * 16;
+  const float* __restrict__ w = m.w[i];
+  float* __restrict__ wp0 = m.wp0[i];
+  float* __restrict__ wp1 = m.wp1[i];
+  const long t0 = (long)T * KP0 * NP0, t1 = (long)T * KP1 * NP1;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < t0 + t1; e += (long)gridDim.x * blockDim.x) {
+    const bool dg = e >= t0;
+    const long f = dg ? e - t0 : e;
+    const int NP = dg ? NP1 : NP0, KP = dg ? KP1 : KP0;
+    const int n = (int)(f % NP);
+    const long t = f / NP;
+    const int k = (int)(t % KP);
+    const int tap = (int)(t / KP);
+    const int K = dg ? Cout : Cin, N = dg ? Cin : Cout;
+    float v = 0.f;
+    if (k < K && n < N) v = dg ? w[((long)k * Cin + n) * T + (T - 1 - tap)] : w[((long)n * Cin + k) * T + tap];
+    (dg ? wp1 : wp0)[f] = v;
+  }
+}
+
 // gW[co][ci][tap] = sum over slabs s of gWp[s][tap][ci][co]  (fixed summation order -> reproducible).
 // A workgroup owns 64 consecutive packed elements; its 4 waves take slabs s = wave, wave+4, ... so every slab
 // read is a coalesced 256-byte row, then the four partial sums are combined through LDS in wave order.

@@ -132,7 +132,25 @@ class BatchNormAct(nn.Module):
         self.register_buffer("running_var", torch.ones(c, device=device))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long, device=device))
 
+    # ICLTrainer collects the ``num_batches_tracked += 1`` of all BatchNorm layers of a step (18 one-element launches in the
+    # 3-D ICL model) into one multi-tensor add: ``deferred`` maps id(counter) -> [counter, increments] while a step is open.
+    deferred = None
+
+    @classmethod
+    def defer_counters(cls):
+        cls.deferred = {}
+
+    @classmethod
+    def flush_counters(cls):
+        pending, cls.deferred = cls.deferred, None
+        if pending:
+            torch._foreach_add_([t for t, _ in pending.values()], [n for _, n in pending.values()])
+
     def forward(self, x):
         if self.training:
-            self.num_batches_tracked += 1
+            d = BatchNormAct.deferred
+            if d is None:
+                self.num_batches_tracked += 1
+            else:
+                d.setdefault(id(self.num_batches_tracked), [self.num_batches_tracked, 0])[1] += 1
         return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.act)

@@ -118,6 +118,60 @@ def pack_weights(w: torch.Tensor, mode: int) -> torch.Tensor:
     return wp
 
 
+class PackedWeights:
+    """Step-level cache of the packed convolution weights (forward + dgrad layout).  The weights only change in the optimiser
+    step, so ICLTrainer brackets its iteration with ``begin_step()`` / ``end_step()``: the first iteration packs per call (as a
+    bare module does) and records which Parameters asked; every later ``begin_step()`` packs all of them in ONE launch into
+    persistent buffers (fixed addresses: the launch is part of the captured hipGraph).  Outside the bracket nothing is cached."""
+    current: Optional["PackedWeights"] = None
+
+    def __init__(self):
+        self.entries = {}     # id(parameter) -> [parameter, wp, wpt, valid]
+
+    def begin_step(self):
+        PackedWeights.current = self
+        live = list(self.entries.values())
+        if not live:
+            return
+        L = _lib.lib()
+        n = len(live)
+        arr = ctypes.c_void_p * n
+        iarr = ctypes.c_int32 * n
+        _lib.check(L.icl_conv3d_pack_weights_multi(arr(*[e[0].data_ptr() for e in live]), arr(*[e[1].data_ptr() for e in live]),
+                                                   arr(*[e[2].data_ptr() for e in live]), iarr(*[e[0].shape[0] for e in live]),
+                                                   iarr(*[e[0].shape[1] for e in live]), iarr(*[e[0].shape[2] for e in live]), n,
+                                                   _stream(live[0][0])), "pack_weights_multi")
+        for e in live:
+            e[3] = True
+
+    def end_step(self):
+        for e in self.entries.values():
+            e[3] = False
+        if PackedWeights.current is self:
+            PackedWeights.current = None
+
+    @staticmethod
+    def get(weight):
+        """(wp, wpt) of ``weight`` (contiguous [Cout, Cin, k, k, k]), packed now unless this step's begin_step() already did."""
+        L = _lib.lib()
+        cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
+        cache = PackedWeights.current if isinstance(weight, torch.nn.Parameter) else None
+        e = cache.entries.get(id(weight)) if cache is not None else None
+        if e is not None and e[0] is not weight:
+            e = None
+        if e is not None and e[3]:
+            return e[1], e[2]
+        if e is not None:
+            wp, wpt = e[1], e[2]
+        else:
+            wp = torch.empty(L.icl_conv3d_packed_elems(cout, cin, ks, 0), dtype=torch.float32, device=weight.device)
+            wpt = torch.empty(L.icl_conv3d_packed_elems(cout, cin, ks, 1), dtype=torch.float32, device=weight.device)
+        _lib.check(L.icl_conv3d_pack_weights_both(_ptr(weight), _ptr(wp), _ptr(wpt), cout, cin, ks, _stream(weight)), "pack_weights_both")
+        if cache is not None:
+            cache.entries[id(weight)] = [weight, wp, wpt, True]
+        return wp, wpt
+
+
 def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_bstride):
     L = _lib.lib()
     s = d * h * w
@@ -170,12 +224,9 @@ class _Conv3d(torch.autograd.Function):
             return y.view(n, cout, d, h, w)
         y = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
         ctx.wpt = None
-        if x.requires_grad and torch.is_grad_enabled():
+        if ctx.needs_input_grad[0]:
             # the input gradient will need the flipped/transposed packing too: one launch for both, kept for backward
-            L = _lib.lib()
-            wp = torch.empty(L.icl_conv3d_packed_elems(cout, cin, ks, 0), dtype=torch.float32, device=x.device)
-            ctx.wpt = torch.empty(L.icl_conv3d_packed_elems(cout, cin, ks, 1), dtype=torch.float32, device=x.device)
-            _lib.check(L.icl_conv3d_pack_weights_both(_ptr(weight), _ptr(wp), _ptr(ctx.wpt), cout, cin, ks, _stream(x)), "pack_weights_both")
+            wp, ctx.wpt = PackedWeights.get(weight)
         else:
             wp = pack_weights(weight, 0)
         conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, cin * s, y, cout * s)

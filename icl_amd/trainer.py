@@ -19,6 +19,7 @@ import torch
 from torch.nn.modules.loss import CrossEntropyLoss
 
 from . import ops
+from .networks.layers import BatchNormAct
 from .optim import FusedSGD
 from .utils import losses as L
 
@@ -51,6 +52,7 @@ class ICLTrainer:
             self.aux_loss = L.AuxLoss(cfg.num_classes, cfg.patch_size)
             self.pse_loss = L.PseudoSoftLoss(cfg.num_classes, cfg.patch_size)
         self.iter_num = 0
+        self.packed = ops.PackedWeights()
         self.graph = None
         self.graph_update = None
         self.lr_dev = None
@@ -69,17 +71,23 @@ class ICLTrainer:
     def _forward_backward(self, volume_batch, label_batch):
         cfg = self.cfg
         ops.StepRNG.begin_step()
+        self.packed.begin_step()        # every convolution weight packed once, in one launch (ops.PackedWeights)
         self.optimizer.zero_grad(set_to_none=True)
-        with ops.FactoredGrads(cfg.factored_mlp2_grads):
-            outputs = self.model(volume_batch[:cfg.labeled_bs], volume_batch[cfg.labeled_bs:])
-            loss, parts = self.compute_loss(outputs, label_batch)
-            loss.backward()
+        BatchNormAct.defer_counters()
+        try:
+            with ops.FactoredGrads(cfg.factored_mlp2_grads):
+                outputs = self.model(volume_batch[:cfg.labeled_bs], volume_batch[cfg.labeled_bs:])
+                loss, parts = self.compute_loss(outputs, label_batch)
+                loss.backward()
+        finally:
+            BatchNormAct.flush_counters()     # all num_batches_tracked increments of the step in one launch
         parts = {k: v.detach() for k, v in parts.items()}
         parts["loss"] = loss.detach()
         return parts
 
     def _apply_update(self):
         self.optimizer.step()
+        self.packed.end_step()
         ops.StepRNG.end_step()
 
     def _step_body(self, volume_batch, label_batch):

@@ -32,6 +32,10 @@ int64_t icl_conv3d_packed_elems(int cout, int cin, int ks, int mode);
 int icl_conv3d_pack_weights(const float* w, float* wp, int cout, int cin, int ks, int mode, void* stream);
 /* both packings (mode 0 into wp_fwd, mode 1 into wp_dgrad) in one launch — a training step needs both of every weight */
 int icl_conv3d_pack_weights_both(const float* w, float* wp_fwd, float* wp_dgrad, int cout, int cin, int ks, void* stream);
+/* Both packings of `count` weights in one launch per 32 weights (arrays of device pointers and of Cout / Cin / kernel size): the
+ * trainer packs every convolution weight of the model once per step (they only change in the optimiser), not once per call. */
+int icl_conv3d_pack_weights_multi(const void* const* w, void* const* wp_fwd, void* const* wp_dgrad, const int32_t* cout, const int32_t* cin,
+                                  const int32_t* ks, int count, void* stream);
 /* y[n, 0:cout] = conv(x[n, 0:cin], Wp) + bias (bias may be NULL).  dgrad: call with Wp packed in mode 1,
  * x = dY, cin/cout swapped, bias NULL.  Batch strides in elements; channel stride is D*H*W.
  * ws: icl_conv3d_fwd_ws_bytes(...) bytes (0 for most shapes): launches with too few output tiles to fill the chip

@@ -572,6 +572,9 @@ def test_trainer_step_with_factored_mlp2_gradients_matches_reference_golden(dev)
     assert np.allclose(got, g["losses"], rtol=0, atol=1e-4), (got, g["losses"])
     big = [k for k, p in model.named_parameters() if p.numel() >= (1 << 22)]
     assert len(big) == 4 and all(dict(model.named_parameters())[k].grad is None for k in big)   # never materialised
+    # BatchNorm step counters (one deferred multi-tensor add per step): sspa normalises both inputs, uscl one
+    counters = {k: int(b) for k, b in model.named_buffers() if k.endswith("num_batches_tracked")}
+    assert counters and all(v == (2 if k.startswith("sspa") else 1) for k, v in counters.items()), counters
     post = np.array([float(p.detach().double().norm()) for _, p in model.named_parameters()])
     names = [k for k, _ in model.named_parameters()]
     off = [(names[i], post[i], g["post_sgd_norms"][i]) for i in range(len(names))

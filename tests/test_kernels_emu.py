@@ -227,6 +227,37 @@ def test_drop_path_is_per_sample_and_consistent_in_backward():
     assert not torch.equal(ops.drop_path(x.detach(), 0.25, seed=78) != 0, y.detach() != 0)
 
 
+def test_packed_weight_cache_repacks_all_weights_in_one_launch():
+    """ops.PackedWeights: first bracketed step packs per call and records the Parameters, later begin_step() calls repack all of
+    them at once (after an in-place weight update, as FusedSGD does) — results equal the uncached path, gradients included."""
+    ws = [torch.nn.Parameter(_rand((5, 3, 3, 3, 3), 101) * 0.2), torch.nn.Parameter(_rand((20, 5, 3, 3, 3), 102) * 0.2),
+          torch.nn.Parameter(_rand((4, 20, 1, 1, 1), 103) * 0.2)]
+    x = _rand((2, 3, 6, 5, 7), 104, True)
+
+    def run():
+        x.grad = None
+        for w in ws:
+            w.grad = None
+        h = x
+        for w in ws:
+            h = ops.conv3d(h, w, None)
+        h.backward(torch.ones_like(h))
+        return h.detach().clone(), x.grad.clone(), [w.grad.clone() for w in ws]
+
+    cache = ops.PackedWeights()
+    for step in range(3):
+        ref = run()                                   # uncached: packs per call
+        cache.begin_step()
+        got = run()
+        cache.end_step()
+        assert ops.PackedWeights.current is None and len(cache.entries) == 3
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        assert all(torch.equal(a, b) for a, b in zip(got[2], ref[2]))
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(0.9).add_(0.01)                # the weights change between steps
+
+
 def test_drop_path_add_matches_separate_ops():
     """res + drop_path(x) fused (also with res is x) equals the two-kernel form, forward and both gradients."""
     x = _rand((6, 3, 5), 81, True)
