@@ -84,9 +84,9 @@ def test_instance_norm_relu(shape):
     assert rel_err(x.grad, xr.grad) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 4, 4, 4, 6), (3, 4, 12, 24, 20)])   # one workgroup per channel / chunked two-launch path
 @pytest.mark.parametrize("training", [True, False])
-def test_batch_norm_relu(training):
-    shape = (3, 4, 4, 4, 6)
+def test_batch_norm_relu(training, shape):
     x = (_rand(shape, 7) + 0.3).requires_grad_()
     ga = (1 + 0.1 * _rand((4,), 8)).requires_grad_()
     be = (0.1 * _rand((4,), 9)).requires_grad_()
