@@ -210,6 +210,13 @@ def main():
                                  "hbm_frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
                     "per_kernel": {k: {"launches_per_step": v[0] // 3, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
                                        "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(conv.items())}}
+            sg = summ.get("sgd_factored_kernel")
+            if sg:   # the largest single kernel of the U-Net step by time: the factored SGD update of the four 13,824^2 matrices
+                gbs = sg[3] / (sg[1] * 1e-3) / 1e9
+                roof["sgd_factored_update"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                               "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": sg[0] // 3,
+                                               "avg_launch_us": round(sg[1] * 1e3 / sg[0], 2),
+                                               "algorithmic_bytes_per_launch": int(sg[3] / sg[0])}
             wa = {k: v for k, v in summ.items() if k.startswith("window_attn")}
             if wa:   # SwinUNETR: the fused window-attention kernels (fp32 MFMA), forward and backward (dQKV + bias gradient)
                 roof["window_attention"] = {k: {"launches_per_step": v[0] // 3, "ms_per_step": round(v[1] / 3, 3),

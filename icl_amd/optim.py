@@ -48,8 +48,10 @@ class FusedSGD(torch.optim.Optimizer):
         stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream) if p.is_cuda else None
         lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
         g, x = g.contiguous(), x.contiguous()
-        _lib.check(L.icl_sgd_step_factored(p.data_ptr(), m.data_ptr(), g.data_ptr(), x.data_ptr(), g.shape[0], n, k, lr, mom, wd,
-                                           first, lrp, stream), "sgd_step_factored")
+        from . import ops   # KernelTimer bracket: the update streams p and m in and out (16 B per weight), HBM-bound
+        with ops._timed("sgd_factored_kernel", 2.0 * g.shape[0] * n * k, 16.0 * n * k, p):
+            _lib.check(L.icl_sgd_step_factored(p.data_ptr(), m.data_ptr(), g.data_ptr(), x.data_ptr(), g.shape[0], n, k, lr, mom, wd,
+                                               first, lrp, stream), "sgd_step_factored")
 
     @torch.no_grad()
     def step(self, closure=None):
