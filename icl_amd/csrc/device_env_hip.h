@@ -27,6 +27,16 @@ __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 // tell the compiler a value is the same in every lane of the wave (lets it use SGPRs / scalar loads for what depends on it)
 #define ICL_WAVE_UNIFORM(x) ((x) = __builtin_amdgcn_readfirstlane(x))
 
+// non-temporal 16-byte accesses for streams that are touched once per launch (optimiser state): keep them out of L2 / MALL
+__device__ __forceinline__ float4 icl_nt_load4(const float* p) {
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void icl_nt_store4(float* p, float4 v) {
+  const f32x4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(p));
+}
+
 #define ICL_DYN_LDS(type, name)                                              \
   extern __shared__ __attribute__((aligned(16))) unsigned char icl_dyn_lds_raw[]; \
   type* name = reinterpret_cast<type*>(icl_dyn_lds_raw)

@@ -77,6 +77,10 @@ constexpr int kSvRows = 16, kSvCols = 256, kSvChunk = 32;
 
 // Variant for M <= 32 factor rows (one rank): plain VALU FMAs, no transposition step.
 // grid (ceil(K/256), ceil(N/16)), block 256: thread = float4 column kq (0..63) x row lane rl (rows 4*rl .. 4*rl+3).  K % 4 == 0.
+// V: 0 = load p / m after the products, 1 = issue the p / m loads first (their HBM latency overlaps the staging and the FMAs),
+//    2 = as 1 with non-temporal loads and stores (the default: p and m are touched once per step; 13,824^2, M = 8:
+//    567 / 553 / 502 us = 5.4 / 5.5 / 6.1 TB/s, tools/sgd_probe.py).
+template <int V>
 __global__ __launch_bounds__(256) void sgd_factored_small_kernel(float* __restrict__ p, float* __restrict__ mom, const float* __restrict__ g,
                                                            const float* __restrict__ x, int M, int N, int K, float lr, float momentum,
                                                            float wd, int first, const float* __restrict__ lr_dev) {
@@ -88,6 +92,20 @@ __global__ __launch_bounds__(256) void sgd_factored_small_kernel(float* __restri
   float4 acc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pv[4], mv[4];
+  const bool col_ok = k0 + kq * 4 < K;
+  if (V >= 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + rl * 4 + r;
+      pv[r] = mv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col_ok && n < N) {
+        const long idx = (long)n * K + k0 + kq * 4;
+        pv[r] = V == 2 ? icl_nt_load4(p + idx) : *reinterpret_cast<const float4*>(p + idx);
+        if (!first) mv[r] = V == 2 ? icl_nt_load4(mom + idx) : *reinterpret_cast<const float4*>(mom + idx);
+      }
+    }
+  }
   for (int m0 = 0; m0 < M; m0 += kSvChunk) {
     __syncthreads();
     for (int it = threadIdx.x; it < kSvChunk * (kSvCols / 4); it += 256) {
@@ -111,17 +129,24 @@ __global__ __launch_bounds__(256) void sgd_factored_small_kernel(float* __restri
       }
     }
   }
-  if (k0 + kq * 4 >= K) return;
+  if (!col_ok) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + rl * 4 + r;
     if (n >= N) continue;
     const long idx = (long)n * K + k0 + kq * 4;
-    float4 pv = *reinterpret_cast<float4*>(p + idx);
-    float4 mv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(mom + idx);
-    sgd_update4(pv, acc[r], mv, lr, momentum, wd, first);
-    *reinterpret_cast<float4*>(p + idx) = pv;
-    *reinterpret_cast<float4*>(mom + idx) = mv;
+    if (V == 0) {
+      pv[r] = *reinterpret_cast<float4*>(p + idx);
+      mv[r] = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(mom + idx);
+    }
+    sgd_update4(pv[r], acc[r], mv[r], lr, momentum, wd, first);
+    if (V == 2) {
+      icl_nt_store4(p + idx, pv[r]);
+      icl_nt_store4(mom + idx, mv[r]);
+    } else {
+      *reinterpret_cast<float4*>(p + idx) = pv[r];
+      *reinterpret_cast<float4*>(mom + idx) = mv[r];
+    }
   }
 }
 
@@ -152,21 +177,41 @@ __global__ __launch_bounds__(256) void sgd_factored_kernel(float* __restrict__ p
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the factor slices of chunk c+1 are fetched into registers before the MFMAs of chunk c (8 float4 of x, 8 floats of g per thread)
+  constexpr int XV = kSfChunk * (kSfCols / 4) / 256, GV = kSfChunk * kSfRows / 256;
+  float4 xv[XV];
+  float gv[GV];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int it = threadIdx.x + j * 256;
+      const int m = it / (kSfCols / 4), q = it % (kSfCols / 4);
+      xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + m < M && k0 + q * 4 < K) xv[j] = *reinterpret_cast<const float4*>(x + (long)(m0 + m) * K + k0 + q * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int it = threadIdx.x + j * 256;
+      const int m = it / kSfRows, r = it % kSfRows;
+      gv[j] = (m0 + m < M && n0 + r < N) ? g[(long)(m0 + m) * N + n0 + r] : 0.f;
+    }
+  };
+  fetch(0);
   for (int m0 = 0; m0 < M; m0 += kSfChunk) {
     __syncthreads();
-    for (int it = threadIdx.x; it < kSfChunk * (kSfCols / 4); it += 256) {
-      const int m = it / (kSfCols / 4), q = it % (kSfCols / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + m < M && k0 + q * 4 < K) v = *reinterpret_cast<const float4*>(x + (long)(m0 + m) * K + k0 + q * 4);
-      *reinterpret_cast<float4*>(xs + m * kSfXp + q * 4) = v;
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int it = threadIdx.x + j * 256;
+      *reinterpret_cast<float4*>(xs + (it / (kSfCols / 4)) * kSfXp + (it % (kSfCols / 4)) * 4) = xv[j];
     }
-    for (int it = threadIdx.x; it < kSfChunk * kSfRows; it += 256) {
-      const int m = it / kSfRows, r = it % kSfRows;
-      gs[m * kSfGp + r] = (m0 + m < M && n0 + r < N) ? g[(long)(m0 + m) * N + n0 + r] : 0.f;
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int it = threadIdx.x + j * 256;
+      gs[(it / kSfRows) * kSfGp + it % kSfRows] = gv[j];
     }
     __syncthreads();
-    const int steps = ((M - m0 < kSfChunk ? M - m0 : kSfChunk) + 3) / 4;   // rows past M are zero in LDS
-    for (int s = 0; s < steps; ++s) {
+    if (m0 + kSfChunk < M) fetch(m0 + kSfChunk);
+    auto kstep = [&](int s) {
       float av[4], bv[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) av[a] = gs[(s * 4 + lg) * kSfGp + a * 16 + lr_];
@@ -176,6 +221,13 @@ __global__ __launch_bounds__(256) void sgd_factored_kernel(float* __restrict__ p
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = icl_mfma_16x16x4(av[a], bv[b], acc[a][b]);
+    };
+    if (M - m0 >= kSfChunk) {   // full chunk: straight-line code, operand reads of step s+1 under the MFMAs of step s
+#pragma unroll
+      for (int s = 0; s < kSfChunk / 4; ++s) kstep(s);
+    } else {
+      const int steps = (M - m0 + 3) / 4;   // rows past M are zero in LDS
+      for (int s = 0; s < steps; ++s) kstep(s);
     }
   }
   // d block -> LDS (row-major), then the streaming update
@@ -189,16 +241,29 @@ __global__ __launch_bounds__(256) void sgd_factored_kernel(float* __restrict__ p
   __syncthreads();
   const int kq = threadIdx.x & 63, rl = threadIdx.x >> 6;
   if (k0 + kq * 4 >= K) return;
-  for (int row = rl; row < kSfRows; row += 4) {
-    const int n = n0 + row;
-    if (n >= N) break;
-    const long idx = (long)n * K + k0 + kq * 4;
-    const float4 d = *reinterpret_cast<const float4*>(lds + row * kSfDp + kq * 4);
-    float4 pv = *reinterpret_cast<float4*>(p + idx);
-    float4 mv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(mom + idx);
-    sgd_update4(pv, d, mv, lr, momentum, wd, first);
-    *reinterpret_cast<float4*>(p + idx) = pv;
-    *reinterpret_cast<float4*>(mom + idx) = mv;
+  // four rows per thread in flight: 8 x 16 B of loads per lane (two workgroups per CU -> 64 KB per CU, enough to keep HBM streaming)
+  for (int row0 = rl; row0 < kSfRows; row0 += 16) {
+    float4 pv[4], mv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + row0 + 4 * j;
+      pv[j] = mv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) {
+        const long idx = (long)n * K + k0 + kq * 4;
+        pv[j] = icl_nt_load4(p + idx);   // p and m are touched once per step: non-temporal, as in the small variant (+10 % there)
+        if (!first) mv[j] = icl_nt_load4(mom + idx);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = row0 + 4 * j, n = n0 + row;
+      if (n >= N) continue;
+      const long idx = (long)n * K + k0 + kq * 4;
+      const float4 d = *reinterpret_cast<const float4*>(lds + row * kSfDp + kq * 4);
+      sgd_update4(pv[j], d, mv[j], lr, momentum, wd, first);
+      icl_nt_store4(p + idx, pv[j]);
+      icl_nt_store4(mom + idx, mv[j]);
+    }
   }
 }
 

@@ -13,7 +13,7 @@ N = K = 13824
 p = torch.randn(N, K, device=dev)
 m = torch.zeros_like(p)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for M in (8, 16, 24, 64, 128, 192, 512, 1024):
+for M in [int(a) for a in sys.argv[1:]] or (8, 16, 24, 64, 128, 192, 512, 1024):
     g = torch.randn(M, N, device=dev) * 1e-3
     x = torch.randn(M, K, device=dev)
     def run():
