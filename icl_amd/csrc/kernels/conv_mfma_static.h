@@ -208,10 +208,14 @@ struct WgradTileT {
 // NCB = 16-cout blocks per workgroup (1..3): every staged x value (the B operand, one LDS read per tap) then feeds NCB MFMAs,
 // as the forward kernel does with NBT — (4 NCB + 28) LDS dwords per 28 NCB MFMAs, and the x halo tile is re-staged NCB times
 // less often.
-template <class TC, int WV, int NCB>
+// TGN = tap groups (4 or 8): with 8 waves and TGN = 8 every wave owns 3-4 taps of ALL rows instead of 7 taps of half the rows
+// (12 accumulator registers less per cout block; with one cout block the kernel then fits 124 registers, i.e. four waves per SIMD,
+// without spilling: 79 vs 74 TFLOP/s on 16->16 @96^3).  Interleaving the k-steps of two taps to break the dependent-accumulator
+// chains (40 instead of 32 cycles) was measured slower: the other waves of the SIMD already fill those gaps.
+template <class TC, int WV, int NCB, int TGN = 4>
 __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                               float* __restrict__ gwp, ConvGeom g) {
-  constexpr int T = 27, NTW = 7, TG = 4, NT = 64 * WV, HALVES = WV / 4, MB = 16 * NCB;
+  constexpr int T = 27, NTW = (27 + TGN - 1) / TGN, TG = TGN, NT = 64 * WV, HALVES = WV / TGN, MB = 16 * NCB;
   constexpr int PS = TC::PS, PXL = TC::PXL, PY = TC::PY, PZ = TC::PZ, MT = TC::MT, MTP = TC::MTP;
   constexpr int NP = TC::NP, CPP = TC::CPP, Q = TC::Q;
   constexpr int JX = (CPP * TC::PER_CH + NT - 1) / NT;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kern
   const float* xb = x + (long)blockIdx.z * g.x_bstride;
   const float* gb = gy + (long)blockIdx.z * g.y_bstride;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int tg = wid & 3, half = wid >> 2;
+  const int tg = wid % TGN, half = wid / TGN;
   const int lq = lane >> 4, lr = lane & 15;
   const int ntiles = g.ntz * g.nty * g.ntx;
 
