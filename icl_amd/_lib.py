@@ -58,6 +58,7 @@ _SIGNATURES = {
     "icl_gather_rows": (c_int, [P, P, P, L, L, L, I, P]),
     "icl_gather_rows_sum2": (c_int, [P, P, P, L, L, L, I, P]),
     "icl_im2col3": (c_int, [P, P, I, I, I, I, I, P]),
+    "icl_im2col3_planes": (c_int, [P, P, I, I, I, I, I, P]),
     "icl_col2im3": (c_int, [P, P, I, I, I, I, I, P]),
     "icl_linear_wgrad_ws_bytes": (c_int64, [L, I, I]),
     "icl_linear_wgrad": (c_int, [P, P, P, P, P, L, I, I, P]),

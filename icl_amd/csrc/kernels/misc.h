@@ -143,6 +143,34 @@ __global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ 
   }
 }
 
+// Channel-major variant for the FIRST convolution (Cin = 1..2 on a big volume): planes[b][ci*27 + tap][v] = x[b][ci][v + offset(tap)].
+// With one input channel the implicit-GEMM weight gradient pads Cin to 16 and spends 300 us on 0.8 GFLOP; as 27 shifted planes
+// the same gradient is the HBM-bound 1x1x1 reduction  dW[co][tap] = sum_v gy[co][v] * planes[tap][v]  (conv1x1_wgrad_kernel).
+// One thread per four consecutive v (W % 4 == 0): 16-byte stores.
+__global__ __launch_bounds__(256) void im2col3_planes_kernel(const float* __restrict__ x, float* __restrict__ planes, int N, int C, int D,
+                                                             int H, int W) {
+  const long S = (long)D * H * W, S4 = S >> 2;
+  const long total = (long)N * C * 27 * S4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long v = (e % S4) << 2;
+    const long r = e / S4;
+    const int tap = (int)(r % 27);
+    const long bc = r / 27;
+    const int ox = (int)(v % W), oy = (int)((v / W) % H), oz = (int)(v / ((long)W * H));
+    const int z = oz + tap / 9 - 1, yy = oy + (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (z >= 0 && z < D && yy >= 0 && yy < H) {
+      const float* row = x + bc * S + ((long)z * H + yy) * W;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int xx = ox + k + dx;
+        if (xx >= 0 && xx < W) o[k] = row[xx];
+      }
+    }
+    *reinterpret_cast<float4*>(planes + r * S + v) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // dx[b][ci][u] = sum_tap g[b*S + (u - offset(tap))][ci*27 + tap]   (exact transpose of im2col3)
 __global__ __launch_bounds__(256) void col2im3_kernel(const float* __restrict__ g, float* __restrict__ dx, int N, int C, int D, int H, int W) {
   const long S = (long)D * H * W, K = (long)C * 27, total = (long)N * C * S;

@@ -7,6 +7,7 @@ Each function cites the reference operator it replaces (paths relative to /root/
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -197,6 +198,7 @@ def _cached_zeros(n: int, device) -> torch.Tensor:
 
 
 CONV1X1_WGRAD_MIN_VOXELS = 4096
+FIRST_CONV_PLANES_MAX_K = int(os.environ.get("ICL_FIRST_CONV_PLANES_K", "32"))      # Cin * 27 <= 32, i.e. one input channel
 CONV1X1_GEMM_MIN_VOXELS = 65536
 
 
@@ -267,6 +269,15 @@ class _Conv3d(torch.autograd.Function):
                 with _timed("conv1x1_wgrad_kernel", flops, nbytes, x):
                     _lib.check(L.icl_conv1x1_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin, cout, s, cin * s,
                                                    cout * s, _stream(x)), "conv1x1_wgrad")
+            elif ks == 3 and cin * 27 <= FIRST_CONV_PLANES_MAX_K and w % 4 == 0 and n * s >= CONV1X1_WGRAD_MIN_VOXELS * 64:
+                # first convolution (one input channel, big volume): 27 shifted planes + the same HBM-bound reduction; the implicit
+                # GEMM pads Cin to 16 and takes 300 us for 0.8 GFLOP (batch 2, 96^3), this takes ~130
+                planes = torch.empty((n, cin * 27, s), dtype=torch.float32, device=x.device)
+                _lib.check(L.icl_im2col3_planes(_ptr(x), _ptr(planes), n, cin, d, h, w, _stream(x)), "im2col3_planes")
+                ws = _ws(L.icl_conv1x1_wgrad_ws_bytes(n, s, cin * 27, cout), x)
+                with _timed("conv1x1_wgrad_kernel", flops, nbytes, x):
+                    _lib.check(L.icl_conv1x1_wgrad(_ptr(planes), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin * 27, cout, s,
+                                                   cin * 27 * s, cout * s, _stream(x)), "conv1x1_wgrad")
             else:
                 ws = _ws(L.icl_conv3d_wgrad_ws_bytes(n, cin, cout, ks), x)
                 with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):

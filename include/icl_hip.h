@@ -155,6 +155,9 @@ int icl_gather_rows_sum2(const float* src, const int32_t* idx2, float* out, int6
  * cols [n*S, c*27] with cols[b*S+v][ci*27+tap] = x[b][ci][v+offset(tap)] (zero padded), y = cols * W[cout, c*27]^T on the
  * library GEMM.  col2im3 is the exact transpose (input gradient from d(cols)). */
 int icl_im2col3(const float* x, float* cols, int n, int c, int d, int h, int w, void* stream);
+/* planes[b][ci*27 + tap][v] = x[b][ci][v + offset(tap)] (zero outside), w % 4 == 0: the first convolution's weight gradient
+ * (Cin = 1: networks/unet_3D.py:27, utils.py:104) as icl_conv1x1_wgrad over 27 shifted planes instead of a Cin-padded implicit GEMM. */
+int icl_im2col3_planes(const float* x, float* planes, int n, int c, int d, int h, int w, void* stream);
 int icl_col2im3(const float* g, float* dx, int n, int c, int d, int h, int w, void* stream);
 
 /* ---- ConvTranspose3d(kernel 2, stride 2, no bias) = GEMM + depth-to-space (MONAI UnetrUpBlock.transp_conv in SwinUNETR,

@@ -427,6 +427,14 @@ def test_conv1x1_wgrad_big_volume_path(n, cin, cout, d, h, w):
     _conv_check(n, cin, cout, d, h, w, 1)
 
 
+@pytest.mark.parametrize("n,cout,d,h,w", [(2, 16, 5, 7, 12), (1, 20, 4, 6, 8)])
+def test_first_conv_weight_gradient_through_shifted_planes(monkeypatch, n, cout, d, h, w):
+    """One input channel on a big volume: the weight gradient runs as 27 shifted planes + the 1x1x1 reduction (threshold lowered
+    so that the emulator reaches that branch)."""
+    monkeypatch.setattr(ops, "CONV1X1_WGRAD_MIN_VOXELS", 1)
+    _conv_check(n, 1, cout, d, h, w, 3)
+
+
 def test_conv1x1_big_volume_runs_as_batched_gemm(monkeypatch):
     """>= 65536 voxels: forward / input gradient of a 1x1x1 convolution are one batched library GEMM (with and without bias)."""
     monkeypatch.setattr(ops, "CONV1X1_GEMM_MIN_VOXELS", 4096)
