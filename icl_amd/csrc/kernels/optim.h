@@ -186,14 +186,18 @@ __global__ __launch_bounds__(256) void sgd_factored_kernel(float* __restrict__ p
     for (int j = 0; j < XV; ++j) {
       const int it = threadIdx.x + j * 256;
       const int m = it / (kSfCols / 4), q = it % (kSfCols / 4);
-      xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + m < M && k0 + q * 4 < K) xv[j] = *reinterpret_cast<const float4*>(x + (long)(m0 + m) * K + k0 + q * 4);
+      // branch-free: out-of-range items load element 0 and are zeroed afterwards, so the loads issue back to back
+      const bool ok = m0 + m < M && k0 + q * 4 < K;
+      xv[j] = *reinterpret_cast<const float4*>(x + (ok ? (long)(m0 + m) * K + k0 + q * 4 : 0L));
+      if (!ok) xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int j = 0; j < GV; ++j) {
       const int it = threadIdx.x + j * 256;
       const int m = it / kSfRows, r = it % kSfRows;
-      gv[j] = (m0 + m < M && n0 + r < N) ? g[(long)(m0 + m) * N + n0 + r] : 0.f;
+      const bool ok = m0 + m < M && n0 + r < N;
+      gv[j] = g[ok ? (long)(m0 + m) * N + n0 + r : 0L];
+      if (!ok) gv[j] = 0.f;
     }
   };
   fetch(0);
