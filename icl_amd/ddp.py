@@ -39,8 +39,9 @@ class GradientReducer:
         self._handles = []
         self._early = set()
         self._flat = []          # [(flat buffer, [params])]
-        self._fac = []           # [(param, g_scaled, x, G_all, X_all)]
+        self._fac = []           # [(param, G_all, X_all)]
         self._avg = dist.is_initialized() and dist.get_backend() == "nccl"   # RCCL averages in the collective
+        self._send = self._recv = None   # all factor rows of a step, packed / gathered
         if world_size > 1:
             for p in self.params:
                 if p.numel() >= overlap_min_elems:
@@ -89,17 +90,21 @@ class GradientReducer:
             else:
                 self._flat.append((torch.cat([p.grad.reshape(-1) for p in bucket]), bucket))
         inv = 1.0 / self.world
+        pieces = []
         for p in self.params:
             fac = getattr(p, "_icl_factors", None)
             if not fac:
                 continue
             g = fac[0][0] if len(fac) == 1 else torch.cat([f[0] for f in fac], 0)
             x = fac[0][1] if len(fac) == 1 else torch.cat([f[1] for f in fac], 0)
-            g = (g * inv).contiguous()
-            x = x.contiguous()
             G = torch.empty((self.world * g.shape[0], g.shape[1]), dtype=g.dtype, device=g.device)
             X = torch.empty((self.world * x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
-            self._fac.append((p, g, x, G, X))
+            self._fac.append((p, G, X))
+            pieces += [(g * inv).reshape(-1), x.reshape(-1)]
+        self._send = self._recv = None
+        if pieces:   # ONE exchange for all factor rows of the step: [g_1/W | x_1 | g_2/W | x_2 | ...]
+            self._send = torch.cat(pieces)
+            self._recv = torch.empty(self.world * self._send.numel(), dtype=self._send.dtype, device=self._send.device)
 
     def communicate(self):
         """The collectives on the packed buffers (every rank must hold the same set of non-None grads and the same number of
@@ -112,19 +117,34 @@ class GradientReducer:
             dist.all_reduce(flat, op=op)
             if not self._avg:
                 flat.mul_(inv)
-        for _, g, x, G, X in self._fac:
+        if self._send is not None:
             if self._avg:     # RCCL: one contiguous gather
-                dist.all_gather_into_tensor(G, g)
-                dist.all_gather_into_tensor(X, x)
+                dist.all_gather_into_tensor(self._recv, self._send)
             else:
-                dist.all_gather(list(G.chunk(self.world, 0)), g)
-                dist.all_gather(list(X.chunk(self.world, 0)), x)
+                dist.all_gather(list(self._recv.chunk(self.world, 0)), self._send)
         for h, p in self._handles:
             h.wait()
             if not self._avg:
                 p.grad.mul_(inv)
         self._handles.clear()
         self._early.clear()
+
+    def unpack(self):
+        """Device-side, after ``communicate()``: the gathered block [rank][g_1 | x_1 | g_2 | ...] is split into the per-matrix row
+        blocks [g_i of rank 0; g_i of rank 1; ...] that ``sgd_factored_kernel`` reads (one multi-tensor copy)."""
+        if self._send is None:
+            return
+        t = self._send.numel()
+        recv = self._recv.view(self.world, t)
+        dsts, srcs, off = [], [], 0
+        for _, G, X in self._fac:
+            for buf in (G, X):
+                n = buf.numel() // self.world
+                dsts.append(buf.view(self.world, n))
+                srcs.append(recv[:, off:off + n])
+                off += n
+        assert off == t
+        torch._foreach_copy_(dsts, srcs)
 
     def rebind(self):
         """``p.grad`` becomes a view into its bucket's reduced buffer (no copy back) and ``p._icl_factors`` the gathered rows."""
@@ -136,7 +156,7 @@ class GradientReducer:
                 n = p.grad.numel()
                 p.grad = flat[off:off + n].view_as(p)
                 off += n
-        for p, _, _, G, X in self._fac:
+        for p, G, X in self._fac:
             p._icl_factors = [(G, X)]
 
     def reduce_gradients(self):
@@ -145,6 +165,8 @@ class GradientReducer:
             return
         self.pack()
         self.communicate()
+        self.unpack()
         self.rebind()
         if not self.static:
             self._flat, self._fac = [], []
+            self._send = self._recv = None

@@ -835,7 +835,7 @@ class FactoredGrads:
     Off (the default), ``weight.grad`` is a dense tensor as usual, e.g. for ``torch.optim.SGD`` in the reference trainers."""
 
     enabled = False
-    min_elems = 1 << 22
+    min_elems = 1 << 21      # the four 13,824^2 and the four 1,728^2 token-axis matrices of the 3-D ICL models
     max_rows = 512
 
     def __init__(self, on: bool = True):

@@ -165,6 +165,7 @@ class ICLTrainer:
             ddp.rebind()
             update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(update, pool=graph.pool(), **mode):
+                ddp.unpack()
                 self._apply_update()
             self.graph_update = update
         self.graph = graph
