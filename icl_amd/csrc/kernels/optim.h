@@ -245,12 +245,16 @@ __global__ __launch_bounds__(256) void sgd_factored_kernel(float* __restrict__ p
   __syncthreads();
   const int kq = threadIdx.x & 63, rl = threadIdx.x >> 6;
   if (k0 + kq * 4 >= K) return;
-  // four rows per thread in flight: 8 x 16 B of loads per lane (two workgroups per CU -> 64 KB per CU, enough to keep HBM streaming)
-  for (int row0 = rl; row0 < kSfRows; row0 += 16) {
-    float4 pv[4], mv[4];
+  // eight rows of the thread in flight at once (16 x 16 B of loads per lane; sixteen would cost the second wave per SIMD): the
+  // waves of this kernel spent 54 % of their life waiting on these loads (PMC) with only two workgroups per CU to cover for
+  // each other, so fewer, deeper round trips
+  constexpr int RB = 8;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + row0 + 4 * j;
+  for (int j0 = 0; j0 < kSfRows / 4; j0 += RB) {
+    float4 pv[RB], mv[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int n = n0 + rl + 4 * (j0 + j);
       pv[j] = mv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (n < N) {
         const long idx = (long)n * K + k0 + kq * 4;
@@ -259,8 +263,8 @@ __global__ __launch_bounds__(256) void sgd_factored_kernel(float* __restrict__ p
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = row0 + 4 * j, n = n0 + row;
+    for (int j = 0; j < RB; ++j) {
+      const int row = rl + 4 * (j0 + j), n = n0 + row;
       if (n >= N) continue;
       const long idx = (long)n * K + k0 + kq * 4;
       const float4 d = *reinterpret_cast<const float4*>(lds + row * kSfDp + kq * 4);
