@@ -61,6 +61,19 @@ __device__ __forceinline__ void wa_stage_rows(float* dst, const float* __restric
   }
 }
 
+// Region ids of one window into LDS (0 where unmasked / padding).  `mixed` (one LDS word, cleared by the caller before the
+// barrier that precedes this call) is raised when the window holds more than one region: most shifted windows are interior
+// ones with a single region (216 of 343 at the 48^3 stage), and for those the per-score compare/select — a third of the
+// softmax's VALU work — is skipped altogether.
+__device__ __forceinline__ void wa_stage_regions(int* rid, int* mixed, const int* __restrict__ regions, long win_off, int n, int npad) {
+  const int first = regions ? regions[win_off] : 0;
+  for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+    const int v = (regions && i < n) ? regions[win_off + i] : 0;
+    rid[i] = v;
+    if (regions && i < n && v != first) *mixed = 1;
+  }
+}
+
 // The DH values a lane contributes to a DH-deep contraction: dims 16*u + 4*lg + t (u < DH/16, t < 4) — MFMA step 4u + t.
 template <int DH> struct WaFrag {
   float v[DH / 4];
@@ -144,7 +157,10 @@ __global__ __launch_bounds__(256) void relpos_bias_scatter_kernel(const float* _
 }
 
 // grid = B_ * heads workgroups of kWaThreads threads; LDS = (2 * npad * (DH + 4) + npad) * 4 bytes.
-template <int NKB, int DH>
+// EXACT: the window has exactly NKB key blocks (343 tokens -> 22, 216 -> 14): the per-block guards compile away and the whole
+// query-block body becomes straight-line code, so the bias loads and K/V operand reads of later key blocks are issued under
+// the MFMAs of earlier ones (with the guards every key block was its own basic block: load, wait, four MFMAs).
+template <int NKB, int DH, bool EXACT>
 __global__ __launch_bounds__(kWaThreads) void window_attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
                                                               const int* __restrict__ regions, float* __restrict__ out,
                                                               float* __restrict__ lse, WinAttnGeom g) {
@@ -159,9 +175,12 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_fwd_kernel(const float
   const float* base = qkv + (long)b_ * g.n * rs + h * DH;
   wa_stage_rows<DH>(Ks, base + C, rs, g.n, g.npad, 1.f);
   wa_stage_rows<DH>(Vs, base + 2 * C, rs, g.n, g.npad, 1.f);
-  const bool masked = regions != nullptr;
-  for (int i = threadIdx.x; i < g.npad; i += blockDim.x) rid[i] = (masked && i < g.n) ? regions[(long)(b_ % g.nW) * g.n + i] : 0;
+  __shared__ int mixed;
+  if (threadIdx.x == 0) mixed = 0;
   __syncthreads();
+  wa_stage_regions(rid, &mixed, regions, (long)(b_ % g.nW) * g.n, g.n, g.npad);
+  __syncthreads();
+  const bool masked = regions != nullptr && mixed != 0;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   for (int qb = wid; qb < nkb; qb += kWaWaves) {
     const int query = qb * 16 + lr, qc = query < g.n ? query : g.n - 1;
@@ -173,7 +192,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_fwd_kernel(const float
     float m = -3.0e38f;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      if (kb < nkb) {
+      if (EXACT || kb < nkb) {
         s[kb] = wa_scores_t<DH>(Ks, kb, lr, lg, qf, brow, rid, rq, masked);
         m = fmaxf(m, fmaxf(fmaxf(s[kb][0], s[kb][1]), fmaxf(s[kb][2], s[kb][3])));
       }
@@ -183,7 +202,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_fwd_kernel(const float
     float l = 0.f;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      if (kb < nkb) {
+      if (EXACT || kb < nkb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = wa_exp(s[kb][r] - m);
@@ -201,7 +220,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_fwd_kernel(const float
     for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      if (kb < nkb) {
+      if (EXACT || kb < nkb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -244,9 +263,11 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_kv_kernel(const fl
   const float* ob = out + (long)b_ * g.n * C + h * DH;
   wa_stage_rows<DH>(Qs, base, rs, g.n, np, g.scale);
   wa_stage_rows<DH>(Gs, dob, C, g.n, np, 1.f);
-  const bool masked = regions != nullptr;
+  __shared__ int mixed;
+  if (threadIdx.x == 0) mixed = 0;
+  __syncthreads();
+  wa_stage_regions(rid, &mixed, regions, (long)(b_ % g.nW) * g.n, g.n, np);
   for (int i = threadIdx.x; i < np; i += blockDim.x) {
-    rid[i] = (masked && i < g.n) ? regions[(long)(b_ % g.nW) * g.n + i] : 0;
     float dl = 0.f, ls = 1.0e30f;
     if (i < g.n) {
       ls = lse[((long)b_ * g.heads + h) * g.n + i];
@@ -261,6 +282,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_kv_kernel(const fl
     Ds[i] = dl;
   }
   __syncthreads();
+  const bool masked = regions != nullptr && mixed != 0;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   for (int kb = wid; kb < nkb; kb += kWaWaves) {
     const int key = kb * 16 + lr, kc = key < g.n ? key : g.n - 1;
@@ -312,7 +334,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_kv_kernel(const fl
 // in LDS, dS is recomputed (S^T layout), dQ of the 16 queries is written, and dS is added to a register-resident 16 x n slab
 // of d(bias), which is summed over all windows of the batch and added to HBM once at the end.
 // grid (ceil(nkb/kWaWaves), heads, chunks); LDS = (2 * npad * (DH + 4) + npad) * 4 bytes.  dbias [heads, n, npad] zeroed (may be NULL).
-template <int NKB, int DH>
+template <int NKB, int DH, bool EXACT>
 __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_q_bias_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
                                                                      const int* __restrict__ regions, const float* __restrict__ out,
                                                                      const float* __restrict__ lse, const float* __restrict__ dout,
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_q_bias_kernel(cons
   const bool active = qb < nkb;
   const int query = qb * 16 + lr, qc = (active && query < g.n) ? query : g.n - 1;
   const bool qvalid = active && query < g.n;
-  const bool masked = regions != nullptr;
+  __shared__ int mixed;
   const float* brow = bias + ((long)h * g.n + qc) * g.npad;
   const int per = (g.B_ + gridDim.z - 1) / gridDim.z;
   const int b0 = blockIdx.z * per, b1 = (b0 + per < g.B_) ? b0 + per : g.B_;
@@ -339,10 +361,13 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_q_bias_kernel(cons
   for (int b_ = b0; b_ < b1; ++b_) {
     const float* base = qkv + (long)b_ * g.n * rs + h * DH;
     __syncthreads();
+    if (threadIdx.x == 0) mixed = 0;
     wa_stage_rows<DH>(Ks, base + C, rs, g.n, g.npad, 1.f);
     wa_stage_rows<DH>(Vs, base + 2 * C, rs, g.n, g.npad, 1.f);
-    for (int i = threadIdx.x; i < g.npad; i += blockDim.x) rid[i] = (masked && i < g.n) ? regions[(long)(b_ % g.nW) * g.n + i] : 0;
     __syncthreads();
+    wa_stage_regions(rid, &mixed, regions, (long)(b_ % g.nW) * g.n, g.n, g.npad);
+    __syncthreads();
+    const bool masked = regions != nullptr && mixed != 0;
     if (!active) continue;
     WaFrag<DH> qf, gf, of;
     qf.load(base + (long)qc * rs, lg, g.scale);
@@ -360,7 +385,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_q_bias_kernel(cons
     for (int t = 0; t < DT; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      if (kb < nkb) {
+      if (EXACT || kb < nkb) {
         const f32x4 s = wa_scores_t<DH>(Ks, kb, lr, lg, qf, brow, rid, rq, masked);
         WaFrag<DH> vf;
         vf.load(Vs + (kb * 16 + lr) * LD, lg);
@@ -387,7 +412,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_q_bias_kernel(cons
   float* drow = dbias + ((long)h * g.n + query) * g.npad;
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
-    if (kb < nkb) {
+    if (EXACT || kb < nkb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = kb * 16 + lg * 4 + r;
