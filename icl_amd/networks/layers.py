@@ -143,8 +143,38 @@ class BatchNormAct(nn.Module):
     @classmethod
     def flush_counters(cls):
         pending, cls.deferred = cls.deferred, None
-        if pending:
+        if not pending:
+            return
+        pool = cls._shared
+        if pool is not None and all(k in pool["index"] for k in pending):
+            # all counters live in one int64 vector (share_counters): one add of a cached increment vector
+            counts = [0] * pool["vector"].numel()
+            for k, (_, n) in pending.items():
+                counts[pool["index"][k]] = n
+            key = tuple(counts)
+            inc = pool["incs"].get(key)
+            if inc is None:
+                inc = pool["incs"][key] = torch.tensor(counts, dtype=torch.long, device=pool["vector"].device)
+            pool["vector"].add_(inc)
+        else:
             torch._foreach_add_([t for t, _ in pending.values()], [n for _, n in pending.values()])
+
+    _shared = None
+
+    @classmethod
+    def share_counters(cls, model):
+        """Re-home the ``num_batches_tracked`` buffers of all BatchNorm layers of ``model`` as 0-dim views of ONE int64 vector
+        (same values, same ``state_dict`` keys), so that a step's increments are a single launch instead of one per layer."""
+        mods = [m for m in model.modules() if isinstance(m, BatchNormAct)]
+        if not mods:
+            cls._shared = None
+            return
+        vec = torch.stack([m.num_batches_tracked.detach().reshape(()) for m in mods]).to(torch.long)
+        index = {}
+        for i, m in enumerate(mods):
+            m._buffers["num_batches_tracked"] = vec[i]
+            index[id(m._buffers["num_batches_tracked"])] = i
+        cls._shared = {"vector": vec, "index": index, "incs": {}}
 
     def forward(self, x):
         if self.training:

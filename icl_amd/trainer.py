@@ -53,6 +53,7 @@ class ICLTrainer:
             self.pse_loss = L.PseudoSoftLoss(cfg.num_classes, cfg.patch_size)
         self.iter_num = 0
         self.packed = ops.PackedWeights()
+        BatchNormAct.share_counters(model)   # one vector for all BatchNorm step counters: one add per step
         self.graph = None
         self.graph_update = None
         self.lr_dev = None
