@@ -47,7 +47,9 @@ _SIGNATURES = {
     "icl_trilinear_bwd": (c_int, [P, P, P, I, I, I, I, I, I, I, I, L, I, P]),
     "icl_copy_rows": (c_int, [P, P, L, L, L, L, P]),
     "icl_dwconv3_fwd": (c_int, [P, P, P, I, I, I, I, I, I, P]),
-    "icl_dwconv3_wgrad": (c_int, [P, P, P, I, I, I, I, I, P]),
+    "icl_dwconv3_wgrad_ws_bytes": (c_int64, [I, I, I, I, I]),
+    "icl_dwconv3_wgrad": (c_int, [P, P, P, P, I, I, I, I, I, P]),
+    "icl_conv1x1_small": (c_int, [P, P, P, P, I, I, I, L, I, I, P]),
     "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P, P]),
     "icl_drop_path": (c_int, [P, P, L, L, ctypes.c_uint32, F, P, P]),
     "icl_drop_path_add": (c_int, [P, P, P, L, L, ctypes.c_uint32, F, P, P]),
@@ -55,6 +57,7 @@ _SIGNATURES = {
     "icl_window_attn_bias_elems": (c_int64, [I, I]),
     "icl_depth_to_space2": (c_int, [P, P, I, I, I, I, I, L, P]),
     "icl_space_to_depth2": (c_int, [P, P, I, I, I, I, I, L, P]),
+    "icl_colsum_multi": (c_int, [P, P, P, P, I, P]),
     "icl_gather_rows": (c_int, [P, P, P, L, L, L, I, P]),
     "icl_gather_rows_sum2": (c_int, [P, P, P, L, L, L, I, P]),
     "icl_im2col3": (c_int, [P, P, I, I, I, I, I, P]),

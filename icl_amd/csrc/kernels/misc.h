@@ -42,8 +42,10 @@ __global__ __launch_bounds__(256) void dwconv3_fwd_kernel(const float* __restric
   }
 }
 
-// gw[c][tap] += sum over a chunk of (n, voxels) of gy * shifted x.  grid (chunks, C); gw pre-zeroed.
-__global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gw,
+// slab[chunk][c][tap] = sum over a chunk of (n, voxels) of gy * shifted x.  grid (chunks, C): the 27 sums are reduced inside each
+// wave with shuffles and across the four waves through LDS (one barrier); dwconv3_wgrad_reduce_kernel adds the chunks in a fixed
+// order (no atomics: reproducible).
+__global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ slab,
                                                             int N, int C, int D, int H, int W, long chunk) {
   const int c = blockIdx.y;
   const long S = (long)D * H * W;
@@ -74,11 +76,89 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restr
       }
     }
   }
-  __shared__ float red[4];
+  __shared__ float red[4][28];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 27; ++i) {
-    const float s = block_sum<256>(acc[i], red);
-    if (threadIdx.x == 0) atomicAdd(gw + c * 27 + i, s);
+    const float s = wave_sum(acc[i]);
+    if (lane == 0) red[wid][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27)
+    slab[((long)blockIdx.x * C + c) * 27 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void dwconv3_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gw, int E, int chunks) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float v = 0.f;
+  for (int k = 0; k < chunks; ++k) v += slab[(long)k * E + e];
+  gw[e] = v;
+}
+
+// ---- 1x1x1 convolution with a handful of channels on a small volume (the aligner's SeparableConv3d.pointwise h -> h and attn_convs1
+// h -> 1 on <= 4 x 24^3 maps, unet_3D_icl.py:196,327, and their input gradients): y[b][o][v] = bias[o] + sum_i w(o, i) * x[b][i][v],
+// w(o, i) = w[o * w_ostride + i * w_istride] (the input gradient is the same kernel with the strides swapped).  One thread per
+// (b, o, four consecutive voxels), 16-byte loads and stores; the implicit-GEMM kernel pads such a layer to 16 output channels
+// and a halo tile and takes 10-14 us for it.
+__global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int N, int CI, int CO,
+                                                            long S, int wos, int wis) {
+  const long S4 = S >> 2, total = (long)N * CO * S4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long v4 = e % S4, r = e / S4;
+    const int o = (int)(r % CO);
+    const long b = r / CO;
+    const float b0 = bias ? bias[o] : 0.f;
+    float4 acc = make_float4(b0, b0, b0, b0);
+    const float* xp = x + b * CI * S + (v4 << 2);
+    const float* wp = w + (long)o * wos;
+    for (int i = 0; i < CI; ++i) {
+      const float4 xv = *reinterpret_cast<const float4*>(xp + (long)i * S);
+      const float wv = wp[(long)i * wis];
+      acc.x = fmaf(wv, xv.x, acc.x);
+      acc.y = fmaf(wv, xv.y, acc.y);
+      acc.z = fmaf(wv, xv.z, acc.z);
+      acc.w = fmaf(wv, xv.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(y + (b * CO + o) * S + (v4 << 2)) = acc;
+  }
+}
+
+// ---- column sums of up to kColsumMulti small row-major matrices in ONE launch (grid.y = matrix): out_i[c] = sum_r g_i[r][c].
+// The bias gradients of the aligner's Linear layers (a few to a few hundred rows each): the trainer collects them during backward
+// and reduces them together instead of one tiny reduction launch per layer (38 per U-Net step).
+constexpr int kColsumMulti = 48;
+struct ColsumMulti {
+  const float* g[kColsumMulti];
+  float* out[kColsumMulti];
+  int rows[kColsumMulti], cols[kColsumMulti];
+};
+
+// Block 256 = 16 consecutive columns x 16 row lanes (every row is read as a 64-byte segment, 16 rows in flight per block); the 16
+// partial sums of a column are combined through LDS in lane order — a fixed summation order.  grid (ceil(max cols / 16), matrices).
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumMulti m) {
+  __shared__ float red[16][17];
+  const int i = blockIdx.y;
+  const int R = m.rows[i], C = m.cols[i];
+  const float* __restrict__ g = m.g[i];
+  const int lc = threadIdx.x & 15, lr = threadIdx.x >> 4;
+  for (int c0 = blockIdx.x * 16; c0 < C; c0 += gridDim.x * 16) {      // block-uniform loop
+    const int c = c0 + lc;
+    float acc = 0.f;
+    if (c < C) {
+#pragma unroll 4
+      for (int r = lr; r < R; r += 16) acc += g[(long)r * C + c];
+    }
+    __syncthreads();
+    red[lr][lc] = acc;
+    __syncthreads();
+    if (lr == 0 && c < C) {
+#pragma unroll
+      for (int k = 1; k < 16; ++k) acc += red[k][lc];
+      m.out[i][c] = acc;
+    }
   }
 }
 

@@ -200,6 +200,7 @@ def _cached_zeros(n: int, device) -> torch.Tensor:
 CONV1X1_WGRAD_MIN_VOXELS = 4096
 FIRST_CONV_PLANES_MAX_K = int(os.environ.get("ICL_FIRST_CONV_PLANES_K", "32"))      # Cin * 27 <= 32, i.e. one input channel
 CONV1X1_GEMM_MIN_VOXELS = 65536
+CONV1X1_SMALL_MAX_CHANNELS = 16       # 1x1x1 convolutions with <= 16 -> <= 16 channels below the GEMM threshold: icl_conv1x1_small
 
 
 class _Conv3d(torch.autograd.Function):
@@ -226,6 +227,13 @@ class _Conv3d(torch.autograd.Function):
             return y.view(n, cout, d, h, w)
         y = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
         ctx.wpt = None
+        ctx.pointwise_small = (ks == 1 and cin <= CONV1X1_SMALL_MAX_CHANNELS and cout <= CONV1X1_SMALL_MAX_CHANNELS and s % 4 == 0
+                               and os.environ.get("ICL_CONV1X1_SMALL", "1") != "0")
+        if ctx.pointwise_small:
+            # the aligner's h -> h / h -> 1 maps on <= 4 x 24^3 voxels: a VALU kernel on the natural weight layout
+            _lib.check(_lib.lib().icl_conv1x1_small(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), n, cin, cout, s, cin, 1, _stream(x)),
+                       "conv1x1_small")
+            return y
         if ctx.needs_input_grad[0]:
             # the input gradient will need the flipped/transposed packing too: one launch for both, kept for backward
             wp, ctx.wpt = PackedWeights.get(weight)
@@ -246,6 +254,10 @@ class _Conv3d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ctx.pointwise_gemm:
                 gx = torch.bmm(weight.view(cout, cin).t().unsqueeze(0).expand(n, cin, cout), gy.view(n, cout, s)).view(n, cin, d, h, w)
+            elif ctx.pointwise_small:
+                gx = torch.empty_like(x)
+                _lib.check(L.icl_conv1x1_small(_ptr(gy), _ptr(weight), None, _ptr(gx), n, cout, cin, s, 1, cin, _stream(x)),
+                           "conv1x1_small dgrad")
             else:
                 gx = torch.empty_like(x)
                 wpt = ctx.wpt if ctx.wpt is not None else pack_weights(weight, 1)
@@ -622,7 +634,8 @@ class _DWConv3(torch.autograd.Function):
             _lib.check(L.icl_dwconv3_fwd(_ptr(gy), _ptr(weight), _ptr(gx), n, c, d, h, w, 1, _stream(x)), "dwconv3_dgrad")
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(weight)
-            _lib.check(L.icl_dwconv3_wgrad(_ptr(x), _ptr(gy), _ptr(gw), n, c, d, h, w, _stream(x)), "dwconv3_wgrad")
+            ws = _ws(L.icl_dwconv3_wgrad_ws_bytes(n, c, d, h, w), x)
+            _lib.check(L.icl_dwconv3_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(ws), n, c, d, h, w, _stream(x)), "dwconv3_wgrad")
         return gx, gw
 
 
@@ -785,14 +798,57 @@ def _tall_atb(a: torch.Tensor, b: torch.Tensor, want_colsum: bool):
     return out, colsum
 
 
+class DeferredBiasGrads:
+    """While open (ICLTrainer brackets forward/backward with ``begin()`` / ``flush()``), the Linear layers that know their module
+    (``owner``) and see few rows do not reduce their bias gradient inside backward: they queue (bias, dY) and ``flush()`` computes
+    all column sums in ONE launch and assigns (or accumulates into) ``bias.grad``.  Closed, every bias gradient is reduced on
+    the spot as usual."""
+    pending = None
+
+    @classmethod
+    def begin(cls):
+        cls.pending = [] if os.environ.get("ICL_DEFER_BIAS", "1") != "0" else None
+
+    @classmethod
+    def defer(cls, bias, g2) -> bool:
+        if cls.pending is None or not isinstance(bias, torch.nn.Parameter) or g2.shape[0] >= LINEAR_WGRAD_MIN_ROWS:
+            return False
+        cls.pending.append((bias, g2.contiguous()))
+        return True
+
+    @classmethod
+    def flush(cls):
+        items, cls.pending = cls.pending, None
+        if not items:
+            return
+        L = _lib.lib()
+        n = len(items)
+        sizes = [g.shape[1] for _, g in items]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=items[0][1].device)
+        outs, off = [], 0
+        for c in sizes:
+            outs.append(flat[off:off + c])
+            off += c
+        arr = ctypes.c_void_p * n
+        iarr = ctypes.c_int32 * n
+        _lib.check(L.icl_colsum_multi(arr(*[g.data_ptr() for _, g in items]), arr(*[o.data_ptr() for o in outs]),
+                                      iarr(*[g.shape[0] for _, g in items]), iarr(*sizes), n, _stream(flat)), "colsum_multi")
+        for (bias, _), o in zip(items, outs):
+            if bias.grad is None:
+                bias.grad = o
+            else:
+                bias.grad = bias.grad + o      # a bias used by several calls of the step
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b.  Forward and dx are plain library GEMMs (rocBLAS); dW/db of TALL inputs (>= 2048 rows: the Swin token
     grids) use csrc/kernels/linear_wgrad.h — the library runs a 221K-deep reduction on ten workgroups there."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, owner=None):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_param = owner.bias if (owner is not None and bias is not None and getattr(owner, "bias", None) is bias) else None
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -804,8 +860,12 @@ class _Linear(torch.autograd.Function):
             gx = torch.matmul(gy, weight)
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or need_b:
-            gw, gb = _tall_atb(gy.reshape(-1, o), x.reshape(-1, i), need_b)
-        return gx, gw, gb
+            g2 = gy.reshape(-1, o)
+            if need_b and ctx.bias_param is not None and DeferredBiasGrads.defer(ctx.bias_param, g2):
+                need_b = False      # reduced with all the other bias gradients of the step (DeferredBiasGrads.flush)
+            if ctx.needs_input_grad[1] or need_b:
+                gw, gb = _tall_atb(g2, x.reshape(-1, i), need_b)
+        return gx, gw, gb, None
 
 
 class _MatmulTall(torch.autograd.Function):
@@ -864,7 +924,9 @@ class _LinearFactored(torch.autograd.Function):
         o, i = weight.shape
         gx = torch.matmul(gy, weight) if ctx.needs_input_grad[0] else None
         g2, x2 = gy.reshape(-1, o).contiguous(), x.reshape(-1, i).contiguous()
-        gb = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2] and not DeferredBiasGrads.defer(getattr(ctx.owner, "bias", None), g2):
+            gb = g2.sum(0)
         param = ctx.owner.weight
         if getattr(param, "_icl_factors", None) is None:
             param._icl_factors = []
@@ -877,7 +939,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     if (owner is not None and FactoredGrads.enabled and weight.requires_grad and weight.numel() >= FactoredGrads.min_elems
             and x.numel() // x.shape[-1] <= FactoredGrads.max_rows and weight.shape[1] % 4 == 0 and torch.is_grad_enabled()):
         return _LinearFactored.apply(x, weight, bias, owner)
-    return _Linear.apply(x, weight, bias)
+    return _Linear.apply(x, weight, bias, owner)
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -75,6 +75,7 @@ class ICLTrainer:
         self.packed.begin_step()        # every convolution weight packed once, in one launch (ops.PackedWeights)
         self.optimizer.zero_grad(set_to_none=True)
         BatchNormAct.defer_counters()
+        ops.DeferredBiasGrads.begin()
         try:
             with ops.FactoredGrads(cfg.factored_mlp2_grads):
                 outputs = self.model(volume_batch[:cfg.labeled_bs], volume_batch[cfg.labeled_bs:])
@@ -82,6 +83,7 @@ class ICLTrainer:
                 loss.backward()
         finally:
             BatchNormAct.flush_counters()     # all num_batches_tracked increments of the step in one launch
+            ops.DeferredBiasGrads.flush()     # all small-Linear bias gradients of the step in one launch
         parts = {k: v.detach() for k, v in parts.items()}
         parts["loss"] = loss.detach()
         return parts

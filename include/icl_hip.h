@@ -91,9 +91,17 @@ int icl_copy_rows(const float* src, float* dst, int64_t rows, int64_t row_elems,
                   void* stream);
 
 /* ---- depthwise Conv3d k=3 pad=1 groups=C, no bias (networks/unet_3D_icl.py:320-323).
- * w is [C][27]; flip=1 applies the transposed stencil (input gradient). gw [C][27] is overwritten. */
+ * w is [C][27]; flip=1 applies the transposed stencil (input gradient). gw [C][27] is overwritten (per-chunk partial sums in `ws`,
+ * icl_dwconv3_wgrad_ws_bytes, added in a fixed order). */
 int icl_dwconv3_fwd(const float* x, const float* w, float* y, int n, int c, int d, int h, int wd, int flip, void* stream);
-int icl_dwconv3_wgrad(const float* x, const float* gy, float* gw, int n, int c, int d, int h, int wd, void* stream);
+int64_t icl_dwconv3_wgrad_ws_bytes(int n, int c, int d, int h, int wd);
+int icl_dwconv3_wgrad(const float* x, const float* gy, float* gw, void* ws, int n, int c, int d, int h, int wd, void* stream);
+
+/* ---- 1x1x1 Conv3d with a handful of channels on a small volume (SeparableConv3d.pointwise and attn_convs1 of the aligner,
+ * networks/unet_3D_icl.py:196,327): y[b][o][v] = bias[o] + sum_i w[o * w_ostride + i * w_istride] * x[b][i][v], x [n, cin, s],
+ * y [n, cout, s], s % 4 == 0, bias may be NULL.  The input gradient is the same call with the strides swapped. */
+int icl_conv1x1_small(const float* x, const float* w, const float* bias, float* y, int n, int cin, int cout, int64_t s, int w_ostride,
+                      int w_istride, void* stream);
 
 /* ---- nn.Dropout(p) (networks/unet_3D_icl.py:67-68,110,116): y = keep ? x/(1-p) : 0 with a counter-based
  * mask keyed by (seed, element index); calling it again with the same seed on dY is the backward.  seed_dev (may be
@@ -140,6 +148,10 @@ int icl_attn_fwd(const float* q, const float* kv, float* logits, float* out, flo
                  float scale, void* stream);
 int icl_attn_bwd(const float* q, const float* kv, const float* logits, const float* stats, const float* out, const float* gout,
                  const float* glog, float* gq, float* gkv, int b, int h, int nc, int n, int d, float scale, void* stream);
+
+/* out_i[c] = sum_r g_i[r * cols_i + c] for `count` small row-major matrices, one launch per 48 of them: the bias gradients of the
+ * aligner / Swin Linear layers (unet_3D_icl.py:244-315) collected over a backward pass. */
+int icl_colsum_multi(const void* const* g, void* const* out, const int32_t* rows, const int32_t* cols, int count, void* stream);
 
 /* ---- token <-> window order of the Swin blocks (pad + roll + window_partition, window_reverse + roll + crop:
  * networks/swinunetr_icl.py:825-866, networks/swinunet_icl.py:256-283): out[b][m][0..c) = idx[m] >= 0 ? src[b][idx[m]][0..c) : 0,

@@ -37,7 +37,11 @@ def _rand(shape, seed, grad=False):
     (1, 1, 16, 6, 6, 6, 3),     # first-layer shape class (Cin = 1), non-multiple-of-4 width
     (1, 16, 32, 4, 8, 16, 3),   # two cout groups per block
     (1, 20, 48, 6, 6, 12, 3),   # partial cin chunk + partial cout tile
-    (2, 8, 2, 4, 4, 8, 1),      # 1x1x1 (final conv class)
+    (2, 8, 2, 4, 4, 8, 1),      # 1x1x1, few channels: icl_conv1x1_small (forward and input gradient)
+    (4, 16, 1, 6, 6, 6, 1),     # attn_convs1 class (h -> 1)
+    (2, 4, 4, 3, 4, 5, 1),      # pointwise h -> h
+    (1, 20, 3, 4, 4, 8, 1),     # 1x1x1 beyond 16 channels: implicit-GEMM kernel (final conv class)
+    (1, 4, 4, 3, 3, 5, 1),      # voxel count not a multiple of 4: implicit-GEMM kernel
     (1, 32, 16, 2, 8, 32, 3),   # wide row: several x tiles
     (1, 8, 48, 5, 12, 12, 3),   # static 4x4x16 tile, masked x/z borders, NB = 48
     (2, 4, 16, 3, 16, 24, 3),   # static 2x8x16 tile, CinP = 4 chunks, partial x tile
@@ -199,6 +203,21 @@ def test_fused_losses(nc):
     assert rel_err(a2.grad, a2r.grad) < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(3, 4, 5, 6, 7), (2, 3, 12, 12, 12)])      # one chunk / several chunks of the weight gradient
+def test_depthwise_conv(shape):
+    x = _rand(shape, 44, True)
+    c = shape[1]
+    w = (_rand((c, 1, 3, 3, 3), 45) * 0.3).requires_grad_()
+    y = ops.depthwise_conv3d(x, w)
+    gy = _rand(tuple(y.shape), 46)
+    y.backward(gy)
+    xr, wr = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    yr = F.conv3d(xr, wr, None, padding=1, groups=c)
+    yr.backward(gy)
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    assert rel_err(x.grad, xr.grad) < 1e-5 and rel_err(w.grad, wr.grad) < 1e-5
+
+
 def test_depthwise_and_dropout():
     x = _rand((3, 4, 5, 6, 7), 41, True)
     w = (_rand((4, 1, 3, 3, 3), 42) * 0.3).requires_grad_()
@@ -258,6 +277,34 @@ def test_packed_weight_cache_repacks_all_weights_in_one_launch():
         with torch.no_grad():
             for w in ws:
                 w.mul_(0.9).add_(0.01)                # the weights change between steps
+
+
+def test_deferred_bias_gradients_match_immediate_ones():
+    """ops.DeferredBiasGrads: bias gradients of owner-Linear layers queued during backward and reduced in one launch equal the
+    per-layer reductions, also for a layer used twice in the step and with an existing .grad to accumulate into."""
+    from icl_amd.networks.aligner import Linear
+    torch.manual_seed(5)
+    la, lb = Linear(12, 20), Linear(20, 7)
+    x1, x2 = _rand((3, 15, 12), 111), _rand((4, 12), 112)
+
+    def loss():
+        return lb(torch.tanh(la(x1))).pow(2).sum() + la(x2).sum() * 0.5        # la is used twice
+
+    for p in list(la.parameters()) + list(lb.parameters()):
+        p.grad = None
+    loss().backward()
+    ref = [p.grad.clone() for p in (la.weight, la.bias, lb.weight, lb.bias)]
+    for p in (la.weight, la.bias, lb.weight, lb.bias):
+        p.grad = None
+    lb.bias.grad = torch.ones(7)                                               # pre-existing gradient: must be accumulated
+    ops.DeferredBiasGrads.begin()
+    loss().backward()
+    assert la.bias.grad is None and len(ops.DeferredBiasGrads.pending) == 3    # nothing reduced yet
+    ops.DeferredBiasGrads.flush()
+    assert ops.DeferredBiasGrads.pending is None
+    got = [la.weight.grad, la.bias.grad, lb.weight.grad, lb.bias.grad - 1.0]
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) < 1e-6
 
 
 def test_drop_path_add_matches_separate_ops():
