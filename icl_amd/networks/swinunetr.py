@@ -398,7 +398,9 @@ class SwinUNETRBackbone(nn.Module):
         self.decoder1 = UnetrUpBlock(f, f, device)
         self.out = UnetOutBlock(f, out_channels, device)
 
-    def run_backbone(self, x):
+    def run_backbone(self, x, heads=None):
+        """``heads`` (the ICL model's aligner calls) is invoked on [dec3, dec2, dec1] as soon as they exist; its result is returned as
+        a third value."""
         hs = self.swinViT(x, self.normalize)
         enc0 = self.encoder1(x)
         enc1 = self.encoder2(hs[0])
@@ -408,8 +410,11 @@ class SwinUNETRBackbone(nn.Module):
         dec3 = self.decoder5(dec4, hs[3])
         dec2 = self.decoder4(dec3, enc3)
         dec1 = self.decoder3(dec2, enc2)
+        extra = heads([dec3, dec2, dec1]) if heads is not None else None
         dec0 = self.decoder2(dec1, enc1)
         out = self.decoder1(dec0, enc0)
+        if heads is not None:
+            return self.out(out), [dec3, dec2, dec1, dec0], extra
         return self.out(out), [dec3, dec2, dec1, dec0]
 
     def load_from(self, weights):

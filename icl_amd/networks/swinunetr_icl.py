@@ -36,8 +36,15 @@ class SwinUNETR_icl(SwinUNETRBackbone):  # noqa: N801 — reference class name
         # window, InstanceNorm per sample), so they run as one batch — same per-sample results as the reference's two
         # passes (:313-347) with half the launches and one weight-gradient product per layer.
         bl = x_lab.shape[0]
-        logits, feats = self.run_backbone(torch.cat([x_lab, x_unlab], 0))
-        (maps_lab, qs_lab), (maps_con, _) = self.sspa.forward_labeled_pair(feats[:3], bl)
-        maps_unlab, _ = self.uscl([t[bl:] for t in feats[:3]], qs_lab, "unlabeled")
+
+        def heads(feats):
+            # the aligners need only dec3..dec1: they run on a second stream next to the 48^3 / 96^3 decoder stages
+            with ops.SideStream(feats) as side:
+                (maps_lab, qs_lab), (maps_con, _) = self.sspa.forward_labeled_pair(feats, bl)
+                maps_unlab, _ = self.uscl([t[bl:] for t in feats], qs_lab, "unlabeled")
+            return side, maps_lab, maps_unlab, maps_con
+
+        logits, _, (side, maps_lab, maps_unlab, maps_con) = self.run_backbone(torch.cat([x_lab, x_unlab], 0), heads)
+        side.join(maps_lab + maps_unlab + maps_con)
         logits_lab, logits_unlab = ops.split_batch(logits, bl)
         return logits_lab, logits_unlab, maps_lab, maps_unlab, maps_con

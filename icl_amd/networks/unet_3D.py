@@ -41,8 +41,9 @@ class UNet3DBackbone(nn.Module):
         self.dropout1 = Dropout3(0.3)
         self.dropout2 = Dropout3(0.3)
 
-    def run_backbone(self, x):
-        """One stream: returns (logits, [center, up4, up3]) — unet_3D_icl.py:100-117."""
+    def run_backbone(self, x, heads=None):
+        """One stream: returns (logits, [center, up4, up3]) — unet_3D_icl.py:100-117.  ``heads`` (the ICL model's aligner calls) is
+        invoked on the three deep maps as soon as they exist and its result returned as a third value."""
         from .. import ops
         c1 = self.conv1(x)
         c2 = self.conv2(ops.max_pool3d_2(c1))
@@ -51,8 +52,11 @@ class UNet3DBackbone(nn.Module):
         center = self.dropout1(self.center(ops.max_pool3d_2(c4)))
         up4 = self.up_concat4(c4, center)
         up3 = self.up_concat3(c3, up4)
+        extra = heads([center, up4, up3]) if heads is not None else None
         up2 = self.up_concat2(c2, up3)
         up1 = self.dropout2(self.up_concat1(c1, up2))
+        if heads is not None:
+            return self.final(up1), [center, up4, up3], extra
         return self.final(up1), [center, up4, up3]
 
 

@@ -33,10 +33,17 @@ class unet_3D_icl(UNet3DBackbone):  # noqa: N801 — reference class name
         # the same per-sample results while halving the launch count and doubling the parallelism of the 6^3..24^3
         # layers; the weight gradients of both streams come out of one wgrad launch instead of two plus an add.
         bl = x_lab.shape[0]
-        final, feats = self.run_backbone(torch.cat([x_lab, x_unlab], 0))
+
+        def heads(feats):
+            # the aligners need only the three deep maps: they run on a second stream next to the 48^3 / 96^3 decoder stages
+            with ops.SideStream(feats) as side:
+                (maps_lab, qs_lab), (maps_consis, _) = self.sspa.forward_labeled_pair(feats, bl)
+                maps_unlab, _ = self.uscl([f[bl:] for f in feats], qs_lab, "unlabeled")
+            return side, maps_lab, maps_unlab, maps_consis
+
+        final, _, (side, feat_maps_lab, feat_maps_unlab, feat_maps_consis) = self.run_backbone(torch.cat([x_lab, x_unlab], 0), heads)
+        side.join(feat_maps_lab + feat_maps_unlab + feat_maps_consis)
         final_lab, final_unlab = ops.split_batch(final, bl)
-        (feat_maps_lab, updated_qs_lab), (feat_maps_consis, _) = self.sspa.forward_labeled_pair(feats, bl)
-        feat_maps_unlab, _ = self.uscl([f[bl:] for f in feats], updated_qs_lab, "unlabeled")
         return final_lab, final_unlab, feat_maps_lab, feat_maps_unlab, feat_maps_consis
 
     @staticmethod

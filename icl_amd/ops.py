@@ -37,6 +37,51 @@ def _require(*ts: Optional[torch.Tensor]):
             raise RuntimeError("icl_amd: HIP kernels need device tensors (no CPU fallback)")
 
 
+class SideStream:
+    """Fork/join of the aligner heads onto a second HIP stream.
+
+    The aligners (three calls, ~600 small launches forward+backward and the HBM-bound streaming of the 764 MB ``mlp2`` weights) need
+    only the three deepest decoder maps; the rest of the decoder (the 48^3 / 96^3 convolutions, compute-bound on the matrix cores) does
+    not depend on them.  ``with SideStream(inputs) as side:`` runs its body on a second stream ordered after everything queued on the
+    current one; ``side.join(outputs)`` orders the current stream after it.  Autograd runs every backward node on the stream of its
+    forward and synchronises across streams itself, so the aligner backward overlaps the backward of the upper decoder too; inside a
+    captured step (ICLTrainer.capture) the two streams become parallel branches of the hipGraph.  Tensors crossing streams are
+    recorded with the caching allocator (``record_stream``).  ``ICL_ALIGNER_STREAM=0`` (or a CPU tensor) runs the body in line."""
+    enabled = os.environ.get("ICL_ALIGNER_STREAM", "1") != "0"
+    _streams = {}
+
+    def __init__(self, inputs):
+        self.stream = None
+        t0 = inputs[0]
+        if SideStream.enabled and t0.is_cuda and torch.is_grad_enabled():
+            dev = t0.device
+            s = SideStream._streams.get(dev.index)
+            if s is None:
+                s = SideStream._streams[dev.index] = torch.cuda.Stream(device=dev)
+            self.main = torch.cuda.current_stream(dev)
+            s.wait_stream(self.main)
+            for t in inputs:
+                t.record_stream(s)
+            self.stream = s
+            self._guard = torch.cuda.stream(s)
+
+    def __enter__(self):
+        if self.stream is not None:
+            self._guard.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.stream is not None:
+            self._guard.__exit__(*a)
+
+    def join(self, outputs):
+        if self.stream is None:
+            return
+        self.main.wait_stream(self.stream)
+        for t in outputs:
+            t.record_stream(self.main)
+
+
 class KernelTimer:
     """HIP-event timing of individual kernel launches on the stream they are launched on (bench.py roofline).
     Usage: ``with KernelTimer() as kt: step()``; ``kt.summary()`` -> {name: (launches, ms_total, flops, bytes)}."""
