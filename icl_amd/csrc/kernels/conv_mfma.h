@@ -154,6 +154,33 @@ __global__ __launch_bounds__(256) void reduce_unpack_wgrad_kernel(const float* _
   }
 }
 
+// The same reduction for MANY slabs of FEW elements (the 16-channel layers on 96^3: 512-1024 slabs of 6,912 packed elements; with
+// the kernel above 108 workgroups each walk 128-256 slabs per wave, 35 us).  Block 256 = 16 consecutive packed elements x 16 slab
+// lanes: slab lane l adds slabs l, l+16, ... (64-byte row segments, independent loads), the 16 partial sums are combined through
+// LDS in lane order (fixed order -> reproducible).  grid ceil(pe / 16).
+__global__ __launch_bounds__(256) void reduce_unpack_wgrad_tall_kernel(const float* __restrict__ gwp, float* __restrict__ gw, int Cout,
+                                                                       int Cin, int T, int CinP, int CoutP, int nslabs) {
+  __shared__ float part[16][17];
+  const long pe = (long)T * CinP * CoutP;
+  const int le = threadIdx.x & 15, ls = threadIdx.x >> 4;
+  const long idx = (long)blockIdx.x * 16 + le;
+  float acc = 0.f;
+  if (idx < pe) {
+#pragma unroll 8
+    for (int s = ls; s < nslabs; s += 16) acc += gwp[s * pe + idx];
+  }
+  part[ls][le] = acc;
+  __syncthreads();
+  if (ls != 0 || idx >= pe) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) acc += part[k][le];
+  const int co = (int)(idx % CoutP);
+  const long t = idx / CoutP;
+  const int ci = (int)(t % CinP);
+  const int tap = (int)(t / CinP);
+  if (co < Cout && ci < Cin) gw[((long)co * Cin + ci) * T + tap] = acc;
+}
+
 // y[b][c][v] = bias[c] + sum_ks slab[ks][b][c][v]   (fixed order; per = Cout*DHW elements per batch item)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
                                                             float* __restrict__ y, int ksplit, int n, long per, long DHW, long y_bstride) {

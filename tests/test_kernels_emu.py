@@ -59,6 +59,20 @@ def test_conv3d_forced_big_tile(monkeypatch):
     _conv_check(1, 8, 32, 4, 16, 16, 3)
 
 
+def test_conv3d_wgrad_tall_slab_reduction():
+    """Weight gradient whose partial slabs are added by reduce_unpack_wgrad_tall_kernel (16 slab lanes per packed element; on the GPU
+    the 16-channel layers at 96^3 with 512+ slabs) — run in a subprocess: the threshold is read once per process."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path[:0] = [%r, %r]; import test_kernels_emu as t; from icl_amd import _lib;"
+            "_lib._use_library_for_tests(t.build_emu(), host_pointers=True);"
+            "t._conv_check(2, 16, 16, 8, 8, 32, 3); t._conv_check(1, 5, 40, 4, 8, 16, 3)") % (os.path.dirname(here), here)
+    env = dict(os.environ, ICL_WGRAD_TALL_MIN="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def _conv_check(n, cin, cout, d, h, w, ks):
     x = _rand((n, cin, d, h, w), 1, True)
     wt = (_rand((cout, cin, ks, ks, ks), 2) * 0.2).requires_grad_()
