@@ -23,6 +23,8 @@ __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 
 // hide an integer from constant folding: keeps LDS offsets small enough for ds_read2_b32 pairing (8-bit dword offsets)
 #define ICL_OPAQUE_INT(x) asm volatile("" : "+v"(x))
+// nothing may be scheduled across this point (keeps software-prefetched LDS reads ahead of the MFMAs they overlap)
+#define ICL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 
 // tell the compiler a value is the same in every lane of the wave (lets it use SGPRs / scalar loads for what depends on it)
 #define ICL_WAVE_UNIFORM(x) ((x) = __builtin_amdgcn_readfirstlane(x))

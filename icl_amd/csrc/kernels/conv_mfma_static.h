@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kern
   int bb[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
-    const int tap = tg + t * TG;
+    const int tap = tg + t * TG < T ? tg + t * TG : T - 1;   // a wave without a last tap prefetches (and ignores) tap 26
     const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
     bb[t] = lr * PS + lq + (TC::HX - 1) + (dz * PY + dy) * PXL + dx;
   }
@@ -330,32 +330,86 @@ __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kern
     store_tile();
     __syncthreads();
     if (bt + 1 < bt_end) load_tile(bt + 1);
-    // one x-row of the tile (16 voxels = 4 k-steps) at a time: per operand ONE row base register and the four k-steps at
-    // dword offsets 0/4/8/12, which the compiler pairs into ds_read2_b32 (8-bit dword offsets) — half the LDS instructions
+    if constexpr (NCB >= 2) {
+      // one x-row of the tile (16 voxels = 4 k-steps) at a time: per operand ONE row base register and the four k-steps at
+      // dword offsets 0/4/8/12, which the compiler pairs into ds_read2_b32 (8-bit dword offsets).
+      // Software pipeline (two / three cout blocks at two waves per SIMD: +3-8 % on the 32- and 48-multiple layers): the B
+      // operand of the NEXT (row, tap) step — and, at the last tap of a row, the A operand of the next row — is read from LDS
+      // before the MFMAs of the current step are issued (left to itself the compiler emits read, wait lgkmcnt(0), 4 MFMAs for
+      // every half step, i.e. the whole LDS latency in front of every 128 cycles of matrix work).
+      auto load_a = [&](int rr, float (&a)[NCB][4]) {
 #pragma unroll
-    for (int rr = 0; rr < RPH; ++rr) {
-      // rows of this wave group; (row / TY, row % TY) must be compile-time per unrolled step, so the half enters as an offset
-      float a[NCB][4];
+        for (int cb = 0; cb < NCB; ++cb) {
+          int ai = ab + cb * 16 * MTP + 16 * rr + half * (16 * RPH);
+          ICL_OPAQUE_INT(ai);
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        int ai = ab + cb * 16 * MTP + 16 * rr + half * (16 * RPH);
-        ICL_OPAQUE_INT(ai);
+          for (int s = 0; s < 4; ++s) a[cb][s] = Gs[ai + 4 * s];
+        }
+      };
+      auto load_b = [&](int rr, int t, float (&bv)[4]) {
+        // RPH is a multiple of TY for every tile used (4x4x16: 16 rows, TY 4; 8 rows per half = 2 z-planes)
+        int bi = bb[t] + ((rr / TC::TY) * PY + (rr % TC::TY)) * PXL + half * ((RPH / TC::TY) * PY * PXL);
+        ICL_OPAQUE_INT(bi);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[cb][s] = Gs[ai + 4 * s];
+        for (int s = 0; s < 4; ++s) bv[s] = Xs[bi + 4 * s];
+      };
+      float a[NCB][4], an[NCB][4], b[4], bn[4];
+      load_a(0, a);
+      load_b(0, 0, b);
+#pragma unroll
+      for (int rr = 0; rr < RPH; ++rr) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          if (t + 1 < NTW) load_b(rr, t + 1, bn);
+          else if (rr + 1 < RPH) { load_a(rr + 1, an); load_b(rr + 1, 0, bn); }
+          ICL_SCHED_BARRIER();
+          if (t < NTW - 1 || tg + t * TG < T) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int cb = 0; cb < NCB; ++cb) acc[cb][t] = icl_mfma_16x16x4(a[cb][s], b[s], acc[cb][t]);
+          }
+          ICL_SCHED_BARRIER();
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[s] = bn[s];
+          if (t == NTW - 1 && rr + 1 < RPH) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+              for (int s = 0; s < 4; ++s) a[cb][s] = an[cb][s];
+          }
+        }
       }
+    } else {
+      // one cout block (124 registers, four waves per SIMD): the explicit prefetch spills (128 registers + 40 B scratch) and is 1-3 % slower;
+      // with four waves per SIMD the other waves cover the LDS latency
+      // one x-row of the tile (16 voxels = 4 k-steps) at a time: per operand ONE row base register and the four k-steps at
+      // dword offsets 0/4/8/12, which the compiler pairs into ds_read2_b32 (8-bit dword offsets) — half the LDS instructions
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        if (t < NTW - 1 || tg + t * TG < T) {
-          // RPH is a multiple of TY for every tile used (4x4x16: 16 rows, TY 4; 8 rows per half = 2 z-planes)
-          int bi = bb[t] + ((rr / TC::TY) * PY + (rr % TC::TY)) * PXL + half * ((RPH / TC::TY) * PY * PXL);
-          ICL_OPAQUE_INT(bi);
-          float b[4];
+      for (int rr = 0; rr < RPH; ++rr) {
+        // rows of this wave group; (row / TY, row % TY) must be compile-time per unrolled step, so the half enters as an offset
+        float a[NCB][4];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) b[s] = Xs[bi + 4 * s];
+        for (int cb = 0; cb < NCB; ++cb) {
+          int ai = ab + cb * 16 * MTP + 16 * rr + half * (16 * RPH);
+          ICL_OPAQUE_INT(ai);
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
+          for (int s = 0; s < 4; ++s) a[cb][s] = Gs[ai + 4 * s];
+        }
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb][t] = icl_mfma_16x16x4(a[cb][s], b[s], acc[cb][t]);
+        for (int t = 0; t < NTW; ++t) {
+          if (t < NTW - 1 || tg + t * TG < T) {
+            // RPH is a multiple of TY for every tile used (4x4x16: 16 rows, TY 4; 8 rows per half = 2 z-planes)
+            int bi = bb[t] + ((rr / TC::TY) * PY + (rr % TC::TY)) * PXL + half * ((RPH / TC::TY) * PY * PXL);
+            ICL_OPAQUE_INT(bi);
+            float b[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[s] = Xs[bi + 4 * s];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int cb = 0; cb < NCB; ++cb) acc[cb][t] = icl_mfma_16x16x4(a[cb][s], b[s], acc[cb][t]);
+          }
         }
       }
     }

@@ -240,6 +240,7 @@ static inline float icl_fast_exp(float x) { return expf(x); }
 static inline float4 icl_nt_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static inline void icl_nt_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 #define ICL_OPAQUE_INT(x) ((void)(x))
+#define ICL_SCHED_BARRIER() ((void)0)
 #define ICL_WAVE_UNIFORM(x) ((void)(x))
 static inline float atomicAdd(float* p, float v) {
   uint32_t* ip = (uint32_t*)p;

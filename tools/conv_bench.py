@@ -28,24 +28,25 @@ def timeit(fn, iters=10):
 def main():
     dev = torch.device("cuda", 0)
     L = _lib.lib()
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1      # batch (bench.py runs 2 volumes per step)
     rows = []
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     for cin, cout, s in LAYERS:
-        x = torch.randn(1, cin, s, s, s, device=dev)
+        x = torch.randn(nb, cin, s, s, s, device=dev)
         w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
         b = torch.randn(cout, device=dev)
-        gy = torch.randn(1, cout, s, s, s, device=dev)
+        gy = torch.randn(nb, cout, s, s, s, device=dev)
         y = torch.empty_like(gy)
         gx = torch.empty_like(x)
         gw = torch.empty_like(w)
         gb = torch.empty_like(b)
         wp, wpt = ops.pack_weights(w, 0), ops.pack_weights(w, 1)
         S = s ** 3
-        ws = torch.empty(L.icl_conv3d_wgrad_ws_bytes(1, cin, cout, 3) // 4, device=dev)
-        fl = 2.0 * 27 * cin * cout * S
-        t_f = timeit(lambda: ops.conv3d_forward_raw(x, wp, b, 1, cin, cout, s, s, s, 3, cin * S, y, cout * S))
-        t_d = timeit(lambda: ops.conv3d_forward_raw(gy, wpt, None, 1, cout, cin, s, s, s, 3, cout * S, gx, cin * S)) if cin > 1 else 0.0
-        t_w = timeit(lambda: _lib.check(L.icl_conv3d_wgrad(ops._ptr(x), ops._ptr(gy), ops._ptr(gw), ops._ptr(gb), ops._ptr(ws), 1, cin, cout,
+        ws = torch.empty(L.icl_conv3d_wgrad_ws_bytes(nb, cin, cout, 3) // 4, device=dev)
+        fl = 2.0 * 27 * cin * cout * S * nb
+        t_f = timeit(lambda: ops.conv3d_forward_raw(x, wp, b, nb, cin, cout, s, s, s, 3, cin * S, y, cout * S))
+        t_d = timeit(lambda: ops.conv3d_forward_raw(gy, wpt, None, nb, cout, cin, s, s, s, 3, cout * S, gx, cin * S)) if cin > 1 else 0.0
+        t_w = timeit(lambda: _lib.check(L.icl_conv3d_wgrad(ops._ptr(x), ops._ptr(gy), ops._ptr(gw), ops._ptr(gb), ops._ptr(ws), nb, cin, cout,
                                                            s, s, s, 3, cin * S, cout * S, ops._stream(x))))
         mult = 2 if (cin, cout, s) in [(16, 16, 96), (32, 32, 48), (64, 64, 24), (128, 128, 12)] else 1
         for k, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
@@ -54,7 +55,7 @@ def main():
                          fwd_tf=round(fl / t_f / 1e9, 2), dgrad_tf=round(fl / t_d / 1e9, 2) if t_d else None, wgrad_tf=round(fl / t_w / 1e9, 2)))
         print(rows[-1], flush=True)
     print("per-volume totals (ms, x2 for the repeated shapes):", {k: round(v, 3) for k, v in tot.items()}, "sum", round(sum(tot.values()), 3))
-    json.dump(rows, open(os.path.join("gpurun_out", "conv_bench.json"), "w"), indent=1)
+    json.dump(rows, open(os.path.join("gpurun_out", os.environ.get("ICL_CONV_BENCH_OUT", "conv_bench.json")), "w"), indent=1)
 
 
 if __name__ == "__main__":
