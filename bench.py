@@ -190,6 +190,7 @@ def main():
     if rank == 0 and not args.no_kernel_timer:
         trainer.graph = trainer.graph_update = None   # per-kernel HIP-event timing needs eager launches ...
         trainer.ddp = None                              # ... of this rank's step alone: the other ranks are done
+        ops.SideStream.enabled = False                  # ... on ONE stream: a kernel's duration is its own, not a share of the GPU
         with ops.KernelTimer() as kt:
             for _ in range(3):
                 trainer.step(vol, lab)
@@ -245,6 +246,11 @@ def main():
             del trainer, model
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(nc, args.model)
+        try:    # RCCL / HIP banners sit in the C stdio buffer of a piped stdout: push them out first, the JSON line comes last
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
     if use_ddp:
         torch.distributed.barrier()    # rank 0 may still have been timing kernels

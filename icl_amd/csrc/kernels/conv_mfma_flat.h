@@ -156,21 +156,32 @@ __global__ __launch_bounds__(256) void conv3d_mfma_fwd_flat_kernel(const float* 
     store_chunk();
     __syncthreads();
     if (ci + g.ksplit < nchunks) load_chunk((ci + g.ksplit) * KC);
-#pragma unroll
-    for (int tap = 0; tap < T; ++tap) {
+    // software pipeline over the T * KC/4 k-steps of the chunk: the operands of step i+1 are read from LDS before the MFMAs of
+    // step i are issued (see conv3d_mfma_wgrad_static_kernel)
+    constexpr int STEPS = T * (KC / 4);
+    auto load_ab = [&](int step, float (&av)[MV], float (&bv)[NBT]) {
+      const int tap = step / (KC / 4), cc = (step % (KC / 4)) * 4;
       const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
 #pragma unroll
-      for (int cc = 0; cc < KC; cc += 4) {
-        float b[NBT];
+      for (int j = 0; j < NBT; ++j) bv[j] = Ws[bbase[j] + (tap * KC + cc) * NBP];
 #pragma unroll
-        for (int j = 0; j < NBT; ++j) b[j] = Ws[bbase[j] + (tap * KC + cc) * NBP];
+      for (int m = 0; m < MV; ++m) av[m] = Xs[vbase[m] + cc * PS + (dz * PY + dy) * PXL + dx];
+    };
+    float a[MV], an[MV], b[NBT], bn[NBT];
+    load_ab(0, a, b);
 #pragma unroll
-        for (int m = 0; m < MV; ++m) {
-          const float a = Xs[vbase[m] + cc * PS + (dz * PY + dy) * PXL + dx];
+    for (int step = 0; step < STEPS; ++step) {
+      if (step + 1 < STEPS) load_ab(step + 1, an, bn);
+      ICL_SCHED_BARRIER();
 #pragma unroll
-          for (int j = 0; j < NBT; ++j) acc[m][j] = icl_mfma_16x16x4(a, b[j], acc[m][j]);
-        }
-      }
+      for (int m = 0; m < MV; ++m)
+#pragma unroll
+        for (int j = 0; j < NBT; ++j) acc[m][j] = icl_mfma_16x16x4(a[m], b[j], acc[m][j]);
+      ICL_SCHED_BARRIER();
+#pragma unroll
+      for (int m = 0; m < MV; ++m) a[m] = an[m];
+#pragma unroll
+      for (int j = 0; j < NBT; ++j) b[j] = bn[j];
     }
   }
 
