@@ -679,3 +679,47 @@ def test_graph_replay_equals_eager_steps(dev):
     b = ops.dropout(x, 0.3)
     assert abs((a != 0).float().mean().item() - 0.7) < 0.02 and not torch.equal(a != 0, b != 0)
     ops.StepRNG.tensor = None
+
+
+def test_aligner_side_stream_equals_single_stream(dev):
+    """ops.SideStream (aligner heads forked onto a second HIP stream, forward and backward) changes the schedule, not the result:
+    losses, every dense gradient and the factored mlp2 gradients of one step equal those of the single-stream run up to the
+    run-to-run noise of the library GEMMs (a race between the streams would show as garbage, not as 1e-6)."""
+    from icl_amd import ops
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, 2).to(dev)
+    runs = []
+    prev = ops.SideStream.enabled
+    try:
+        for side in (False, True, True):        # the second two-stream run reuses the allocator state of the first
+            ops.SideStream.enabled = side
+            ops.StepRNG.tensor = None
+            model = unet_3D_icl(n_classes=2, in_channels=1, device=dev)
+            fill_like_reference_init(list(model.named_parameters()))
+            _parity_mode(model)
+            model.train()
+            tr = ICLTrainer(model, ICLConfig(num_classes=2, labeled_bs=1, max_iterations=10))
+            parts = tr._forward_backward(vol, lab)
+            torch.cuda.synchronize()
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            facs = {k: [(g.detach().clone(), x.detach().clone()) for g, x in p._icl_factors] for k, p in model.named_parameters()
+                    if getattr(p, "_icl_factors", None)}
+            runs.append(({k: float(v) for k, v in parts.items()}, grads, facs))
+            del tr, model
+            torch.cuda.empty_cache()
+    finally:
+        ops.SideStream.enabled = prev
+        ops.StepRNG.tensor = None
+    base = runs[0]
+    assert len(base[2]) == 8                      # four 13,824^2 and four 1,728^2 token-axis matrices stay factored
+    for losses, grads, facs in runs[1:]:
+        for k, v in base[0].items():
+            assert abs(losses[k] - v) <= 1e-5 * max(1.0, abs(v)), (k, losses[k], v)
+        assert grads.keys() == base[1].keys() and facs.keys() == base[2].keys()
+        for k, g in base[1].items():
+            assert rel_err(grads[k].cpu(), g.cpu()) < 2e-4, k
+        for k, pairs in base[2].items():
+            for (g0, x0), (g1, x1) in zip(pairs, facs[k]):
+                assert rel_err(g1.cpu(), g0.cpu()) < 2e-4 and rel_err(x1.cpu(), x0.cpu()) < 2e-4, k
