@@ -330,10 +330,10 @@ __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kern
     store_tile();
     __syncthreads();
     if (bt + 1 < bt_end) load_tile(bt + 1);
-    if constexpr (NCB >= 2) {
+    if constexpr (NCB == 2) {
       // one x-row of the tile (16 voxels = 4 k-steps) at a time: per operand ONE row base register and the four k-steps at
       // dword offsets 0/4/8/12, which the compiler pairs into ds_read2_b32 (8-bit dword offsets).
-      // Software pipeline (two / three cout blocks at two waves per SIMD: +3-8 % on the 32- and 48-multiple layers): the B
+      // Software pipeline (two cout blocks at two waves per SIMD: +3-8 % on the 32-multiple layers): the B
       // operand of the NEXT (row, tap) step — and, at the last tap of a row, the A operand of the next row — is read from LDS
       // before the MFMAs of the current step are issued (left to itself the compiler emits read, wait lgkmcnt(0), 4 MFMAs for
       // every half step, i.e. the whole LDS latency in front of every 128 cycles of matrix work).
@@ -381,8 +381,9 @@ __global__ __launch_bounds__(64 * WV, WV / 2) void conv3d_mfma_wgrad_static_kern
         }
       }
     } else {
-      // one cout block (124 registers, four waves per SIMD): the explicit prefetch spills (128 registers + 40 B scratch) and is 1-3 % slower;
-      // with four waves per SIMD the other waves cover the LDS latency
+      // one cout block (124 registers, four waves per SIMD): the explicit prefetch spills (128 registers + 40 B scratch) and is 1-3 %
+      // slower — the other waves cover the LDS latency; three cout blocks: 256 registers + 164 B scratch with the prefetch, 6-8 %
+      // slower (48->48 @96^3: 97 -> 89 TFLOP/s)
       // one x-row of the tile (16 voxels = 4 k-steps) at a time: per operand ONE row base register and the four k-steps at
       // dword offsets 0/4/8/12, which the compiler pairs into ds_read2_b32 (8-bit dword offsets) — half the LDS instructions
 #pragma unroll

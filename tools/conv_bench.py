@@ -13,6 +13,10 @@ LAYERS = [(1, 16, 96), (16, 16, 96), (16, 32, 48), (32, 32, 48), (32, 64, 24), (
           (128, 256, 6), (256, 256, 6), (384, 128, 12), (192, 64, 24), (96, 32, 48), (48, 16, 96)]
 
 
+if os.environ.get("ICL_CONV_BENCH_LAYERS"):      # "cin,cout,side;cin,cout,side;..."
+    LAYERS = [tuple(int(v) for v in item.split(",")) for item in os.environ["ICL_CONV_BENCH_LAYERS"].split(";")]
+
+
 def timeit(fn, iters=10):
     fn()
     torch.cuda.synchronize()
