@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph"],
+                    help="one rank: auto = after capture, time 3 replayed and 3 eager steps and run the timed region in the faster mode "
+                         "(with the aligner heads on their own stream an eager step beats the replay when the host keeps up); "
+                         "graph = always replay.  N > 1 always replays.")
     ap.add_argument("--force-ddp", action="store_true", help="with --gpus 1: run the data-parallel step on a one-rank RCCL group")
     args = ap.parse_args()
 
@@ -152,6 +156,7 @@ def main():
         torch.cuda.synchronize()
 
     graphed = not args.no_graph
+    launch_probe = None
     if graphed:
         # N > 1: forward/backward graph, eager RCCL collectives, optimiser graph (ICLTrainer.capture)
         ok = 1
@@ -170,6 +175,20 @@ def main():
                 ddp.static = False
                 graphed = False
         trainer.step(vol, lab)
+        if graphed and ddp is None and args.launch == "auto":
+            def probe(use_graph, k=3):
+                trainer.use_graph = use_graph
+                trainer.step(vol, lab)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(k):
+                    trainer.step(vol, lab)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / k
+            t_graph, t_eager = probe(True), probe(False)
+            launch_probe = {"graph_ms": round(t_graph * 1e3, 3), "eager_ms": round(t_eager * 1e3, 3)}
+            trainer.use_graph = t_graph <= t_eager
+            graphed = trainer.use_graph
     else:
         for _ in range(args.warmup):
             trainer.step(vol, lab)
@@ -239,7 +258,8 @@ def main():
                                    f"batch=2 per GPU (1 labeled + 1 unlabeled), full ICL step incl. SGD",
                        "global_batch": 2 * world, "parallelism": f"dp{world}",
                        "launch": ("eager" if not graphed else "hipGraph replay" if ddp is None else
-                                  "hipGraph replay (forward/backward, optimiser) + eager RCCL collectives")},
+                                  "hipGraph replay (forward/backward, optimiser) + eager RCCL collectives"),
+                       **({"launch_probe": launch_probe} if launch_probe else {})},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

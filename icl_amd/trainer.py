@@ -56,6 +56,7 @@ class ICLTrainer:
         BatchNormAct.share_counters(model)   # one vector for all BatchNorm step counters: one add per step
         self.graph = None
         self.graph_update = None
+        self.use_graph = True     # False: launch eagerly although a captured graph exists (bench.py --launch auto compares the two)
         self.lr_dev = None
 
     def compute_loss(self, outputs, label_batch):
@@ -111,12 +112,13 @@ class ICLTrainer:
         """One iteration; returns the (device-resident, un-synced) loss terms.  After ``capture()`` the whole iteration
         (forward, losses, backward, optimiser) is one hipGraph replay: ~1400 kernel launches per step otherwise cost
         ~21 ms of host time, on par with the GPU time."""
-        if self.graph is not None:
+        if self.lr_dev is not None:       # after capture() the kernels read the learning rate from device memory, replayed or not
+            self.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
+        if self.graph is not None and self.use_graph:
             if volume_batch.data_ptr() != self.static_vol.data_ptr():
                 self.static_vol.copy_(volume_batch)
             if label_batch.data_ptr() != self.static_lab.data_ptr():
                 self.static_lab.copy_(label_batch)
-            self.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
             self.graph.replay()
             if self.graph_update is not None:    # data-parallel: collectives between the two graphs
                 self.ddp.communicate()
