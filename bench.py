@@ -229,6 +229,9 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": traffic["hbm_bytes"] if traffic else None, "traffic_detail": traffic,
                     "launches_per_step": n // 3, "avg_launch_us": round(ms * 1e3 / n, 2),
+                    # what the event pair itself adds to a bracketed launch on the idle eager stream (NOT subtracted above: the raw
+                    # durations are the conservative ones; rocprofv3's per-kernel averages in profiles/ are shorter by about this much)
+                    "event_bracket_overhead_us": round(ops.event_bracket_overhead_us(dev), 2),
                     "all_conv": {"ms_per_step": round(tot_ms / 3, 3), "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 3),
                                  "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                  "algorithmic_gbs": round(tot_by / (tot_ms * 1e-3) / 1e9, 1),

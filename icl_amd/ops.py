@@ -110,6 +110,23 @@ class KernelTimer:
         return out
 
 
+def event_bracket_overhead_us(device, reps: int = 40) -> float:
+    """Median HIP-event duration of a bracket around a one-element fill kernel: what an event pair adds to the kernel it brackets on an
+    otherwise idle stream (dispatch latency of the kernel packet behind the event packet).  bench.py reports it next to the raw numbers."""
+    t = torch.zeros(1, device=device)
+    s = torch.cuda.current_stream(device)
+    vals = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        t.fill_(1.0)
+        e1.record(s)
+        torch.cuda.synchronize(device)
+        vals.append(e0.elapsed_time(e1) * 1e3)
+    vals.sort()
+    return vals[len(vals) // 2]
+
+
 class _TimedRegion:
     def __init__(self, kt, name, flops, nbytes, like):
         self.kt, self.name, self.flops, self.nbytes, self.like = kt, name, flops, nbytes, like
