@@ -372,6 +372,45 @@ __global__ __launch_bounds__(256) void resize_bwd_axis_i4_kernel(const float* __
   }
 }
 
+// resize_bwd_axis for the x pass (inner == 1) of LARGE upscales (the 6/12/24 -> 96 maps of the deep-supervision losses, 16 classes:
+// 56 MB of dY): the per-thread walk of resize_bwd_axis_i4_kernel reads dY four bytes at a time with a 16-output stride between
+// lanes (147 us for 56 MB).  Here a workgroup stages kRbxRows complete rows of dY in LDS with coalesced 16-byte loads and every
+// thread then gathers its (row, i) sums from LDS — same taps, same summation order over o as the other variants.
+// Lo % 4 == 0, 16-byte aligned rows; LDS = kRbxRows * (Lo + 4) floats; grid ceil(B * rows / kRbxRows).
+constexpr int kRbxRows = 32;
+__global__ __launch_bounds__(256) void resize_bwd_axis_x_lds_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, long rows,
+                                                                    int Li, int Lo, float rscale, long src_bstride, int align) {
+  ICL_DYN_LDS(float, tile);
+  const int pitch = Lo + 4, lo4 = Lo >> 2;
+  const long total_rows = (long)B * rows;
+  const long r0 = (long)blockIdx.x * kRbxRows;
+  for (int it = threadIdx.x; it < kRbxRows * lo4; it += 256) {
+    const int row = it / lo4, q = it - row * lo4;
+    const long gr = r0 + row;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gr < total_rows) {
+      const long b = gr / rows, rr = gr - b * rows;
+      v = *reinterpret_cast<const float4*>(src + b * src_bstride + rr * Lo + q * 4);
+    }
+    *reinterpret_cast<float4*>(tile + row * pitch + q * 4) = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kRbxRows * Li; e += 256) {
+    const int row = e / Li, i = e - row * Li;
+    const long gr = r0 + row;
+    if (gr >= total_rows) break;
+    int lo, hi;
+    lin_range(i, rscale, Lo, align, lo, hi);
+    const float* p = tile + row * pitch;
+    float acc = 0.f;
+    for (int o = lo; o <= hi; ++o) {
+      const float w = lin_w(o, i, rscale, Li, align);
+      if (w != 0.f) acc += w * p[o];
+    }
+    dst[gr * Li + i] = acc;
+  }
+}
+
 // dst[r*dst_stride + i] = src[r*src_stride + i], i < row_elems
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows,
                                                         long row_elems, long src_stride, long dst_stride) {

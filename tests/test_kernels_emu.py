@@ -139,6 +139,7 @@ def test_maxpool_ties_and_grad():
 
 @pytest.mark.parametrize("ins,outs", [((3, 4, 5), (6, 8, 10)), ((2, 2, 2), (12, 12, 12)), ((6, 6, 6), (24, 24, 24)),
                                       ((4, 4, 8), (8, 12, 16)), ((5, 3, 12), (7, 6, 20)),
+                                      ((3, 6, 6), (12, 24, 48)),      # >= 4x along x: LDS-staged x pass of the backward, ragged last row block
                                       # exact 2x: the specialised one-pass kernels (bwd needs W % 4 == 0), incl. size-1 / size-2 axes
                                       ((4, 6, 8), (8, 12, 16)), ((1, 2, 4), (2, 4, 8)), ((6, 6, 6), (12, 12, 12)), ((3, 5, 12), (6, 10, 24))])
 def test_trilinear(ins, outs):
