@@ -114,23 +114,31 @@ __global__ __launch_bounds__(256) void loss_stats_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ stats,
                                                             const float* __restrict__ weight, float* __restrict__ out, int nc,
                                                             float inv_vox, float inv_elems, int mode) {
-  // lanes = slots (a wave reads the nslot consecutive floats of a block's partials: coalesced), the four waves take the blocks
-  // b = wave, wave + 4, ...; the four sums of a slot are added in wave order.  (One wave per slot with lanes over the blocks
-  // read with a stride of nslot floats: 34 us for 16 classes.)
+  // 256 threads = S slot lanes x G block groups (S = power of two >= min(nslot, 64)): thread (slot, grp) adds the partials of
+  // blocks grp, grp + G, ... — a wave reads runs of consecutive floats (the slots of consecutive blocks) — and the G sums of a
+  // slot are added in group order.  2 classes: 8 x 32; 16 classes: 64 x 4.  (One wave per slot with lanes over the blocks read
+  // with a stride of nslot floats: 34 us for 16 classes.)
   const int nslot = 3 * nc + 1;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  __shared__ float red[4][64];
-  for (int s0 = 0; s0 < nslot; s0 += 64) {
-    const int slot = s0 + lane;
+  __shared__ float red[256];
+  int S = 8;
+  while (S < nslot && S < 64) S <<= 1;
+  const int G = 256 / S;
+  const int sl = threadIdx.x % S, grp = threadIdx.x / S;
+  for (int s0 = 0; s0 < nslot; s0 += S) {
+    const int slot = s0 + sl;
     float v = 0.f;
     if (slot < nslot) {
 #pragma unroll 4
-      for (int b = wid; b < nblk; b += 4) v += part[(long)b * nslot + slot];
+      for (int b = grp; b < nblk; b += G) v += part[(long)b * nslot + slot];
     }
     __syncthreads();
-    red[wid][lane] = v;
+    red[grp * S + sl] = v;
     __syncthreads();
-    if (wid == 0 && slot < nslot) stats[slot] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (grp == 0 && slot < nslot) {
+      float t = red[sl];
+      for (int k = 1; k < G; ++k) t += red[k * S + sl];
+      stats[slot] = t;
+    }
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
