@@ -651,8 +651,9 @@ class _UpCat(torch.autograd.Function):
         s = d * h * w
         gskip = gdeep = None
         if ctx.needs_input_grad[0]:
-            gskip = torch.empty((n, cs, d, h, w), dtype=torch.float32, device=g.device)
-            _lib.check(L.icl_copy_rows(_ptr(g), _ptr(gskip), n, cs * s, (cs + cd) * s, cs * s, _stream(g)), "copy_rows")
+            # a VIEW of the concat gradient, not a copy: the skip tensor also feeds the max-pool, so autograd adds this to the pooling
+            # gradient right away (one strided read instead of a copy pass plus a read); a sole consumer makes it contiguous itself
+            gskip = g[:, :cs]
         if ctx.needs_input_grad[1]:
             gdeep = torch.empty((n, cd, d // 2, h // 2, w // 2), dtype=torch.float32, device=g.device)
             gv = g[:, cs:]
