@@ -63,6 +63,12 @@ _SIGNATURES = {
     "icl_im2col3": (c_int, [P, P, I, I, I, I, I, P]),
     "icl_im2col3_planes": (c_int, [P, P, I, I, I, I, I, P]),
     "icl_col2im3": (c_int, [P, P, I, I, I, I, I, P]),
+    "icl_linear_ws_bytes": (c_int64, [L, I, I, I]),
+    "icl_linear_fwd": (c_int, [P, P, P, P, P, L, I, I, I, P]),
+    "icl_linear_dgrad": (c_int, [P, P, P, P, L, I, I, P]),
+    "icl_linear_wgrad_small": (c_int, [P, P, P, P, L, I, I, P]),
+    "icl_gemm_ws_bytes": (c_int64, [L, I, I, I]),
+    "icl_gemm": (c_int, [P, P, P, P, P, L, I, I, L, L, L, I, I, I, I, L, L, L, P]),
     "icl_linear_wgrad_ws_bytes": (c_int64, [L, I, I]),
     "icl_linear_wgrad": (c_int, [P, P, P, P, P, L, I, I, P]),
     "icl_conv1x1_wgrad_ws_bytes": (c_int64, [I, L, I, I]),

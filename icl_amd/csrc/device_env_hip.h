@@ -26,6 +26,11 @@ __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 // nothing may be scheduled across this point (keeps software-prefetched LDS reads ahead of the MFMAs they overlap)
 #define ICL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 
+// All lanes of a wave have executed what precedes this point before any lane continues.  On the GPU a wave runs in lockstep and
+// its LDS operations execute in issue order, so this is only a compiler scheduling fence (no instruction); the CPU emulation,
+// where lanes are independent fibers, makes it a rendezvous.  Used between the writes and reads of a wave-private LDS buffer.
+#define ICL_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+
 // tell the compiler a value is the same in every lane of the wave (lets it use SGPRs / scalar loads for what depends on it)
 #define ICL_WAVE_UNIFORM(x) ((x) = __builtin_amdgcn_readfirstlane(x))
 

@@ -1,0 +1,382 @@
+// gemm.h — the dense fp32 products of the ICL hot path on v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain).
+//
+// Reference operators replaced (paths relative to /root/reference/code):
+//   nn.Linear forward / input gradient / weight gradient of the aligner heads — fc_q, fc_kv, proj, MLP.fc1/fc2 and the token-axis
+//   Class_Decoder.mlp2 (networks/unet_3D_icl.py:258-268,283-315), query_convs (Conv1d k=1, :197), the token projection (:212);
+//   the Swin qkv / proj / MLP / PatchMerging / PatchEmbed linears (networks/swinunetr_icl.py:703-750,812,946-976,1170);
+//   ConvTranspose3d(k=2, s=2) of MONAI UnetrUpBlock as one product (swinunetr_icl.py:178-225); the 3^3 convolutions on <= 6^3
+//   voxels (`center`, networks/utils.py:104,107) through im2col.
+//
+// Two kernels:
+//   linear_stream_kernel     y = x W^T and gx = gy W for <= 32 rows: the weight matrix is STREAMED once from HBM (4 rows x 256
+//                            contiguous bytes per wave instruction), the small operand stays resident in LDS;
+//   gemm_kernel              C = A B for everything else: LDS-staged 64x64 wave tiles, operands either "k-contiguous" (row-major
+//                            [rows][K]) or "k-strided" ([K][rows]); optional split-K into slabs summed in a fixed order.
+// The MFMA k index is only a label, so a lane's float4 (16-byte) load supplies four k values (k-contiguous operand) or four
+// output columns / rows (k-strided operand) to four MFMAs and no register transposes are needed.
+#pragma once
+
+namespace icl {
+
+__device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+// epilogue shared by all product kernels: bias (per output column) and activation (0 none, 1 exact-erf GELU)
+__device__ __forceinline__ float gemm_epilogue(float v, const float* __restrict__ bias, int col, int act) {
+  if (bias) v += bias[col];
+  if (act == 1) v = gelu_erf(v);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ weight streaming
+// Skinny products against a big row-major weight W [O][K] (the 13,824^2 token-axis MLP, <= 32 activation rows):
+//   NN = false  forward         part[s][m][o] = sum_{k in slice s} xs[m][k] W[o][k]      xs = x  [M][K]
+//   NN = true   input gradient  part[s][m][k] = sum_{o in slice s} xs[m][o] W[o][k]      xs = gy [M][O]
+// W is read exactly once, at the HBM rate.  Measured on MI355X (tools/probe/rowwidth_probe.hip): a wave instruction must cover
+// >= 256 contiguous bytes per weight row to stream at 6.6 TB/s (128 B: 6.0, the 64 B of an MFMA-fragment-shaped load: 3.6-4.6),
+// so every load instruction here is 4 rows x 256 B (lane l: row l >> 4, 16-byte quad l & 15) and the 16 x 64 tile goes through a
+// wave-private 4 KiB LDS buffer into the MFMA operand layout (LDS operations of one wave execute in order: no barrier in the loop).
+// The contraction axis is cut into `nslice` slices; the workgroup (8 waves) keeps the slice of the small operand xs resident in
+// LDS (k-contiguous rows, quads XOR-swizzled with the row so a fragment read is conflict free) and each wave walks `upw` units
+// of the other weight axis: a unit is 16 weight rows (forward: one MFMA tile of outputs, the wave walks the slice's 64-column
+// tiles) or 64 weight columns (input gradient: four MFMA tiles, the wave walks down the slice's 16-row tiles).  P tiles are in
+// flight per wave (registers).  Partials go to slab[slice]; gemm_reduce_slabs_kernel adds them in a fixed order (+ bias, act).
+// grid (ceil(units / (8 upw)), nslice), block 512, dynamic LDS = (16 MT slice_len + 8 * 1024) floats; slice_len % 64 == 0, K % 4 == 0.
+template <int MT, bool NN, int P>
+__global__ __launch_bounds__(512) void linear_stream_kernel(const float* __restrict__ xs, const float* __restrict__ w, float* __restrict__ slab,
+                                                            int M, int K, int O, int slice_len, int upw) {
+  ICL_DYN_LDS(float, lds);
+  float* xl = lds;                                        // [16 MT][slice_len], quad q of row m stored at quad q ^ (m & 15)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, u = lane & 15, lg = lane >> 4;
+  float* wl = lds + 16 * MT * slice_len + wid * 1024;     // this wave's 16 x 64 weight tile
+  const int cdim = NN ? O : K;                            // contraction axis (columns of xs)
+  const int c0 = blockIdx.y * slice_len;
+  const int clen = c0 + slice_len < cdim ? slice_len : cdim - c0;   // > 0 by construction of the grid
+  const int tpu = NN ? (clen + 15) / 16 : (clen + 63) / 64;         // tiles per unit
+  const int nunits = NN ? (K + 63) / 64 : (O + 15) / 16;
+  const int unit0 = (blockIdx.x * 8 + wid) * upw;
+  int my_units = nunits - unit0;
+  if (my_units > upw) my_units = upw;
+  const int total = my_units > 0 ? my_units * tpu : 0;
+
+  // ---- weight tile stream (loads are issued first so that they overlap the staging of xs)
+  float4 ring[P][4];
+  int l_unit = unit0, l_t = 0;                            // position of the next tile to load
+  auto issue = [&](int p, bool live) {
+    // tile rows/cols: forward: rows 16 unit + 4 j + lg, cols c0 + 64 t + 4 u;  gradient: rows c0 + 16 t + 4 j + lg, cols 64 unit + 4 u
+    const int row0 = NN ? c0 + 16 * l_t : 16 * l_unit;
+    const int col = (NN ? 64 * l_unit : c0 + 64 * l_t) + 4 * u;
+    const int row_end = NN ? c0 + clen : O, col_end = NN ? K : c0 + clen;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = row0 + 4 * j + lg;
+      const bool ok = live && row < row_end && col < col_end;
+      ring[p][j] = icl_nt_load4(w + (ok ? (long)row * K + col : 0L));
+      if (!ok) ring[p][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (++l_t == tpu) { l_t = 0; ++l_unit; }
+  };
+#pragma unroll
+  for (int p = 0; p < P; ++p) issue(p, p < total);
+
+  // ---- resident slice of the small operand
+  const int qpr = slice_len >> 2;                         // quads per row
+  for (int it = tid; it < 16 * MT * qpr; it += 512) {
+    const int m = it / qpr, q = it % qpr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M && 4 * q < clen) v = *reinterpret_cast<const float4*>(xs + (long)m * cdim + c0 + 4 * q);
+    *reinterpret_cast<float4*>(xl + m * slice_len + 4 * (q ^ (m & 15))) = v;
+  }
+  __syncthreads();
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[t][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int c_unit = unit0, c_t = 0;                            // position of the tile being computed
+  float* out = slab + (long)blockIdx.y * 16 * MT * (NN ? K : O);
+
+  for (int base = 0; base < total; base += P) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (base + p >= total) break;
+      // registers -> wave-private LDS tile [16][64]; forward swizzles the quad with the row (fragment rows = lanes u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 4 * j + lg;
+        *reinterpret_cast<float4*>(wl + row * 64 + 4 * (NN ? u : (u ^ row))) = ring[p][j];
+      }
+      ICL_WAVE_SYNC();
+      issue(p, base + p + P < total);
+      if (!NN) {
+        // 64 columns of the tile = 4 groups of 16 k labels: lane (u, lg) takes k = 64 t + 16 s + 4 lg + e of weight row u / xs row u
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float4 b = *reinterpret_cast<const float4*>(wl + u * 64 + 4 * ((4 * s + lg) ^ u));
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const int m = 16 * t + u;
+            const float4 a = *reinterpret_cast<const float4*>(xl + m * slice_len + 4 * ((16 * c_t + 4 * s + lg) ^ u));
+            acc[t][0] = icl_mfma_16x16x4(a.x, b.x, acc[t][0]);
+            acc[t][1] = icl_mfma_16x16x4(a.y, b.y, acc[t][1]);
+            acc[t][2] = icl_mfma_16x16x4(a.z, b.z, acc[t][2]);
+            acc[t][3] = icl_mfma_16x16x4(a.w, b.w, acc[t][3]);
+          }
+        }
+      } else {
+        // 16 weight rows of the tile = k labels 16 t + 4 lg + e; each row read gives four consecutive output columns 4 u + e'
+        float4 b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = *reinterpret_cast<const float4*>(wl + (4 * lg + e) * 64 + 4 * u);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int m = 16 * t + u;
+          const float4 a = *reinterpret_cast<const float4*>(xl + m * slice_len + 4 * ((4 * c_t + lg) ^ u));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float av = f4c(a, e);
+            acc[t][0] = icl_mfma_16x16x4(av, b[e].x, acc[t][0]);
+            acc[t][1] = icl_mfma_16x16x4(av, b[e].y, acc[t][1]);
+            acc[t][2] = icl_mfma_16x16x4(av, b[e].z, acc[t][2]);
+            acc[t][3] = icl_mfma_16x16x4(av, b[e].w, acc[t][3]);
+          }
+        }
+      }
+      if (++c_t == tpu) {
+        // unit done: D register q of lane (u, lg) is row 16 t + 4 lg + q
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int m = 16 * t + 4 * lg + q;
+            if (NN) {
+              const int col = 64 * c_unit + 4 * u;
+              if (col < K) *reinterpret_cast<float4*>(out + (long)m * K + col) = make_float4(acc[t][0][q], acc[t][1][q], acc[t][2][q], acc[t][3][q]);
+            } else {
+              const int o = 16 * c_unit + u;
+              if (o < O) out[(long)m * O + o] = (acc[t][0][q] + acc[t][1][q]) + (acc[t][2][q] + acc[t][3][q]);
+            }
+          }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        c_t = 0;
+        ++c_unit;
+      }
+    }
+  }
+}
+
+// out[m][n] = act(bias[n] + sum_s slab[s][m][n]) for m < M: fixed-order sum of split partials (bitwise reproducible).
+// slab rows have pitch `spitch` and slabs are `sstride` floats apart; out rows have pitch ldo.  N % 4 == 0.
+__global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, const float* __restrict__ bias,
+                                                                int S, long M, int N, long spitch, long sstride, long ldo, int act_flags) {
+  const int act = act_flags & 15;
+  const bool brow = (act_flags & 16) != 0;            // bias indexed by the output row instead of the column
+  const int nq = N >> 2;
+  const long total = M * nq;
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long m = it / nq;
+    const int n = (int)(it % nq) * 4;
+    float4 a = *reinterpret_cast<const float4*>(slab + m * spitch + n);
+    for (int s = 1; s < S; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(slab + s * sstride + m * spitch + n);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    a.x = gemm_epilogue(a.x, bias, brow ? (int)m : n, act);
+    a.y = gemm_epilogue(a.y, bias, brow ? (int)m : n + 1, act);
+    a.z = gemm_epilogue(a.z, bias, brow ? (int)m : n + 2, act);
+    a.w = gemm_epilogue(a.w, bias, brow ? (int)m : n + 3, act);
+    *reinterpret_cast<float4*>(out + m * ldo + n) = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ general product
+// C[m][n] = sum_k A(m,k) B(k,n), block tile (WM*64) x (WN*64), wave tile 64 x 64 (4 x 4 MFMA tiles), k-steps of 32 staged in LDS.
+//   AK  = true : A is row-major [M][lda], k contiguous.   LDS image rows x 32 floats, the eight 16-byte quads of a row XOR-swizzled
+//                with (row >> 1) & 7: the fragment read (lane (u = l & 15, lg): row 16 i + u, quad 4 s + lg, one ds_read_b128 = four
+//                k labels) touches 16 different 16-byte slots per lane group — conflict free;
+//   AK  = false: A is given transposed, [K][lda] with m contiguous.  LDS image 32 k-rows x (WM*64) floats; the fragment read of
+//                k row 16 s + 4 lg + e takes four consecutive m (tile c of the 64-row group holds rows 4 u + c): conflict free.
+//   BK_ likewise for B: true = [N][ldb] (k contiguous: y = x W^T), false = [K][ldb] (n contiguous: gx = gy W).
+// Split-K: split z of nsplit takes the z-th k range of `kper` (multiple of 32) and writes a raw partial tile to C + z * c_split_stride.
+// Epilogue (only when not split): bias per column (act flag 16: per row) + activation (low bits of act).  Global tiles are fetched into registers one k-step ahead.
+struct GemmArgs {
+  const float* a;
+  const float* b;
+  float* c;
+  const float* bias;
+  long lda, ldb, ldc, c_split_stride;
+  long a_bstride, b_bstride, c_bstride;   // batched products: blockIdx.z = batch * nsplit + split
+  int M, N, K, kper, nsplit, act;
+};
+
+__device__ __forceinline__ float4 gemm_load4(const float* __restrict__ base, long ld, int row, int col, int rows, int cols, bool vec_ok) {
+  // element (row, col..col+3) of a row-major [rows][ld] matrix; zeros outside
+  if (row >= rows || col >= cols) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* p = base + (long)row * ld + col;
+  if (vec_ok && col + 3 < cols) return *reinterpret_cast<const float4*>(p);
+  float4 v;
+  v.x = p[0];
+  v.y = col + 1 < cols ? p[1] : 0.f;
+  v.z = col + 2 < cols ? p[2] : 0.f;
+  v.w = col + 3 < cols ? p[3] : 0.f;
+  return v;
+}
+
+template <bool AK, bool BK_, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
+  constexpr int NT = WM * WN * 64, BM = WM * 64, BN = WN * 64, KT = 32;
+  constexpr int AV = BM * KT / 4 / NT, BV = BN * KT / 4 / NT;       // float4 per thread and k-step
+  ICL_DYN_LDS(float, lds);
+  float* as = lds;                 // AK: [BM][32] swizzled; else [32][BM]
+  float* bs = lds + BM * KT;       // BK_: [BN][32] swizzled; else [32][BN]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, u = lane & 15, lg = lane >> 4;
+  const int wm = wid / WN, wn = wid % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int batch = blockIdx.z / g.nsplit, split_id = blockIdx.z % g.nsplit;
+  const int k_lo = split_id * g.kper;
+  const int k_hi = k_lo + g.kper < g.K ? k_lo + g.kper : g.K;
+  g.a += batch * g.a_bstride;
+  g.b += batch * g.b_bstride;
+  const bool avec = (g.lda & 3) == 0 && (((unsigned long long)g.a) & 15ull) == 0;
+  const bool bvec = (g.ldb & 3) == 0 && (((unsigned long long)g.b) & 15ull) == 0;
+  float4 ar[AV], br[BV];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < AV; ++j) {
+      const int it = tid + j * NT;
+      if (AK) {   // item = (row, quad): 8 quads per row
+        const int row = it >> 3, q = it & 7;
+        ar[j] = gemm_load4(g.a, g.lda, m0 + row, k0 + 4 * q, g.M, k_hi, avec);
+      } else {    // item = (k row, quad of m): BM/4 quads per k row
+        const int kr = it / (BM / 4), q = it % (BM / 4);
+        ar[j] = gemm_load4(g.a, g.lda, k0 + kr, m0 + 4 * q, k_hi, g.M, avec);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+      const int it = tid + j * NT;
+      if (BK_) {
+        const int row = it >> 3, q = it & 7;
+        br[j] = gemm_load4(g.b, g.ldb, n0 + row, k0 + 4 * q, g.N, k_hi, bvec);
+      } else {
+        const int kr = it / (BN / 4), q = it % (BN / 4);
+        br[j] = gemm_load4(g.b, g.ldb, k0 + kr, n0 + 4 * q, k_hi, g.N, bvec);
+      }
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int j = 0; j < AV; ++j) {
+      const int it = tid + j * NT;
+      if (AK) {
+        const int row = it >> 3, q = it & 7;
+        *reinterpret_cast<float4*>(as + row * KT + 4 * (q ^ ((row >> 1) & 7))) = ar[j];
+      } else {
+        *reinterpret_cast<float4*>(as + 4 * it) = ar[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+      const int it = tid + j * NT;
+      if (BK_) {
+        const int row = it >> 3, q = it & 7;
+        *reinterpret_cast<float4*>(bs + row * KT + 4 * (q ^ ((row >> 1) & 7))) = br[j];
+      } else {
+        *reinterpret_cast<float4*>(bs + 4 * it) = br[j];
+      }
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += KT) {
+    __syncthreads();
+    stash();
+    __syncthreads();
+    if (k0 + KT < k_hi) fetch(k0 + KT);
+#pragma unroll
+    for (int s = 0; s < KT / 16; ++s) {
+      // operand fragments of this 16-deep k group: af[e][i] / bf[e][t] = value of MFMA tile i / t for k label 16 s + 4 lg + e
+      float af[4][4], bf[4][4];
+      if (AK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wm * 64 + 16 * i + u;
+          const float4 v = *reinterpret_cast<const float4*>(as + row * KT + 4 * ((4 * s + lg) ^ ((row >> 1) & 7)));
+          af[0][i] = v.x; af[1][i] = v.y; af[2][i] = v.z; af[3][i] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float4 v = *reinterpret_cast<const float4*>(as + (16 * s + 4 * lg + e) * BM + wm * 64 + 4 * u);
+          af[e][0] = v.x; af[e][1] = v.y; af[e][2] = v.z; af[e][3] = v.w;
+        }
+      }
+      if (BK_) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = wn * 64 + 16 * t + u;
+          const float4 v = *reinterpret_cast<const float4*>(bs + row * KT + 4 * ((4 * s + lg) ^ ((row >> 1) & 7)));
+          bf[0][t] = v.x; bf[1][t] = v.y; bf[2][t] = v.z; bf[3][t] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float4 v = *reinterpret_cast<const float4*>(bs + (16 * s + 4 * lg + e) * BN + wn * 64 + 4 * u);
+          bf[e][0] = v.x; bf[e][1] = v.y; bf[e][2] = v.z; bf[e][3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[i][t] = icl_mfma_16x16x4(af[e][i], bf[e][t], acc[i][t]);
+    }
+  }
+  // D register q of tile (i, t), lane (u, lg): A-side index 4 lg + q, B-side index u.
+  //   AK : row = 16 i + (4 lg + q)       else: row = 4 (4 lg + q) + i
+  //   BK_: col = 16 t + u                else: col = 4 u + t   (t = 0..3 consecutive: 16-byte stores)
+  float* c = g.c + batch * g.c_bstride + (long)split_id * g.c_split_stride;
+  const int act = g.act & 15;
+  const bool brow = (g.act & 16) != 0;
+  const bool split = g.c_split_stride != 0 || g.nsplit > 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = m0 + wm * 64 + (AK ? 16 * i + 4 * lg + q : 4 * (4 * lg + q) + i);
+      if (row >= g.M) continue;
+      float* crow = c + (long)row * g.ldc;
+      if (BK_) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int col = n0 + wn * 64 + 16 * t + u;
+          if (col < g.N) crow[col] = split ? acc[i][t][q] : gemm_epilogue(acc[i][t][q], g.bias, brow ? row : col, act);
+        }
+      } else {
+        const int col = n0 + wn * 64 + 4 * u;
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = (split || col + t >= g.N) ? acc[i][t][q] : gemm_epilogue(acc[i][t][q], g.bias, brow ? row : col + t, act);
+        if (col + 3 < g.N && (g.ldc & 3) == 0 && (((unsigned long long)c) & 15ull) == 0) {
+          *reinterpret_cast<float4*>(crow + col) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (col + t < g.N) crow[col + t] = v[t];
+        }
+      }
+    }
+}
+
+}  // namespace icl

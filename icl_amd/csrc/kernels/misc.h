@@ -126,6 +126,42 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restr
   }
 }
 
+// ---- the same 1x1x1 convolution for BIG volumes (the `final` 16 -> num_classes convolution on 96^3 voxels, unet_3D_icl.py:65,117,
+// and its input gradient): one thread owns four consecutive voxels and OB output channels, so every input value is loaded once
+// per OB outputs (the kernel above re-reads the input per output channel) and the weights are wave-uniform scalar loads.
+// HBM-bound: 4 (Cin + Cout) bytes per voxel.  grid (voxel-quad blocks, ceil(CO / OB)).
+template <int OB>
+__global__ __launch_bounds__(256) void conv1x1_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y, int N, int CI, int CO,
+                                                             long S, int wos, int wis) {
+  const long S4 = S >> 2, total = (long)N * S4;
+  const int o0 = blockIdx.y * OB;
+  float wb[OB];
+#pragma unroll
+  for (int o = 0; o < OB; ++o) wb[o] = (bias && o0 + o < CO) ? bias[o0 + o] : 0.f;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long v4 = e % S4, b = e / S4;
+    float4 acc[OB];
+#pragma unroll
+    for (int o = 0; o < OB; ++o) acc[o] = make_float4(wb[o], wb[o], wb[o], wb[o]);
+    const float* xp = x + b * CI * S + (v4 << 2);
+    for (int i = 0; i < CI; ++i) {
+      const float4 xv = *reinterpret_cast<const float4*>(xp + (long)i * S);
+#pragma unroll
+      for (int o = 0; o < OB; ++o) {
+        const float wv = o0 + o < CO ? w[(long)(o0 + o) * wos + (long)i * wis] : 0.f;
+        acc[o].x = fmaf(wv, xv.x, acc[o].x);
+        acc[o].y = fmaf(wv, xv.y, acc[o].y);
+        acc[o].z = fmaf(wv, xv.z, acc[o].z);
+        acc[o].w = fmaf(wv, xv.w, acc[o].w);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < OB; ++o)
+      if (o0 + o < CO) *reinterpret_cast<float4*>(y + (b * CO + o0 + o) * S + (v4 << 2)) = acc[o];
+  }
+}
+
 // ---- column sums of up to kColsumMulti small row-major matrices in ONE launch (grid.y = matrix): out_i[c] = sum_r g_i[r][c].
 // The bias gradients of the aligner's Linear layers (a few to a few hundred rows each): the trainer collects them during backward
 // and reduces them together instead of one tiny reduction launch per layer (38 per U-Net step).

@@ -278,21 +278,21 @@ class _Conv3d(torch.autograd.Function):
         s = d * h * w
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        ctx.pointwise_gemm = ks == 1 and n * s >= CONV1X1_GEMM_MIN_VOXELS
+        small_ch = cin <= CONV1X1_SMALL_MAX_CHANNELS and cout <= CONV1X1_SMALL_MAX_CHANNELS and s % 4 == 0
+        ctx.pointwise_gemm = ks == 1 and n * s >= CONV1X1_GEMM_MIN_VOXELS and not small_ch
         if ctx.pointwise_gemm:
-            # 1x1x1 convolution on a big volume = one HBM-bound batched GEMM  W [Cout,Cin] x x[b] [Cin,S]  (plain library GEMM:
-            # 3.2-3.8 TB/s against 1.9-2.4 for the halo-tile kernel, tools/conv1x1_probe.py)
-            w2, x3 = weight.view(cout, cin), x.view(n, cin, s)
-            # bmm with a stride-0 batch of W: torch.matmul(2-D, 3-D) would fold the batch by transposing (copying) the volume
-            wb = w2.unsqueeze(0).expand(n, cout, cin)
-            y = torch.bmm(wb, x3) if bias is None else torch.baddbmm(bias.view(1, cout, 1), wb, x3)
-            return y.view(n, cout, d, h, w)
+            # 1x1x1 convolution with many channels on a big volume = one batched product  W [Cout,Cin] x x[b] [Cin,S]  on the
+            # tiled fp32-MFMA kernel (csrc/kernels/gemm.h), reading the channel-major volume in place (k-strided B operand)
+            y = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
+            gemm(weight, x, cout, s, cin, cin, s, True, False, out=y, ldc=s, bias=bias, act=16, batch=n, b_bstride=cin * s,
+                 c_bstride=cout * s)       # act 16: the bias is indexed by the output row (= channel)
+            return y
         y = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
         ctx.wpt = None
-        ctx.pointwise_small = (ks == 1 and cin <= CONV1X1_SMALL_MAX_CHANNELS and cout <= CONV1X1_SMALL_MAX_CHANNELS and s % 4 == 0
-                               and os.environ.get("ICL_CONV1X1_SMALL", "1") != "0")
+        ctx.pointwise_small = ks == 1 and small_ch and os.environ.get("ICL_CONV1X1_SMALL", "1") != "0"
         if ctx.pointwise_small:
-            # the aligner's h -> h / h -> 1 maps on <= 4 x 24^3 voxels: a VALU kernel on the natural weight layout
+            # <= 16 channels (the aligner's h -> h / h -> 1 maps, the `final` 16 -> num_classes convolution on 96^3 voxels): VALU
+            # kernels on the natural weight layout, HBM-bound on big volumes
             _lib.check(_lib.lib().icl_conv1x1_small(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), n, cin, cout, s, cin, 1, _stream(x)),
                        "conv1x1_small")
             return y
@@ -315,7 +315,9 @@ class _Conv3d(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if ctx.pointwise_gemm:
-                gx = torch.bmm(weight.view(cout, cin).t().unsqueeze(0).expand(n, cin, cout), gy.view(n, cout, s)).view(n, cin, d, h, w)
+                # gx[b] [Cin,S] = W^T gy[b]: A = W read transposed (k-strided), B = gy[b] [Cout,S] (k-strided)
+                gx = torch.empty_like(x)
+                gemm(weight, gy, cin, s, cout, cin, s, False, False, out=gx, ldc=s, batch=n, b_bstride=cout * s, c_bstride=cin * s)
             elif ctx.pointwise_small:
                 gx = torch.empty_like(x)
                 _lib.check(L.icl_conv1x1_small(_ptr(gy), _ptr(weight), None, _ptr(gx), n, cout, cin, s, 1, cin, _stream(x)),
@@ -843,17 +845,69 @@ def drop_path(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Te
 LINEAR_WGRAD_MIN_ROWS = 2048
 
 
+def linear_forward_raw(x2: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0) -> torch.Tensor:
+    """act(x2 W^T + b) for row-major x2 [rows, in], W [out, in] (csrc/kernels/gemm.h: weight streaming for <= 32 rows and
+    >= 2^20 weights, LDS-tiled fp32 MFMA product otherwise)."""
+    _require(x2, weight, bias)
+    L = _lib.lib()
+    rows, i = x2.shape
+    o = weight.shape[0]
+    y = torch.empty((rows, o), dtype=torch.float32, device=x2.device)
+    need = L.icl_linear_ws_bytes(rows, i, o, 0)
+    ws = _ws(need, x2) if need else None
+    with _timed("linear_fwd", 2.0 * rows * i * o, 4.0 * (rows * (i + o) + i * o), x2):
+        _lib.check(L.icl_linear_fwd(_ptr(x2), _ptr(weight), _ptr(bias), _ptr(y), _ptr(ws), rows, i, o, act, _stream(x2)), "linear_fwd")
+    return y
+
+
+def linear_dgrad_raw(g2: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """g2 W for row-major g2 [rows, out], W [out, in] -> [rows, in]."""
+    _require(g2, weight)
+    L = _lib.lib()
+    rows, o = g2.shape
+    i = weight.shape[1]
+    gx = torch.empty((rows, i), dtype=torch.float32, device=g2.device)
+    need = L.icl_linear_ws_bytes(rows, i, o, 1)
+    ws = _ws(need, g2) if need else None
+    with _timed("linear_dgrad", 2.0 * rows * i * o, 4.0 * (rows * (i + o) + i * o), g2):
+        _lib.check(L.icl_linear_dgrad(_ptr(g2), _ptr(weight), _ptr(gx), _ptr(ws), rows, i, o, _stream(g2)), "linear_dgrad")
+    return gx
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, m: int, n: int, k: int, lda: int, ldb: int, a_kcontig: bool, b_kcontig: bool,
+         out: Optional[torch.Tensor] = None, ldc: Optional[int] = None, bias: Optional[torch.Tensor] = None, act: int = 0, batch: int = 1,
+         a_bstride: int = 0, b_bstride: int = 0, c_bstride: int = 0) -> torch.Tensor:
+    """C[b] = act(A[b] B[b] + bias) through icl_gemm (include/icl_hip.h): operands are described by their pitches, so transposed
+    views are consumed in place (no transpose copies)."""
+    _require(a, b, bias)
+    L = _lib.lib()
+    if out is None:
+        out = torch.empty((batch, m, n) if batch > 1 else (m, n), dtype=torch.float32, device=a.device)
+        ldc, c_bstride = n, m * n
+    need = L.icl_gemm_ws_bytes(m, n, k, batch)
+    ws = _ws(need, a) if need else None
+    with _timed("gemm", 2.0 * batch * m * n * k, 4.0 * batch * (m * k + k * n + m * n), a):
+        _lib.check(L.icl_gemm(_ptr(a), _ptr(b), _ptr(out), _ptr(bias), _ptr(ws), m, n, k, lda, ldb, ldc, int(a_kcontig), int(b_kcontig),
+                              act, batch, a_bstride, b_bstride, c_bstride, _stream(a)), "gemm")
+    return out
+
+
 def _tall_atb(a: torch.Tensor, b: torch.Tensor, want_colsum: bool):
-    """a^T b for tall row-major a [rows, A], b [rows, B] (-> [A, B]) and, optionally, the column sums of a (-> [A]).
-    rows >= LINEAR_WGRAD_MIN_ROWS: csrc/kernels/linear_wgrad.h (rows split over many waves); otherwise the library GEMM."""
+    """a^T b for row-major a [rows, A], b [rows, B] (-> [A, B]) and, optionally, the column sums of a (-> [A]).
+    rows >= LINEAR_WGRAD_MIN_ROWS: csrc/kernels/linear_wgrad.h (rows split over many waves); otherwise the tiled product of
+    csrc/kernels/gemm.h with both operands k-strided."""
     rows, A = a.shape
     B = b.shape[1]
-    if rows < LINEAR_WGRAD_MIN_ROWS:
-        return torch.matmul(a.t(), b), (a.sum(0) if want_colsum else None)
     _require(a, b)
     L = _lib.lib()
     a, b = a.contiguous(), b.contiguous()
     out = torch.empty((A, B), dtype=torch.float32, device=a.device)
+    if rows < LINEAR_WGRAD_MIN_ROWS:
+        need = L.icl_linear_ws_bytes(rows, B, A, 2)
+        ws = _ws(need, a) if need else None
+        with _timed("linear_wgrad_small", 2.0 * rows * A * B, 4.0 * (rows * (A + B) + A * B), a):
+            _lib.check(L.icl_linear_wgrad_small(_ptr(a), _ptr(b), _ptr(out), _ptr(ws), rows, B, A, _stream(a)), "linear_wgrad_small")
+        return out, (a.sum(0) if want_colsum else None)
     colsum = torch.empty(A, dtype=torch.float32, device=a.device) if want_colsum else None
     ws = _ws(L.icl_linear_wgrad_ws_bytes(rows, A, B), a)
     with _timed("linear_wgrad_kernel", 2.0 * rows * A * B, 4.0 * rows * (A + B), a):
@@ -904,46 +958,68 @@ class DeferredBiasGrads:
 
 
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b.  Forward and dx are plain library GEMMs (rocBLAS); dW/db of TALL inputs (>= 2048 rows: the Swin token
-    grids) use csrc/kernels/linear_wgrad.h — the library runs a 221K-deep reduction on ten workgroups there."""
+    """y = x W^T + b.  Forward and dx: csrc/kernels/gemm.h (fp32 MFMA; the weight is streamed once for skinny inputs); dW/db of TALL
+    inputs (>= 2048 rows: the Swin token grids) use csrc/kernels/linear_wgrad.h, of short ones the k-strided tiled product."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, owner=None):
-        ctx.save_for_backward(x, weight)
+        weight = weight.contiguous()
+        x2 = x.reshape(-1, weight.shape[1]).contiguous()
+        ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
         ctx.bias_param = owner.bias if (owner is not None and bias is not None and getattr(owner, "bias", None) is bias) else None
-        return torch.nn.functional.linear(x, weight, bias)
+        ctx.x_shape = x.shape
+        return linear_forward_raw(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x2, weight = ctx.saved_tensors
         o, i = weight.shape
         gx = gw = gb = None
+        g2 = gy.reshape(-1, o).contiguous()
         if ctx.needs_input_grad[0]:
-            gx = torch.matmul(gy, weight)
+            gx = linear_dgrad_raw(g2, weight).view(ctx.x_shape)
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or need_b:
-            g2 = gy.reshape(-1, o)
             if need_b and ctx.bias_param is not None and DeferredBiasGrads.defer(ctx.bias_param, g2):
                 need_b = False      # reduced with all the other bias gradients of the step (DeferredBiasGrads.flush)
-            if ctx.needs_input_grad[1] or need_b:
-                gw, gb = _tall_atb(g2, x.reshape(-1, i), need_b)
+            if ctx.needs_input_grad[1]:
+                gw, gb = _tall_atb(g2, x2, need_b)
+            elif need_b:
+                gb = g2.sum(0)
         return gx, gw, gb, None
 
 
-class _MatmulTall(torch.autograd.Function):
-    """y = x W for tall x [..., I] and W [I, O] (the k2s2 transposed convolution as a GEMM); dW = x^T gy on the tall path."""
+class _ConvTransposeGemm(torch.autograd.Function):
+    """y[b, s, :] = sum_ci x[b, ci, s] W[ci, :] — the k2s2 transposed convolution as ONE batched product whose A operand is the
+    channel-major activation itself (k-strided: no transpose copy); gx comes back channel-major, gW is summed over the batch."""
 
     @staticmethod
-    def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
-        return torch.matmul(x, w)
+    def forward(ctx, x, w2):
+        x = x.contiguous()
+        w2 = w2.contiguous()
+        b, cin = x.shape[0], x.shape[1]
+        s = x.numel() // (b * cin)
+        j = w2.shape[1]
+        ctx.save_for_backward(x, w2)
+        return gemm(x, w2, s, j, cin, s, j, False, False, batch=b, a_bstride=cin * s)        # [b, s, j]
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        gx = torch.matmul(gy, w.t()) if ctx.needs_input_grad[0] else None
-        gw = _tall_atb(x.reshape(-1, w.shape[0]), gy.reshape(-1, w.shape[1]), False)[0] if ctx.needs_input_grad[1] else None
+        x, w2 = ctx.saved_tensors
+        gy = gy.contiguous()
+        b, cin = x.shape[0], x.shape[1]
+        s = x.numel() // (b * cin)
+        j = w2.shape[1]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            # gx[b][ci][s] = sum_j W[ci][j] gy[b][s][j]
+            gx = torch.empty_like(x)
+            gemm(w2, gy, cin, s, j, j, j, True, True, out=gx, ldc=s, batch=b, b_bstride=s * j, c_bstride=cin * s)
+        if ctx.needs_input_grad[1]:
+            # gW[ci][j] = sum_{b,s} x[b][ci][s] gy[b][s][j]: one product per sample, summed
+            gw = torch.empty_like(w2)
+            gemm(x, gy, cin, j, s, s, j, True, False, out=gw, ldc=j, batch=b, a_bstride=cin * s, b_bstride=s * j, c_bstride=0)
         return gx, gw
 
 
@@ -976,17 +1052,20 @@ class FactoredGrads:
 class _LinearFactored(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, owner):
-        ctx.save_for_backward(x, weight)
+        weight = weight.contiguous()
+        x2 = x.reshape(-1, weight.shape[1]).contiguous()
+        ctx.save_for_backward(x2, weight)
         ctx.owner = owner
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        ctx.x_shape = x.shape
+        return linear_forward_raw(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x2, weight = ctx.saved_tensors
         o, i = weight.shape
-        gx = torch.matmul(gy, weight) if ctx.needs_input_grad[0] else None
-        g2, x2 = gy.reshape(-1, o).contiguous(), x.reshape(-1, i).contiguous()
+        g2 = gy.reshape(-1, o).contiguous()
+        gx = linear_dgrad_raw(g2, weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2] and not DeferredBiasGrads.defer(getattr(ctx.owner, "bias", None), g2):
             gb = g2.sum(0)
@@ -1112,12 +1191,12 @@ class _DepthToSpaceCat(torch.autograd.Function):
 def conv_transpose3d_k2s2(x: torch.Tensor, weight: torch.Tensor, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
     """nn.ConvTranspose3d(cin, cout, kernel 2, stride 2, no bias) — MONAI UnetrUpBlock.transp_conv — optionally followed by
     ``torch.cat((up, skip), 1)``.  Kernel == stride, so the output voxels do not overlap:
-    out[b, co, 2z+i, 2y+j, 2x+k] = sum_ci x[b, ci, z, y, x] * W[ci, co, i, j, k], i.e. ONE plain GEMM
-    [B*S, Cin] x [Cin, Cout*8] (library GEMM, rocBLAS) followed by a depth-to-space move (csrc/kernels/pool_resize.h) that
-    writes straight into the concat buffer."""
+    out[b, co, 2z+i, 2y+j, 2x+k] = sum_ci x[b, ci, z, y, x] * W[ci, co, i, j, k], i.e. ONE product
+    [B*S, Cin] x [Cin, Cout*8] on the fp32 matrix cores (csrc/kernels/gemm.h, reading the channel-major activation in place)
+    followed by a depth-to-space move (csrc/kernels/pool_resize.h) that writes straight into the concat buffer."""
     b, cin, d, h, w = x.shape
     cout = weight.shape[1]
-    y = _MatmulTall.apply(x.flatten(2).transpose(1, 2), weight.flatten(1))          # [B, S, Cout*8]
+    y = _ConvTransposeGemm.apply(x, weight.flatten(1))          # [B, S, Cout*8]
     return _DepthToSpaceCat.apply(y, skip, (b, d, h, w, cout))
 
 

@@ -179,6 +179,33 @@ int icl_col2im3(const float* g, float* dx, int n, int c, int d, int h, int w, vo
 int icl_depth_to_space2(const float* yt, float* out, int n, int d, int h, int w, int cout, int64_t out_bstride, void* stream);
 int icl_space_to_depth2(const float* g, float* gt, int n, int d, int h, int w, int cout, int64_t g_bstride, void* stream);
 
+/* ---- nn.Linear forward / input gradient and the other dense fp32 products of the path, on the fp32 matrix cores
+ * (csrc/kernels/gemm.h).  Replaces F.linear at networks/unet_3D_icl.py:283-315 (fc_q, fc_kv, proj, MLP.fc1/fc2 and the token-axis
+ * Class_Decoder.mlp2, :258-268), query_convs (:197), the token projection (:212), the Swin qkv / proj / MLP / PatchMerging linears
+ * (networks/swinunetr_icl.py:703-750,812,946-976) and their autograd input gradients.
+ *   icl_linear_fwd    y[rows, out] = act(x[rows, in] W[out, in]^T + bias)     act 0 none, 1 exact-erf GELU (MLP.act, :307); bias may be NULL
+ *   icl_linear_dgrad  gx[rows, in] = gy[rows, out] W[out, in]
+ *   icl_linear_wgrad_small  dw[out, in] = gy^T x for few rows (tall inputs: icl_linear_wgrad above)
+ * rows <= 32 with >= 2^20 weights (the 13,824^2 / 1,728^2 mlp2 matrices): the weight matrix is streamed from HBM exactly once
+ * (HBM-bound); everything else runs on LDS-staged 64x64 wave tiles, split over K when the output has too few tiles to fill the chip.
+ * ws: icl_linear_ws_bytes(rows, in, out, kind) bytes, kind 0 fwd / 1 dgrad / 2 wgrad_small (may be 0; NULL then allowed). */
+int64_t icl_linear_ws_bytes(int64_t rows, int in, int out, int kind);
+int icl_linear_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, int64_t rows, int in, int out, int act,
+                   void* stream);
+int icl_linear_dgrad(const float* gy, const float* w, float* gx, void* ws, int64_t rows, int in, int out, void* stream);
+int icl_linear_wgrad_small(const float* gy, const float* x, float* dw, void* ws, int64_t rows, int in, int out, void* stream);
+/* General (batched) product C[b] = act(A[b] B[b] + bias[n]), C [m, n] with row pitch ldc; act = activation (0 none, 1 GELU)
+ * + 16 when the bias is indexed by the output row m instead of the column (1x1x1 convolution: rows are channels).  a_kcontig 1: A is row-major [m][lda]
+ * (k contiguous), 0: A is given transposed [k][lda] (m contiguous); b_kcontig 1: B is [n][ldb] (k contiguous, "W^T"), 0: B is
+ * [k][ldb].  Batch strides in elements.  Used for ConvTranspose3d(k=2, s=2) as one product (MONAI UnetrUpBlock.transp_conv,
+ * networks/swinunetr_icl.py:178-225: A = x[b] as [Cin][S] transposed view, B = W [Cin][Cout*8]) and its gradients, and for the
+ * 3^3 convolutions on <= 6^3 voxels through im2col (networks/utils.py:104,107 at the `center` level).
+ * ws: icl_gemm_ws_bytes(m, n, k, batch) bytes (split-K slabs, summed in a fixed order); with ws NULL the product runs unsplit. */
+int64_t icl_gemm_ws_bytes(int64_t m, int n, int k, int batch);
+int icl_gemm(const float* a, const float* b, float* c, const float* bias, void* ws, int64_t m, int n, int k, int64_t lda, int64_t ldb,
+             int64_t ldc, int a_kcontig, int b_kcontig, int act, int batch, int64_t a_bstride, int64_t b_bstride, int64_t c_bstride,
+             void* stream);
+
 /* ---- nn.Linear weight/bias gradient for tall token matrices (qkv / proj / MLPBlock linears of the Swin stages,
  * networks/swinunetr_icl.py:703,705,812; PatchEmbed; the k2s2 transposed convolutions written as GEMMs):
  * dw[o][i] = sum_r gy[r][o] * x[r][i], db[o] = sum_r gy[r][o] (db may be NULL); gy [rows, o], x [rows, i] row-major.

@@ -242,6 +242,7 @@ static inline void icl_nt_store4(float* p, float4 v) { *reinterpret_cast<float4*
 #define ICL_OPAQUE_INT(x) ((void)(x))
 #define ICL_SCHED_BARRIER() ((void)0)
 #define ICL_WAVE_UNIFORM(x) ((void)(x))
+#define ICL_WAVE_SYNC() hipemu::yield_state(2)
 static inline float atomicAdd(float* p, float v) {
   uint32_t* ip = (uint32_t*)p;
   uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED), neu;

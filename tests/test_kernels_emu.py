@@ -499,8 +499,10 @@ def test_first_conv_weight_gradient_through_shifted_planes(monkeypatch, n, cout,
     _conv_check(n, 1, cout, d, h, w, 3)
 
 
-def test_conv1x1_big_volume_runs_as_batched_gemm(monkeypatch):
-    """>= 65536 voxels: forward / input gradient of a 1x1x1 convolution are one batched library GEMM (with and without bias)."""
+def test_conv1x1_big_volume_runs_as_batched_product(monkeypatch):
+    """>= 65536 voxels (threshold lowered here): forward / input gradient of a 1x1x1 convolution with many channels are one
+    batched product of csrc/kernels/gemm.h on the channel-major volume (bias indexed by the output row), with <= 16 channels the
+    voxel-streaming VALU kernel (conv1x1_stream_kernel: all outputs of a voxel quad per thread)."""
     monkeypatch.setattr(ops, "CONV1X1_GEMM_MIN_VOXELS", 4096)
     _conv_check(2, 20, 50, 10, 12, 20, 1)
     x = _rand((1, 6, 16, 16, 16), 5, True)
@@ -508,3 +510,9 @@ def test_conv1x1_big_volume_runs_as_batched_gemm(monkeypatch):
     y = ops.conv3d(x, w, None)
     y.sum().backward()
     assert rel_err(y.detach(), F.conv3d(x.detach(), w.detach())) < 1e-5 and x.grad is not None and w.grad is not None
+
+
+@pytest.mark.parametrize("n,cin,cout", [(1, 16, 2), (2, 16, 16), (1, 5, 3), (1, 2, 16)])
+def test_conv1x1_stream_kernel_final_conv_class(n, cin, cout):
+    """The `final` convolution class (unet_3D_icl.py:65): <= 16 channels on >= 65536 voxels, forward and input gradient."""
+    _conv_check(n, cin, cout, 32, 32, 64 // n, 1)
