@@ -43,9 +43,11 @@ __device__ __forceinline__ float gemm_epilogue(float v, const float* __restrict_
 // tiles) or 64 weight columns (input gradient: four MFMA tiles, the wave walks down the slice's 16-row tiles).  P tiles are in
 // flight per wave (registers).  Partials go to slab[slice]; gemm_reduce_slabs_kernel adds them in a fixed order (+ bias, act).
 // grid (ceil(units / (8 upw)), nslice), block 512, dynamic LDS = (16 MT slice_len + 8 * 1024) floats; slice_len % 64 == 0, K % 4 == 0.
+// With a single slice (small weights) `slab` is the final output [M][.]: rows >= M are not stored and bias / act are applied here.
 template <int MT, bool NN, int P>
 __global__ __launch_bounds__(512) void linear_stream_kernel(const float* __restrict__ xs, const float* __restrict__ w, float* __restrict__ slab,
-                                                            int M, int K, int O, int slice_len, int upw) {
+                                                            int M, int K, int O, int slice_len, int upw, const float* __restrict__ bias,
+                                                            int act) {
   ICL_DYN_LDS(float, lds);
   float* xl = lds;                                        // [16 MT][slice_len], quad q of row m stored at quad q ^ (m & 15)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, u = lane & 15, lg = lane >> 4;
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[t][e] = f32x4{0.f, 0.f, 0.f, 0.f};
   int c_unit = unit0, c_t = 0;                            // position of the tile being computed
+  const bool direct = gridDim.y == 1;                      // one slice: write the result itself
   float* out = slab + (long)blockIdx.y * 16 * MT * (NN ? K : O);
 
   for (int base = 0; base < total; base += P) {
@@ -151,12 +154,23 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(const float* __restr
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int m = 16 * t + 4 * lg + q;
+            if (direct && m >= M) continue;
             if (NN) {
               const int col = 64 * c_unit + 4 * u;
-              if (col < K) *reinterpret_cast<float4*>(out + (long)m * K + col) = make_float4(acc[t][0][q], acc[t][1][q], acc[t][2][q], acc[t][3][q]);
+              float4 v = make_float4(acc[t][0][q], acc[t][1][q], acc[t][2][q], acc[t][3][q]);
+              if (direct) {
+                v.x = gemm_epilogue(v.x, bias, col, act);
+                v.y = gemm_epilogue(v.y, bias, col + 1, act);
+                v.z = gemm_epilogue(v.z, bias, col + 2, act);
+                v.w = gemm_epilogue(v.w, bias, col + 3, act);
+              }
+              if (col < K) *reinterpret_cast<float4*>(out + (long)m * K + col) = v;
             } else {
               const int o = 16 * c_unit + u;
-              if (o < O) out[(long)m * O + o] = (acc[t][0][q] + acc[t][1][q]) + (acc[t][2][q] + acc[t][3][q]);
+              if (o < O) {
+                const float v = (acc[t][0][q] + acc[t][1][q]) + (acc[t][2][q] + acc[t][3][q]);
+                out[(long)m * O + o] = direct ? gemm_epilogue(v, bias, o, act) : v;
+              }
             }
           }
 #pragma unroll
@@ -191,6 +205,28 @@ __global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(const float* __r
     a.z = gemm_epilogue(a.z, bias, brow ? (int)m : n + 2, act);
     a.w = gemm_epilogue(a.w, bias, brow ? (int)m : n + 3, act);
     *reinterpret_cast<float4*>(out + m * ldo + n) = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient, few rows
+// dw[o][i] = sum_{r < rows} gy[r][o] * x[r][i] for a handful of rows (the aligner's Linear layers see batch*classes = 4..32 rows):
+// a sum of `rows` outer products, one thread per (o, four consecutive i), 16-byte loads / stores.  I % 4 == 0.
+__global__ __launch_bounds__(256) void linear_wgrad_outer_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ dw,
+                                                                 int rows, int O, int I) {
+  const int iq = I >> 2;
+  const long total = (long)O * iq;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int o = (int)(e / iq), i = (int)(e % iq) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < rows; ++r) {
+      const float g = gy[(long)r * O + o];
+      const float4 xv = *reinterpret_cast<const float4*>(x + (long)r * I + i);
+      acc.x = fmaf(g, xv.x, acc.x);
+      acc.y = fmaf(g, xv.y, acc.y);
+      acc.z = fmaf(g, xv.z, acc.z);
+      acc.w = fmaf(g, xv.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(dw + (long)o * I + i) = acc;
   }
 }
 
