@@ -114,7 +114,7 @@ def test_all_case_base(net, net_type, base_dir, test_list="full_test.list", num_
     if cases is None:
         import h5py  # noqa: F401 — same dependency as the reference
         with open(base_dir + "/{}".format(test_list), "r") as f:
-            ids = [ln.replace("\\n", "").strip().split(",")[0] for ln in f.readlines()]
+            ids = [ln.strip().split(",")[0] for ln in f if ln.strip()]
 
         def _gen():
             for i in ids:
@@ -124,6 +124,76 @@ def test_all_case_base(net, net_type, base_dir, test_list="full_test.list", num_
     metric_cal = [[] for _ in range(num_classes - 1)]
     for image, label in cases:
         prediction = test_single_case_base(net, net_type, image, stride_xy, stride_z, patch_size, num_classes=num_classes)
+        for i in range(1, num_classes):
+            metric_cal[i - 1].append(cal_metric(label == i, prediction == i))
+    return metric_cal
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# AMOS validation: MONAI-style sliding window (val_3D.py:120-137)
+# --------------------------------------------------------------------------------------------------------------------
+
+def _scan_starts(size: int, roi: int, overlap: float):
+    """Window origins along one axis as MONAI 1.0.1 ``sliding_window_inference`` places them (``_get_scan_interval`` +
+    ``dense_patch_slices``): stride ``int(roi * (1 - overlap))`` (the whole axis when it equals the window), ``ceil((size - roi) /
+    stride) + 1`` windows, the last ones shifted back inside the volume."""
+    if size == roi:
+        return [0]
+    interval = int(roi * (1 - overlap))
+    interval = interval if interval > 0 else 1
+    num = int(math.ceil(float(size - roi) / interval)) + 1
+    return [i * interval - max(i * interval + roi - size, 0) for i in range(num)]
+
+
+@torch.no_grad()
+def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap: float = 0.25, **kwargs):
+    """Restatement of ``monai.inferers.sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap=0.25,
+    mode="constant")`` as the reference calls it (val_3D.py:130-132): symmetric zero padding of volumes smaller than the window,
+    the window grid of ``_scan_starts``, ``sw_batch_size`` windows per forward, predictor OUTPUTS (logits) averaged with constant
+    weights over overlapping windows, padding cropped off again.  Everything stays on the device of ``inputs``.  MONAI is not
+    installed in the build image: parity unpinned."""
+    b = inputs.shape[0]
+    size = list(inputs.shape[2:])
+    roi = [int(r) for r in roi_size]
+    pads = []
+    for s, r in zip(size, roi):
+        diff = max(r - s, 0)
+        pads.append((diff // 2, diff - diff // 2))
+    if any(a + c for a, c in pads):
+        flat = [v for a, c in reversed(pads) for v in (a, c)]
+        inputs = torch.nn.functional.pad(inputs, flat)
+    psize = list(inputs.shape[2:])
+    grids = [_scan_starts(s, r, overlap) for s, r in zip(psize, roi)]
+    starts = [(bi, z, y, x) for bi in range(b) for z in grids[0] for y in grids[1] for x in grids[2]]
+    out = cnt = None
+    for i in range(0, len(starts), sw_batch_size):
+        chunk = starts[i:i + sw_batch_size]
+        win = torch.stack([inputs[bi, :, z:z + roi[0], y:y + roi[1], x:x + roi[2]] for bi, z, y, x in chunk]).contiguous()
+        pred = predictor(win, **kwargs)
+        if out is None:
+            out = torch.zeros((b, pred.shape[1], *psize), dtype=torch.float32, device=inputs.device)
+            cnt = torch.zeros((b, 1, *psize), dtype=torch.float32, device=inputs.device)
+        for j, (bi, z, y, x) in enumerate(chunk):
+            out[bi, :, z:z + roi[0], y:y + roi[1], x:x + roi[2]] += pred[j].float()
+            cnt[bi, :, z:z + roi[0], y:y + roi[1], x:x + roi[2]] += 1
+    out = out / cnt
+    sl = tuple(slice(a, a + s) for (a, _), s in zip(pads, size))
+    return out[(slice(None), slice(None)) + sl]
+
+
+def test_all_case_amos(net, net_type, val_loader, num_classes=4):
+    """val_3D.py:120-137: every validation volume through ``sliding_window_inference(image, (96, 96, 96), 4, net[, inference=True])``,
+    argmax over the averaged logits, ``cal_metric`` per foreground class.  The reference wraps the inference in fp16 autocast; the
+    HIP kernels compute in fp32 (a strictly more accurate evaluation of the same network)."""
+    metric_cal = [[] for _ in range(num_classes - 1)]
+    net.eval()
+    dev = next(net.parameters()).device
+    for batch in val_loader:
+        image, label = batch["image"].to(dev), batch["label"].squeeze(0)
+        kw = {"inference": True} if net_type in ("unet_3D_icl", "swinunetr_icl") else {}
+        logits = sliding_window_inference(image, (96, 96, 96), 4, net, **kw)
+        prediction = torch.argmax(logits, dim=1).cpu().numpy()
+        label = np.asarray(label.cpu() if torch.is_tensor(label) else label)
         for i in range(1, num_classes):
             metric_cal[i - 1].append(cal_metric(label == i, prediction == i))
     return metric_cal

@@ -242,6 +242,15 @@ int icl_window_attn_bwd(const float* qkv, const float* bias, const int32_t* regi
                         const float* dout, float* dqkv, float* dbias, int b_, int n, int heads, int nw, int head_dim, float scale,
                         void* stream);
 
+/* ---- on-device training augmentation: RandomRotFlip -> RandomCrop -> ToTensor of the 3-D trainers
+ * (dataloaders/brats2019.py:80-147,177-189; composed at train_inherent_consistent_unet_3D_BraTS.py:66-73) as one gather over
+ * volumes resident in HBM.  images[b] / labels[b]: HOST arrays of device pointers to the fp32 [n0,n1,n2] volume and its uint8
+ * label; params: HOST int32 [batch][11] = {n0, n1, n2, k (np.rot90 count on axes 0,1), flip axis (0, 1, -1 none), zero padding
+ * p0, p1, p2 (both sides), crop origin c0, c1, c2 (in the padded, rotated, flipped volume)}, drawn by the caller with the
+ * reference's numpy call sequence.  image_out [batch,1,o0,o1,o2] fp32, label_out [batch,o0,o1,o2] int64.  batch <= 16. */
+int icl_crop_rotflip(const void* const* images, const void* const* labels, const int32_t* params, int batch, float* image_out,
+                     int64_t* label_out, int o0, int o1, int o2, void* stream);
+
 /* ---- fused SGD(momentum, weight decay) step, torch.optim.SGD semantics (train_inherent_consistent_unet_3D_BraTS.py:85-86,115):
  * d = g + wd*p; m = first ? d : momentum*m + d; p -= lr*m.  The multi form takes HOST arrays of device pointers.
  * lr_dev (may be NULL): when given, the learning rate is read from this device scalar instead of `lr` (hipGraph replay). */

@@ -1,0 +1,150 @@
+"""GPU tests of the drop-in call shapes (run with -m gpu): the literal loop body of the reference trainers
+(/root/reference/code/train_inherent_consistent_unet_3D_BraTS.py:85-90,103-115 and ..._swinunetr_3D_BraTS.py:138-150) executed
+through the `compat/` import root — `net_factory_3d(...)`, `torch.softmax`, `CrossEntropyLoss()`, `DiceLoss(nc)(probabilities,
+y.unsqueeze(1))`, `AuxLoss3D`, `PseudoSoftLoss3D`, `softmax_mse_loss`, stock `torch.optim.SGD` on dense gradients — against the
+vectors captured from the reference; plus the on-device data feed."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from icl_amd.utils.hashfill import fill_like_reference_init, synthetic_labels, synthetic_volume
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def compat_root():
+    """The import root the unchanged trainers run with: `networks`, `utils`, `val_3D`, `dataloaders` resolve to icl_amd."""
+    path = os.path.join(ROOT, "compat")
+    sys.path.insert(0, path)
+    yield path
+    sys.path.remove(path)
+    for name in [m for m in sys.modules if m.split(".")[0] in ("networks", "utils", "val_3D", "dataloaders")]:
+        del sys.modules[name]
+
+
+def _parity_mode(model):
+    from icl_amd.networks.aligner import DropPath
+    from icl_amd.networks.layers import Dropout3
+    for mod in model.modules():
+        if isinstance(mod, Dropout3):
+            mod.p = 0.0
+        if isinstance(mod, DropPath):
+            mod.drop_prob = 0.0
+
+
+def _reference_loop_body(model, volume_batch, label_batch, labeled_bs, num_classes, base_lr):
+    """The statements of the reference `train()` between building the optimiser and `optimizer.step()`, with its names."""
+    import torch.optim as optim
+    from torch.nn.modules.loss import CrossEntropyLoss
+    from utils import losses
+    optimizer = optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001)
+    ce_loss = CrossEntropyLoss()
+    dice_loss = losses.DiceLoss(num_classes)
+    aux_loss = losses.AuxLoss3D(num_classes)
+    pse_loss = losses.PseudoSoftLoss3D(num_classes)
+
+    outputs = model(volume_batch[:labeled_bs], volume_batch[labeled_bs:])
+    outputs_soft = torch.softmax(outputs[0], dim=1)
+    loss_ce = ce_loss(outputs[0], label_batch[:labeled_bs])
+    loss_dice = dice_loss(outputs_soft, label_batch[:labeled_bs].unsqueeze(1))
+    loss_aux = aux_loss(outputs[2], label_batch[:labeled_bs])
+    loss_pse = pse_loss(outputs[3], outputs[1])
+    loss_aux_consis = losses.softmax_mse_loss(outputs[3], outputs[4])
+    loss = loss_dice + loss_ce + loss_aux + loss_pse + 10 * loss_aux_consis
+    optimizer.zero_grad()
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    optimizer.step()
+    return [loss_dice.item(), loss_ce.item(), loss_aux.item(), loss_pse.item(), loss_aux_consis.item(), loss.item()], grads
+
+
+def _check_step(model, g, losses_got, grads, elementwise, norm_skip=lambda k: False):
+    assert np.allclose(losses_got, g["losses"], rtol=0, atol=1e-4), (losses_got, g["losses"])
+    none = [k for k, _ in model.named_parameters() if k not in grads]
+    assert none == list(g["grad_none"])
+    ref = dict(zip(g["grad_norm_keys"], g["grad_norms"]))
+    bad = [(k, float(v.double().norm()), ref[k]) for k, v in grads.items()
+           if not norm_skip(k) and abs(float(v.double().norm()) - ref[k]) > 1e-2 * max(ref[k], 1e-7) + 1e-9]
+    assert not bad, bad[:10]
+    for key, pick, tol in elementwise:
+        assert rel_err(pick(grads[key]).cpu(), g["grad." + key + ("" if "grad." + key in g.files else "_sub")]) < tol, key
+    names = [k for k, _ in model.named_parameters()]
+    post = np.array([float(p.detach().double().norm()) for _, p in model.named_parameters()])
+    off = [(names[i], post[i], g["post_sgd_norms"][i]) for i in range(len(names))
+           if abs(post[i] - g["post_sgd_norms"][i]) > 1e-4 * g["post_sgd_norms"][i]]
+    assert not off, off[:8]
+
+
+def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root):
+    from networks.net_factory_3d import net_factory_3d
+    g = load_golden("model_unet3d_icl_nc2.npz")
+    model = net_factory_3d(net_type="unet_3D_icl", in_chns=1, class_num=2)
+    assert model.training and next(model.parameters()).is_cuda and list(model.state_dict().keys()) == list(g["keys"])
+    fill_like_reference_init(list(model.named_parameters()))
+    _parity_mode(model)
+    dev = next(model.parameters()).device
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, 2).to(dev)
+    got, grads = _reference_loop_body(model, vol, lab, labeled_bs=1, num_classes=2, base_lr=0.01)
+    full = lambda t: t                                             # noqa: E731
+    elementwise = [
+        ("final.weight", full, 1e-3), ("final.bias", full, 1e-3), ("conv1.conv1.0.weight", full, 2e-2), ("sspa.guided_Q", full, 5e-3),
+        ("sspa.class_decoders.0.attn.fc_q.weight", full, 5e-3), ("uscl.attn_convs1.2.weight", full, 5e-3),
+        ("sspa.attn_convs0.2.block.depthwise.weight", full, 5e-3), ("sspa.query_convs.0.weight", full, 5e-3),
+        ("sspa.class_decoders.2.mlp2.fc1.weight", lambda t: t[::432, ::432], 5e-3),      # dense 13,824^2 gradient of stock SGD
+        ("center.conv2.0.weight", lambda t: t[::16, ::16], 2e-2),
+    ]
+    # conv biases in front of an InstanceNorm and attn_convs1 biases in front of the class softmax: the true gradient is exactly 0
+    skip = lambda k: k.endswith(".0.bias") or ("attn_convs1" in k and k.endswith("bias"))   # noqa: E731
+    _check_step(model, g, got, grads, elementwise, skip)
+    assert rel_err(model.final.weight.detach().cpu(), g["post_sgd.final.weight"]) < 1e-5
+    # the first convolution's gradient is the deepest of the model (2e-2 band above); times lr = 0.01 on O(0.3) weights
+    assert rel_err(model.conv1.conv1[0].weight.detach().cpu(), g["post_sgd.conv1.conv1.0.weight"]) < 1e-4
+
+
+def test_reference_loop_body_swinunetr_icl_through_compat_root(compat_root):
+    from networks.net_factory_3d import net_factory_3d
+    g = load_golden("model_swinunetr_icl_nc2.npz")
+    model = net_factory_3d(net_type="swinunetr_icl")                # train_..._swinunetr_3D_BraTS.py:75: no class arguments
+    assert list(model.state_dict().keys()) == list(g["keys"])
+    fill_like_reference_init(list(model.named_parameters()))
+    _parity_mode(model)
+    dev = next(model.parameters()).device
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, 2).to(dev)
+    got, grads = _reference_loop_body(model, vol, lab, labeled_bs=1, num_classes=2, base_lr=0.01)
+    sub = lambda t: t if t.numel() <= 8192 else t.reshape(-1)[::97]   # noqa: E731
+    # deep encoder gradients: the reference's own fp32 CPU backward is 0.5-1 % from an fp64 evaluation
+    elementwise = [("out.conv.conv.weight", sub, 5e-3), ("swinViT.patch_embed.proj.weight", sub, 3e-2),
+                   ("swinViT.layers1.0.blocks.1.attn.relative_position_bias_table", sub, 3e-2),
+                   ("swinViT.layers4.0.blocks.0.attn.qkv.bias", sub, 3e-2), ("decoder5.transp_conv.conv.weight", sub, 3e-2)]
+    skip = lambda k: k.endswith("bias") and ("conv" in k or "attn_convs1" in k)      # noqa: E731
+    _check_step(model, g, got, grads, elementwise, skip)
+
+
+def test_dice_loss_on_probabilities_equals_dice_loss_on_logits():
+    """`DiceLoss(nc)(softmax(logits), y.unsqueeze(1))` (the trainer's call, :105-108) and `DiceLoss(nc)(logits, ..., softmax=True)`
+    (AuxLoss3D's call, losses.py:269) are the same number, and so are their gradients with respect to the logits."""
+    from icl_amd.utils.losses import DiceLoss
+    dev = torch.device("cuda", 0)
+    for nc in (2, 5):
+        a = synthetic_volume((2, nc, 24, 24, 24), 3).to(dev).requires_grad_()
+        y = synthetic_labels((2, 24, 24, 24), 4, nc).to(dev)
+        l1 = DiceLoss(nc)(torch.softmax(a, 1), y.unsqueeze(1))
+        (g1,) = torch.autograd.grad(l1, a)
+        l2 = DiceLoss(nc)(a, y.unsqueeze(1), softmax=True)
+        (g2,) = torch.autograd.grad(l2, a)
+        assert abs(float(l1) - float(l2)) < 1e-6 and rel_err(g1.cpu(), g2.cpu()) < 1e-4
+
+
+def test_on_device_data_feed_equals_the_reference_transforms():
+    sys.path.insert(0, HERE)
+    from test_datafeed import check_augment_cases
+    check_augment_cases(torch.device("cuda", 0))
