@@ -312,14 +312,15 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
 }
 
 // y = keep ? x*scale : 0 with keep(i) = hash(seed, i) >= thresh; the same (seed) regenerates the mask in backward.
-// seed_dev (optional): a device-resident step counter added to the seed, so replays of a captured hipGraph draw new masks.
+// seed_dev (optional): a device-resident step counter HASHED into the seed, so replays of a captured hipGraph draw new masks
+// (mixing it in linearly would make the mask of step t the mask of step 0 shifted by t elements).
 // group > 1: one decision per `group` consecutive elements — per-sample stochastic depth (DropPath: the whole residual branch
 // of a sample is kept, scaled by 1/(1-p), or dropped).
 // res (optional): y = res + dropped(x) — the residual form  x + DropPath(branch)  of the transformer blocks in one pass.
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
                                                       long n, unsigned seed, unsigned thresh, float scale,
                                                       const unsigned* __restrict__ seed_dev, long group) {
-  if (seed_dev) seed += *seed_dev * 0x9E3779B1u;
+  if (seed_dev) seed = mix32(seed ^ mix32(*seed_dev + 0x632BE5ABu));
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long k = group > 1 ? i / group : i;
     const unsigned h = mix32((unsigned)k * 0x9E3779B1u + seed) ^ mix32((unsigned)(k >> 32) + seed * 0x85EBCA77u);

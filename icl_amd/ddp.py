@@ -8,10 +8,11 @@ The reference is single-GPU; this is a capability the build ad
  - parameters whose ``.grad`` is None after backward (33 tensors in an ICL step) are skipped,
    never zero-filled — torch SGD skips them too, so weight decay must not touch them;
  - gradients travel as fp32.  The payload is 3.14 GB and 99 % of it is twelve token-axis ``mlp2`` matrices
-   (four of them 764 MB each).  Those are produced FIRST in backward (the aligners are the last thing in forward),
-   so every large gradient is handed to RCCL the moment autograd has finished accumulating it
-   (``register_post_accumulate_grad_hook``) and its all-reduce runs on RCCL's stream underneath the whole
-   backbone backward; only the small tensors (~6 M elements, one flat bucket) are reduced after backward.
+   (four of them 764 MB each).  With factored gradients (the trainer's default) they travel as ~6 MB of factor rows per rank;
+   with dense gradients every large tensor is all-reduced on its own, in place (no bucket copy), the small tensors
+   (~6 M elements) in flat buckets.  All collectives are issued from ``communicate()``, after backward: a gradient that
+   autograd accumulates more than once per step (a weight used twice, micro-batch accumulation) is complete by then — an
+   all-reduce started from an accumulation hook would reduce a partial sum and race the second accumulation.
    xGMI is point-to-point (7 links x ~153 GB/s per GPU): few, very large messages keep all links busy.
 """
 from __future__ import annotations
@@ -35,17 +36,13 @@ class GradientReducer:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap_min = overlap_min_elems
         self.force = force       # run the collectives even with a single rank (exercises the captured path on one GPU)
-        self.static = False      # set by ICLTrainer.capture(): buffers persist, nothing is issued from autograd hooks
-        self._handles = []
-        self._early = set()
+        self.static = False      # set by ICLTrainer.capture(): the packed buffers persist (they are baked into the graphs)
+        self._captured = False   # set once the graphs exist: pack() may not run eagerly any more
+        self._early = set()      # ids of the large parameters of this step: all-reduced alone, in place
         self._flat = []          # [(flat buffer, [params])]
         self._fac = []           # [(param, G_all, X_all)]
         self._avg = dist.is_initialized() and dist.get_backend() == "nccl"   # RCCL averages in the collective
         self._send = self._recv = None   # all factor rows of a step, packed / gathered
-        if world_size > 1:
-            for p in self.params:
-                if p.numel() >= overlap_min_elems:
-                    p.register_post_accumulate_grad_hook(self._on_grad_ready)
 
     @property
     def active(self) -> bool:
@@ -54,14 +51,6 @@ class GradientReducer:
     def broadcast_parameters(self, src: int = 0):
         for p in self.params:
             dist.broadcast(p.data, src)
-
-    # -- large tensors: start the all-reduce as soon as the gradient is complete, overlap with the rest of backward
-    def _on_grad_ready(self, p: torch.nn.Parameter):
-        if p.grad is None or self.static:
-            return
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        self._handles.append((dist.all_reduce(p.grad, op=op, async_op=True), p))
-        self._early.add(id(p))
 
     def _buckets(self):
         cur, n = [], 0
@@ -81,9 +70,17 @@ class GradientReducer:
         factored gradients (ops.FactoredGrads: dW = g^T x with a few dozen rows) are scaled for the mean — the mean over ranks
         of g_r^T x_r is [g_1/W; ...; g_W/W]^T [x_1; ...; x_W], so the ranks exchange the row blocks (~1 MB per 13,824^2
         matrix) instead of all-reducing 764 MB — and the gather targets are allocated."""
+        if self.static and self._captured:
+            raise RuntimeError("GradientReducer: the packed buffers belong to the captured hipGraphs; an eager step would rebind "
+                               "them and later replays would communicate on buffers the graphs never touch")
         self._flat, self._fac = [], []
         if not self.active:
             return
+        # large dense gradients: reduced alone and in place (no concatenation copy of a 764 MB tensor)
+        self._early = {id(p) for p in self.params if p.grad is not None and p.grad.numel() >= self.overlap_min and p.grad.is_contiguous()}
+        for p in self.params:
+            if id(p) in self._early:
+                self._flat.append((p.grad.view(-1), None))
         for bucket in self._buckets():
             if len(bucket) == 1 and bucket[0].grad.is_contiguous():
                 self._flat.append((bucket[0].grad.view(-1), None))          # reduced in place
@@ -122,12 +119,6 @@ class GradientReducer:
                 dist.all_gather_into_tensor(self._recv, self._send)
             else:
                 dist.all_gather(list(self._recv.chunk(self.world, 0)), self._send)
-        for h, p in self._handles:
-            h.wait()
-            if not self._avg:
-                p.grad.mul_(inv)
-        self._handles.clear()
-        self._early.clear()
 
     def unpack(self):
         """Device-side, after ``communicate()``: the gathered block [rank][g_1 | x_1 | g_2 | ...] is split into the per-matrix row

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .layers import Conv2d, Conv3d
+from .layers import BatchNormAct, Conv2d, Conv3d
 
 
 class Linear(nn.Module):
@@ -42,21 +42,12 @@ class LayerNorm(nn.Module):
         return ops.layer_norm(x, self.weight, self.bias, 1e-5)
 
 
-class BatchNorm3d(nn.Module):
-    """nn.BatchNorm3d parameters/buffers; forward fused with the following ReLU."""
+class BatchNorm3d(BatchNormAct):
+    """nn.BatchNorm3d parameters/buffers; forward fused with the following ReLU.  A ``BatchNormAct`` (act = ReLU), so the
+    trainer's deferred step counters (one multi-tensor add per step instead of one launch per layer) cover the aligners too."""
 
     def __init__(self, c, device=None):
-        super().__init__()
-        self.weight = nn.Parameter(torch.ones(c, device=device))
-        self.bias = nn.Parameter(torch.zeros(c, device=device))
-        self.register_buffer("running_mean", torch.zeros(c, device=device))
-        self.register_buffer("running_var", torch.ones(c, device=device))
-        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long, device=device))
-
-    def forward(self, x):
-        if self.training:
-            self.num_batches_tracked += 1
-        return ops.batch_norm_relu(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu=True)
+        super().__init__(c, 1, device)
 
 
 class DropPath(nn.Module):

@@ -3,8 +3,10 @@
 
 ``forward(x_lab, x_unlab=None, inference=None)``: truthy ``inference`` returns the labeled-stream logits;
 otherwise the 5-tuple ``(final_lab, final_unlab, feat_Maps_lab, feat_Maps_unlab, feat_Maps_consis)``.
-The two streams run as two separate backbone passes with shared weights, exactly like the reference
-(:100-139), so every per-sample statistic matches.
+The reference runs the backbone twice with shared weights (:100-139); every backbone operator is per-sample, so here both
+streams go through it as ONE concatenated batch with identical per-sample results (see ``forward``).
+``icl_in_resolutions`` (not in the reference signature, default = its hard-wired ``[6, 12, 24]``, :78) and ``icl_heads`` let
+tests build small instances of the same class.
 """
 from __future__ import annotations
 
@@ -16,12 +18,13 @@ from .unet_3D import UNet3DBackbone
 
 
 class unet_3D_icl(UNet3DBackbone):  # noqa: N801 — reference class name
-    def __init__(self, feature_scale=4, n_classes=21, is_deconv=True, in_channels=3, is_batchnorm=True, device=None):
+    def __init__(self, feature_scale=4, n_classes=21, is_deconv=True, in_channels=3, is_batchnorm=True, device=None,
+                 icl_in_resolutions=(6, 12, 24), icl_heads=(16, 8, 4)):
         super().__init__(feature_scale, n_classes, is_deconv, in_channels, is_batchnorm, device)
         f = self.filters
         icl_in_chans = (f[4], f[3], f[2])
-        kw = dict(in_chans=icl_in_chans, depths=(2, 2, 2), patch_size=(2, 2, 2), input_resolution=[6, 12, 24],
-                  num_classes=n_classes, num_heads=(16, 8, 4), device=device)
+        kw = dict(in_chans=icl_in_chans, depths=(2, 2, 2), patch_size=(2, 2, 2), input_resolution=list(icl_in_resolutions),
+                  num_classes=n_classes, num_heads=tuple(icl_heads), device=device)
         self.sspa = InherentConsistent(**kw)
         self.uscl = InherentConsistent(**kw)
 

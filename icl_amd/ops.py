@@ -335,7 +335,9 @@ class _Conv3d(torch.autograd.Function):
                 # (the reference holds ~1e-8 rounding noise there); skip the reduction pass over dY.  The zero vector is a
                 # cached constant (nothing ever writes a non-zero into it), not a fill kernel per layer and step; returned as a
                 # fresh view so that AccumulateGrad adopts it instead of cloning a tensor it sees other references to.
-                gb = _cached_zeros(cout, x.device).view(cout)
+                # Only inside ICLTrainer's step bracket, where FusedSGD is the sole consumer of the gradient; anywhere else (stock
+                # optimisers, user code writing into .grad) every bias gets its own zero tensor.
+                gb = _cached_zeros(cout, x.device).view(cout) if PackedWeights.current is not None else x.new_zeros(cout)
                 gb_arg = None
             flops = 2.0 * ks ** 3 * cin * cout * s * n
             nbytes = 4.0 * (n * s * (cin + cout) + 2 * ks ** 3 * cin * cout)
@@ -712,17 +714,36 @@ def depthwise_conv3d(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
 # Dropout — nn.Dropout(p=0.3), unet_3D_icl.py:67-68
 # --------------------------------------------------------------------------------------
 
+def _mix32(x: int) -> int:
+    """The 32-bit finaliser of csrc/kernels/misc.h (mix32), on the host."""
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
 class StepRNG:
     """Device-resident step counter for dropout under hipGraph replay: a captured launch bakes its scalar arguments in,
-    so the per-step variation of the mask comes from this counter (incremented on the device at the end of every step)
-    and the per-call variation from a host-side call index that is identical in every replay."""
+    so the per-step variation of the mask comes from this counter (incremented on the device at the end of every step and
+    hashed into the seed by the kernel) and the per-call variation from a host-side call index that is identical in every
+    replay.  The stream is keyed by ``torch.initial_seed()`` (so ``torch.manual_seed`` selects it) and by the data-parallel rank
+    (every rank draws its own masks, as W independent reference processes would)."""
     tensor: Optional[torch.Tensor] = None
     calls = 0
+    base = 0
 
     @classmethod
-    def enable(cls, device):
+    def enable(cls, device, base_seed: Optional[int] = None, rank: Optional[int] = None):
         cls.tensor = torch.zeros(1, dtype=torch.int32, device=device)
         cls.calls = 0
+        if base_seed is None:
+            base_seed = torch.initial_seed()
+        if rank is None:
+            rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        cls.base = _mix32(_mix32(base_seed & 0xFFFFFFFF) ^ _mix32((base_seed >> 32) + 0x9E3779B1) ^ _mix32(rank + 0x85EBCA77))
 
     @classmethod
     def begin_step(cls):
@@ -732,6 +753,13 @@ class StepRNG:
     def end_step(cls):
         if cls.tensor is not None:
             cls.tensor += 1
+
+    @classmethod
+    def next_seed(cls) -> int:
+        """Seed of the next stochastic call of the step: a hash of (stream key, call index)."""
+        seed = _mix32(cls.base ^ _mix32(cls.calls + 0x2545F491))
+        cls.calls += 1
+        return seed
 
 
 class _Dropout(torch.autograd.Function):
@@ -791,8 +819,7 @@ def _step_seed(x, seed):
     seed_dev = None
     if seed is None:
         if StepRNG.tensor is not None and StepRNG.tensor.device == x.device:
-            seed = 0x2545F491 + 7919 * StepRNG.calls
-            StepRNG.calls += 1
+            seed = StepRNG.next_seed()
             seed_dev = StepRNG.tensor
         else:
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
@@ -814,8 +841,7 @@ def dropout(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Tens
     seed_dev = None
     if seed is None:
         if StepRNG.tensor is not None and StepRNG.tensor.device == x.device:
-            seed = 0x2545F491 + 7919 * StepRNG.calls
-            StepRNG.calls += 1
+            seed = StepRNG.next_seed()
             seed_dev = StepRNG.tensor
         else:
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
@@ -828,8 +854,7 @@ def drop_path(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Te
     seed_dev = None
     if seed is None:
         if StepRNG.tensor is not None and StepRNG.tensor.device == x.device:
-            seed = 0x2545F491 + 7919 * StepRNG.calls
-            StepRNG.calls += 1
+            seed = StepRNG.next_seed()
             seed_dev = StepRNG.tensor
         else:
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())

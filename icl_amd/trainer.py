@@ -114,6 +114,9 @@ class ICLTrainer:
         ~21 ms of host time, on par with the GPU time."""
         if self.lr_dev is not None:       # after capture() the kernels read the learning rate from device memory, replayed or not
             self.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
+        if self.graph_update is not None and not self.use_graph:
+            raise RuntimeError("a data-parallel trainer that has been captured cannot step eagerly (the reducer's buffers belong to "
+                               "the graphs); build a second trainer for eager steps")
         if self.graph is not None and self.use_graph:
             if volume_batch.data_ptr() != self.static_vol.data_ptr():
                 self.static_vol.copy_(volume_batch)
@@ -134,10 +137,18 @@ class ICLTrainer:
         the learning rate and the dropout seed — lives in device memory (FusedSGD.lr_dev, ops.StepRNG) so that a replay
         is a real training step: new masks, scheduled lr, updated weights.
 
+        The ``warmup`` steps before the capture are REAL training steps on this batch (weights, momentum, BatchNorm running
+        statistics, ``iter_num`` and the lr schedule advance): capture at the start of training, on the first batch.  The loss
+        terms returned by ``step()`` after a capture are the graph's static output tensors — every replay overwrites them, so
+        ``.clone()`` (or ``.item()``) what must outlive the next step.
+
         Data-parallel (``ddp`` given): two graphs.  The first holds forward, losses, backward and GradientReducer.pack()
         (gradients concatenated into flat buffers, factor rows scaled); the RCCL collectives on those persistent buffers are
         issued eagerly; the second graph holds the optimiser, reading the reduced buffers.  Nothing is captured while a
         collective is in flight and no collective is captured."""
+        if warmup < 1:
+            raise ValueError("capture() needs at least one warm-up step: the momentum buffers must exist before the capture, "
+                             "otherwise the captured SGD kernels would re-initialise them at every replay")
         dev = volume_batch.device
         ddp = self.ddp if (self.ddp is not None and self.ddp.active) else None
         self.static_vol = volume_batch.clone()
@@ -168,6 +179,7 @@ class ICLTrainer:
         self.graph_update = None
         if ddp is not None:
             ddp.rebind()
+            ddp._captured = True
             update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(update, pool=graph.pool(), **mode):
                 ddp.unpack()

@@ -128,3 +128,77 @@ def test_factored_gradient_exchange_world2(tmp_path):
 def test_gradient_reducer_world2(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+
+
+def _worker_icl_trainer(rank, world, port, tmp):
+    """ICLTrainer + GradientReducer on a small instance of the real model class (unet_3D_icl: backbone, both aligners, factored
+    token-axis MLP gradients, grad-None parameters) on the CPU emulation of the kernels: the gradients every rank ends up with are
+    the mean of the per-rank gradients (gathered and averaged here in plain Python), parameters stay identical across ranks and
+    the applied update is SGD(momentum, weight decay) on that mean."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HIPEMU_THREADS="4")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    from build_emu import build_emu
+    from icl_amd import _lib, ops
+    from icl_amd.ddp import GradientReducer
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    from icl_amd.utils.hashfill import synthetic_labels, synthetic_volume
+    _lib._use_library_for_tests(build_emu(), host_pointers=True)
+    torch.set_num_threads(2)
+    ops.FactoredGrads.min_elems = 64 * 64          # the 64-token mlp2 matrices of the finest scale stay factored
+    torch.manual_seed(50 + rank)                   # different initial weights per rank: broadcast must fix that
+    model = unet_3D_icl(feature_scale=16, n_classes=2, in_channels=1, icl_in_resolutions=(1, 2, 4), icl_heads=(8, 4, 2))
+    red = GradientReducer(model, world, bucket_bytes=1 << 16)
+    red.broadcast_parameters()
+    lr, mom, wd = 0.05, 0.9, 1e-2
+    tr = ICLTrainer(model, ICLConfig(num_classes=2, labeled_bs=1, patch_size=(16, 16, 16), base_lr=lr, weight_decay=wd), ddp=red)
+    vol = synthetic_volume((2, 1, 16, 16, 16), 900 + rank)
+    lab = synthetic_labels((1, 16, 16, 16), 950 + rank, 2)
+    p0 = {k: p.detach().clone() for k, p in model.named_parameters()}
+    tr._forward_backward(vol, lab)
+
+    def dense_grads():
+        out = {}
+        for k, p in model.named_parameters():
+            fac = getattr(p, "_icl_factors", None)
+            if fac:
+                out[k] = sum(g.detach().t() @ x.detach() for g, x in fac)
+            elif p.grad is not None:
+                out[k] = p.grad.detach().clone()
+        return out
+
+    local = dense_grads()
+    factored = [k for k, p in model.named_parameters() if getattr(p, "_icl_factors", None)]
+    assert sum("mlp2" in k for k in factored) == 4 and len(factored) >= 4, factored   # (+ other Linear layers of >= 64 x 64)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, {k: v.numpy() for k, v in local.items()})
+    assert all(sorted(e) == sorted(local) for e in everyone)           # the same grad-None set on every rank
+    none = [k for k, _ in model.named_parameters() if k not in local]
+    assert len(none) == 33 and any("uscl.guided_Q" == k for k in none)   # SURVEY.md §0.7: skipped, never zero-filled
+    red.reduce_gradients()
+    reduced = dense_grads()
+    assert sorted(reduced) == sorted(local)
+    for k, v in reduced.items():
+        mean = sum(torch.as_tensor(e[k]) for e in everyone) / world
+        assert torch.allclose(v, mean, rtol=1e-4, atol=1e-7 + 1e-5 * float(mean.abs().max())), k
+    tr._apply_update()
+    sums = [None] * world
+    dist.all_gather_object(sums, {k: float(p.detach().double().sum()) for k, p in model.named_parameters()})
+    assert sums[0] == sums[rank]                                          # replicas stay bit-identical
+    for k, p in model.named_parameters():
+        if k in none:
+            assert torch.equal(p.detach(), p0[k]), k                      # no weight decay on grad-None parameters
+        else:
+            want = p0[k] - lr * (reduced[k] + wd * p0[k])                 # first step: momentum buffer = d
+            assert torch.allclose(p.detach(), want, rtol=1e-5, atol=1e-6), k
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_icl_trainer_with_gradient_reducer_world2(tmp_path):
+    world = 2
+    from hipemu.build_emu import build_emu  # noqa: F401
+    build_emu()
+    mp.spawn(_worker_icl_trainer, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)

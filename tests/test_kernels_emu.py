@@ -263,6 +263,42 @@ def test_drop_path_is_per_sample_and_consistent_in_backward():
     assert not torch.equal(ops.drop_path(x.detach(), 0.25, seed=78) != 0, y.detach() != 0)
 
 
+def test_step_counter_masks_are_decorrelated_across_steps_ranks_and_seeds():
+    """Dropout under graph replay (ops.StepRNG): the device-resident step counter is hashed into the seed, so the mask of step t is
+    not the mask of step t-1 shifted by one element (the defect of a linear mix), per-sample DropPath decisions do not slide along
+    the batch from step to step, every data-parallel rank draws its own masks and torch.manual_seed selects the stream."""
+    x = torch.ones(1 << 14)
+
+    def masks(steps, rank=0, seed=1234):
+        torch.manual_seed(seed)
+        ops.StepRNG.enable(x.device, rank=rank)
+        out = []
+        for _ in range(steps):
+            ops.StepRNG.begin_step()
+            out.append((ops.dropout(x, 0.3) != 0, ops.drop_path(torch.ones(512, 4), 0.3)[:, 0] != 0))
+            ops.StepRNG.end_step()
+        ops.StepRNG.tensor = None
+        return out
+
+    try:
+        m = masks(4)
+        for t in range(1, 4):
+            a, b = m[t - 1][0], m[t][0]
+            keep = float(a.float().mean())
+            assert 0.66 < keep < 0.74
+            for shift in (0, 1, 2, 3):          # agreement with shifted copies of the previous mask stays at the chance level
+                agree = float((a[shift:] == b[:len(b) - shift]).float().mean())
+                assert abs(agree - (keep ** 2 + (1 - keep) ** 2)) < 0.03, (t, shift, agree)
+            pa, pb = m[t - 1][1], m[t][1]
+            assert float((pa[1:] == pb[:-1]).float().mean()) < 0.75      # sample k at step t is not sample k+1 at step t-1
+        again = masks(2)
+        assert torch.equal(again[1][0], m[1][0])                          # same seed, same rank: same stream
+        other_rank, other_seed = masks(2, rank=1), masks(2, seed=99)
+        assert not torch.equal(other_rank[0][0], m[0][0]) and not torch.equal(other_seed[0][0], m[0][0])
+    finally:
+        ops.StepRNG.tensor = None
+
+
 def test_packed_weight_cache_repacks_all_weights_in_one_launch():
     """ops.PackedWeights: first bracketed step packs per call and records the Parameters, later begin_step() calls repack all of
     them at once (after an in-place weight update, as FusedSGD does) — results equal the uncached path, gradients included."""
