@@ -263,9 +263,17 @@ __device__ __forceinline__ float4 gemm_load4(const float* __restrict__ base, lon
   return v;
 }
 
-template <bool AK, bool BK_, int WM, int WN>
+// swizzled quad of a k-contiguous LDS row: rows of 8 quads (KT = 32) or 16 quads (KT = 64)
+template <int KT>
+__device__ __forceinline__ int gemm_swz(int row, int q) { return KT == 32 ? (q ^ ((row >> 1) & 7)) : (q ^ (row & 15)); }
+
+// FAST (chosen by the launcher): both operands 16-byte aligned with pitches % 4 == 0, K % 4 == 0 for a k-contiguous operand and
+// the row count % 4 == 0 for a k-strided one.  The k-loop then holds nothing but 16-byte loads at loop-invariant pointers + k:
+// row indices are CLAMPED (rows past M / N only feed output rows / columns that are never stored) and only the last, partial
+// k-step zeroes the quads past the end of the range.  !FAST: element-wise bounds-checked loads (gemm_load4).
+template <bool AK, bool BK_, int WM, int WN, bool FAST = true, int KT = 32>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
-  constexpr int NT = WM * WN * 64, BM = WM * 64, BN = WN * 64, KT = 32;
+  constexpr int NT = WM * WN * 64, BM = WM * 64, BN = WN * 64, QR = KT / 4;   // QR quads per k-contiguous row
   constexpr int AV = BM * KT / 4 / NT, BV = BN * KT / 4 / NT;       // float4 per thread and k-step
   ICL_DYN_LDS(float, lds);
   float* as = lds;                 // AK: [BM][32] swizzled; else [32][BM]
@@ -278,30 +286,63 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
   const int k_hi = k_lo + g.kper < g.K ? k_lo + g.kper : g.K;
   g.a += batch * g.a_bstride;
   g.b += batch * g.b_bstride;
-  const bool avec = (g.lda & 3) == 0 && (((unsigned long long)g.a) & 15ull) == 0;
-  const bool bvec = (g.ldb & 3) == 0 && (((unsigned long long)g.b) & 15ull) == 0;
   float4 ar[AV], br[BV];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < AV; ++j) {
-      const int it = tid + j * NT;
-      if (AK) {   // item = (row, quad): 8 quads per row
-        const int row = it >> 3, q = it & 7;
-        ar[j] = gemm_load4(g.a, g.lda, m0 + row, k0 + 4 * q, g.M, k_hi, avec);
-      } else {    // item = (k row, quad of m): BM/4 quads per k row
-        const int kr = it / (BM / 4), q = it % (BM / 4);
-        ar[j] = gemm_load4(g.a, g.lda, k0 + kr, m0 + 4 * q, k_hi, g.M, avec);
-      }
+  // per-thread staging pointers (loop invariant)
+  const float* ap[AV];
+  const float* bp[BV];
+  auto item_ptr = [&](const float* base, long ld, bool kc, int r0, int rows, int it, int BX) -> const float* {
+    if (kc) {   // item = (row, k quad): QR quads per row
+      int row = r0 + it / QR;
+      row = row < rows ? row : rows - 1;
+      return base + (long)row * ld + 4 * (it % QR);
     }
+    // item = (k row, quad of the row index): BX/4 quads per k row; clamped quads feed rows that are never stored
+    int c = r0 + 4 * (it % (BX / 4));
+    c = c + 3 < rows ? c : rows - 4;
+    return base + (long)(it / (BX / 4)) * ld + c;
+  };
+  if (FAST) {
 #pragma unroll
-    for (int j = 0; j < BV; ++j) {
-      const int it = tid + j * NT;
-      if (BK_) {
-        const int row = it >> 3, q = it & 7;
-        br[j] = gemm_load4(g.b, g.ldb, n0 + row, k0 + 4 * q, g.N, k_hi, bvec);
+    for (int j = 0; j < AV; ++j) ap[j] = item_ptr(g.a, g.lda, AK, m0, g.M, tid + j * NT, BM);
+#pragma unroll
+    for (int j = 0; j < BV; ++j) bp[j] = item_ptr(g.b, g.ldb, BK_, n0, g.N, tid + j * NT, BN);
+  }
+  // k offset of an item inside a k-step (for the tail test) and the pointer stride per k
+  auto item_k = [&](bool kc, int it, int BX) { return kc ? 4 * (it % QR) : it / (BX / 4); };
+  const long astep = AK ? 1 : g.lda, bstep = BK_ ? 1 : g.ldb;
+  auto fetch = [&](int k0) {
+    if (FAST) {
+      if (k0 + KT <= k_hi) {                              // every k-step but possibly the last one
+#pragma unroll
+        for (int j = 0; j < AV; ++j) ar[j] = *reinterpret_cast<const float4*>(ap[j] + k0 * astep);
+#pragma unroll
+        for (int j = 0; j < BV; ++j) br[j] = *reinterpret_cast<const float4*>(bp[j] + k0 * bstep);
       } else {
-        const int kr = it / (BN / 4), q = it % (BN / 4);
-        br[j] = gemm_load4(g.b, g.ldb, k0 + kr, n0 + 4 * q, k_hi, g.N, bvec);
+#pragma unroll
+        for (int j = 0; j < AV; ++j) {
+          const bool ok = k0 + item_k(AK, tid + j * NT, BM) < k_hi;
+          const float4 v = *reinterpret_cast<const float4*>(ok ? ap[j] + k0 * astep : g.a);
+          ar[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < BV; ++j) {
+          const bool ok = k0 + item_k(BK_, tid + j * NT, BN) < k_hi;
+          const float4 v = *reinterpret_cast<const float4*>(ok ? bp[j] + k0 * bstep : g.b);
+          br[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < AV; ++j) {
+        const int it = tid + j * NT;
+        if (AK) ar[j] = gemm_load4(g.a, g.lda, m0 + it / QR, k0 + 4 * (it % QR), g.M, k_hi, false);
+        else ar[j] = gemm_load4(g.a, g.lda, k0 + it / (BM / 4), m0 + 4 * (it % (BM / 4)), k_hi, g.M, false);
+      }
+#pragma unroll
+      for (int j = 0; j < BV; ++j) {
+        const int it = tid + j * NT;
+        if (BK_) br[j] = gemm_load4(g.b, g.ldb, n0 + it / QR, k0 + 4 * (it % QR), g.N, k_hi, false);
+        else br[j] = gemm_load4(g.b, g.ldb, k0 + it / (BN / 4), n0 + 4 * (it % (BN / 4)), k_hi, g.N, false);
       }
     }
   };
@@ -310,8 +351,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     for (int j = 0; j < AV; ++j) {
       const int it = tid + j * NT;
       if (AK) {
-        const int row = it >> 3, q = it & 7;
-        *reinterpret_cast<float4*>(as + row * KT + 4 * (q ^ ((row >> 1) & 7))) = ar[j];
+        const int row = it / QR, q = it % QR;
+        *reinterpret_cast<float4*>(as + row * KT + 4 * gemm_swz<KT>(row, q)) = ar[j];
       } else {
         *reinterpret_cast<float4*>(as + 4 * it) = ar[j];
       }
@@ -320,8 +361,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     for (int j = 0; j < BV; ++j) {
       const int it = tid + j * NT;
       if (BK_) {
-        const int row = it >> 3, q = it & 7;
-        *reinterpret_cast<float4*>(bs + row * KT + 4 * (q ^ ((row >> 1) & 7))) = br[j];
+        const int row = it / QR, q = it % QR;
+        *reinterpret_cast<float4*>(bs + row * KT + 4 * gemm_swz<KT>(row, q)) = br[j];
       } else {
         *reinterpret_cast<float4*>(bs + 4 * it) = br[j];
       }
@@ -347,7 +388,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = wm * 64 + 16 * i + u;
-          const float4 v = *reinterpret_cast<const float4*>(as + row * KT + 4 * ((4 * s + lg) ^ ((row >> 1) & 7)));
+          const float4 v = *reinterpret_cast<const float4*>(as + row * KT + 4 * gemm_swz<KT>(row, 4 * s + lg));
           af[0][i] = v.x; af[1][i] = v.y; af[2][i] = v.z; af[3][i] = v.w;
         }
       } else {
@@ -361,7 +402,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int row = wn * 64 + 16 * t + u;
-          const float4 v = *reinterpret_cast<const float4*>(bs + row * KT + 4 * ((4 * s + lg) ^ ((row >> 1) & 7)));
+          const float4 v = *reinterpret_cast<const float4*>(bs + row * KT + 4 * gemm_swz<KT>(row, 4 * s + lg));
           bf[0][t] = v.x; bf[1][t] = v.y; bf[2][t] = v.z; bf[3][t] = v.w;
         }
       } else {

@@ -49,7 +49,7 @@ def test_linear_forward_and_input_gradient(rows, i, o, act):
 
 
 @pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
-@pytest.mark.parametrize("m,n,k", [(70, 150, 100), (200, 40, 36), (33, 260, 72)])
+@pytest.mark.parametrize("m,n,k", [(70, 150, 100), (200, 40, 36), (33, 260, 72), (68, 152, 100)])
 def test_gemm_layouts(ak, bk, m, n, k):
     a = _rand((m, k), 5) if ak else _rand((k, m), 5)
     b = _rand((n, k), 6) if bk else _rand((k, n), 6)

@@ -90,3 +90,11 @@ if which in ("all", "convt"):
         fl = 2.0 * b * r ** 3 * cin * cout * 8 / 1e6
         print(f"convT {cin:4d}->{cout:4d} @{r:2d}^3  fwd {f1:7.1f} us ({fl / f1:6.1f} TF)  fwd+bwd {fb1:7.1f} us ({3 * fl / fb1:6.1f} TF)  "
               f"err y {err(y, yr):.1e} gx {err(gx, gxr):.1e} gw {err(gw, gwr):.1e}", flush=True)
+
+if which == "one":
+    rows, i, o = 128, 13824, 13824
+    x = torch.randn(rows, i, device=dev)
+    w = torch.randn(o, i, device=dev) * 0.05
+    b = torch.randn(o, device=dev)
+    f1 = t(lambda: ops.linear_forward_raw(x, w, b))
+    print(f"[{rows},{i}]->{o} fwd {f1:7.1f} us ({2.0 * rows * i * o / 1e6 / f1:6.1f} TF)")
