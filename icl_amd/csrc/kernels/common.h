@@ -33,6 +33,9 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// component j of a float4 (j is a compile-time constant after unrolling)
+__device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+
 __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Chan et al. merge of two (count, mean, M2) summaries — numerically stable variance.

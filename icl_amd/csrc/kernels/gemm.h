@@ -18,8 +18,6 @@
 
 namespace icl {
 
-__device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
-
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
 // epilogue shared by all product kernels: bias (per output column) and activation (0 none, 1 exact-erf GELU)

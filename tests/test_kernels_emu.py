@@ -53,6 +53,14 @@ def test_conv3d_fwd_bwd(n, cin, cout, d, h, w, ks):
     _conv_check(n, cin, cout, d, h, w, ks)
 
 
+@pytest.mark.parametrize("mode", ["a4", "a2", "b4", "c2"])
+@pytest.mark.parametrize("n,cin,cout,d,h,w", [(1, 16, 16, 4, 8, 16), (2, 20, 48, 6, 8, 16), (1, 8, 32, 5, 12, 12), (1, 4, 16, 3, 16, 24)])
+def test_conv3d_wgrad_row_window_kernel(monkeypatch, mode, n, cin, cout, d, h, w):
+    """conv_wgrad_rows.h: every tile / row-group variant, 1-3 cout blocks per workgroup, ragged channels, partial x / y / z tiles."""
+    monkeypatch.setenv("ICL_WGRAD_ROWS", mode)
+    _conv_check(n, cin, cout, d, h, w, 3)
+
+
 def test_conv3d_forced_big_tile(monkeypatch):
     monkeypatch.setenv("ICL_CONV_FORCE_TILE", "48")
     _conv_check(1, 16, 16, 6, 8, 16, 3)

@@ -1,0 +1,8 @@
+# usage: bash tools/pmc_conv.sh <tag> <env assignments...> -- <conv_one args>   (two SQ counter passes, kernel-trace only)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+TAG=$1; shift
+while [ "$1" != "--" ]; do export "$1"; shift; done; shift
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD --kernel-trace -d $R/gpurun_out/pmc_${TAG}_1 -o p --output-format csv -- python3 $R/tools/conv_one.py "$@" > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --kernel-trace -d $R/gpurun_out/pmc_${TAG}_2 -o p --output-format csv -- python3 $R/tools/conv_one.py "$@" > /dev/null 2>&1
+rm -f $R/gpurun_out/pmc_${TAG}_*/p_kernel_trace.csv
