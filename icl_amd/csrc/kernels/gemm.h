@@ -269,16 +269,22 @@ __device__ __forceinline__ int gemm_swz(int row, int q) { return KT == 32 ? (q ^
 // the row count % 4 == 0 for a k-strided one.  The k-loop then holds nothing but 16-byte loads at loop-invariant pointers + k:
 // row indices are CLAMPED (rows past M / N only feed output rows / columns that are never stored) and only the last, partial
 // k-step zeroes the quads past the end of the range.  !FAST: element-wise bounds-checked loads (gemm_load4).
-template <bool AK, bool BK_, int WM, int WN, bool FAST = true, int KT = 32>
+// TN = MFMA tiles per wave along n (4; 3 for k-contiguous B: 48-column wave tiles fit the 48 / 96 / 144 / 192 / 288-wide Linear layers
+// of the Swin stages without padded columns).
+template <bool AK, bool BK_, int WM, int WN, bool FAST = true, int KT = 32, int TN = 4>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
-  constexpr int NT = WM * WN * 64, BM = WM * 64, BN = WN * 64, QR = KT / 4;   // QR quads per k-contiguous row
-  constexpr int AV = BM * KT / 4 / NT, BV = BN * KT / 4 / NT;       // float4 per thread and k-step
+  static_assert(TN == 4 || BK_, "a k-strided B operand supplies four n tiles per 16-byte read");
+  constexpr int NT = WM * WN * 64, BM = WM * 64, WNC = 16 * TN, BN = WN * WNC, QR = KT / 4;   // QR quads per k-contiguous row
+  constexpr int AV = (BM * KT / 4 + NT - 1) / NT, BV = (BN * KT / 4 + NT - 1) / NT;       // float4 per thread and k-step
+  constexpr bool ARAG = (BM * KT / 4) % NT != 0, BRAG = (BN * KT / 4) % NT != 0;   // the last item of a thread may lie past the tile
   ICL_DYN_LDS(float, lds);
   float* as = lds;                 // AK: [BM][32] swizzled; else [32][BM]
   float* bs = lds + BM * KT;       // BK_: [BN][32] swizzled; else [32][BN]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, u = lane & 15, lg = lane >> 4;
   const int wm = wid / WN, wn = wid % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int m0 = blockIdx.y * BM;            // row block being computed; the workgroup walks row blocks m0, m0 + gridDim.y * BM, ...
+  int mf = m0;                         // row block the staging loads address (one block ahead at the end of a k range)
+  const int n0 = blockIdx.x * BN;
   const int batch = blockIdx.z / g.nsplit, split_id = blockIdx.z % g.nsplit;
   const int k_lo = split_id * g.kper;
   const int k_hi = k_lo + g.kper < g.K ? k_lo + g.kper : g.K;
@@ -299,11 +305,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     c = c + 3 < rows ? c : rows - 4;
     return base + (long)(it / (BX / 4)) * ld + c;
   };
+  auto set_a_ptrs = [&]() {
+#pragma unroll
+    for (int j = 0; j < AV; ++j) {
+      const int it = tid + j * NT;
+      ap[j] = item_ptr(g.a, g.lda, AK, mf, g.M, (ARAG && it >= BM * QR) ? 0 : it, BM);
+    }
+  };
   if (FAST) {
+    set_a_ptrs();
 #pragma unroll
-    for (int j = 0; j < AV; ++j) ap[j] = item_ptr(g.a, g.lda, AK, m0, g.M, tid + j * NT, BM);
-#pragma unroll
-    for (int j = 0; j < BV; ++j) bp[j] = item_ptr(g.b, g.ldb, BK_, n0, g.N, tid + j * NT, BN);
+    for (int j = 0; j < BV; ++j) {
+      const int it = tid + j * NT;
+      bp[j] = item_ptr(g.b, g.ldb, BK_, n0, g.N, (BRAG && it >= BN * QR) ? 0 : it, BN);
+    }
   }
   // k offset of an item inside a k-step (for the tail test) and the pointer stride per k
   auto item_k = [&](bool kc, int it, int BX) { return kc ? 4 * (it % QR) : it / (BX / 4); };
@@ -333,8 +348,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < AV; ++j) {
         const int it = tid + j * NT;
-        if (AK) ar[j] = gemm_load4(g.a, g.lda, m0 + it / QR, k0 + 4 * (it % QR), g.M, k_hi, false);
-        else ar[j] = gemm_load4(g.a, g.lda, k0 + it / (BM / 4), m0 + 4 * (it % (BM / 4)), k_hi, g.M, false);
+        if (AK) ar[j] = gemm_load4(g.a, g.lda, mf + it / QR, k0 + 4 * (it % QR), g.M, k_hi, false);
+        else ar[j] = gemm_load4(g.a, g.lda, k0 + it / (BM / 4), mf + 4 * (it % (BM / 4)), k_hi, g.M, false);
       }
 #pragma unroll
       for (int j = 0; j < BV; ++j) {
@@ -348,6 +363,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < AV; ++j) {
       const int it = tid + j * NT;
+      if (ARAG && it >= BM * QR) continue;
       if (AK) {
         const int row = it / QR, q = it % QR;
         *reinterpret_cast<float4*>(as + row * KT + 4 * gemm_swz<KT>(row, q)) = ar[j];
@@ -358,6 +374,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < BV; ++j) {
       const int it = tid + j * NT;
+      if (BRAG && it >= BN * QR) continue;
       if (BK_) {
         const int row = it / QR, q = it % QR;
         *reinterpret_cast<float4*>(bs + row * KT + 4 * gemm_swz<KT>(row, q)) = br[j];
@@ -366,22 +383,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
       }
     }
   };
-  f32x4 acc[4][4];
+  f32x4 acc[4][TN];
+  fetch(k_lo);
+  // Row blocks are walked inside the workgroup (tall products launch ~2 workgroups per CU): the first staging loads of the NEXT
+  // row block are issued before the epilogue of the current one, so a block's load latency hides behind the previous block's
+  // stores instead of opening every (short-lived) workgroup.
+  for (;;) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  fetch(k_lo);
+    for (int t = 0; t < TN; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int k0 = k_lo; k0 < k_hi; k0 += KT) {
     __syncthreads();
     stash();
     __syncthreads();
-    if (k0 + KT < k_hi) fetch(k0 + KT);
+    if (k0 + KT < k_hi) {
+      fetch(k0 + KT);
+    } else if (m0 + (int)gridDim.y * BM < g.M) {
+      mf = m0 + (int)gridDim.y * BM;
+      if (FAST) set_a_ptrs();
+      fetch(k_lo);
+    }
 #pragma unroll
     for (int s = 0; s < KT / 16; ++s) {
       // operand fragments of this 16-deep k group: af[e][i] / bf[e][t] = value of MFMA tile i / t for k label 16 s + 4 lg + e
-      float af[4][4], bf[4][4];
+      float af[4][4], bf[4][TN];
       if (AK) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -396,17 +422,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
           af[e][0] = v.x; af[e][1] = v.y; af[e][2] = v.z; af[e][3] = v.w;
         }
       }
-      if (BK_) {
+      if constexpr (BK_) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int row = wn * 64 + 16 * t + u;
+        for (int t = 0; t < TN; ++t) {
+          const int row = wn * WNC + 16 * t + u;
           const float4 v = *reinterpret_cast<const float4*>(bs + row * KT + 4 * gemm_swz<KT>(row, 4 * s + lg));
           bf[0][t] = v.x; bf[1][t] = v.y; bf[2][t] = v.z; bf[3][t] = v.w;
         }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float4 v = *reinterpret_cast<const float4*>(bs + (16 * s + 4 * lg + e) * BN + wn * 64 + 4 * u);
+          const float4 v = *reinterpret_cast<const float4*>(bs + (16 * s + 4 * lg + e) * BN + wn * WNC + 4 * u);
           bf[e][0] = v.x; bf[e][1] = v.y; bf[e][2] = v.z; bf[e][3] = v.w;
         }
       }
@@ -415,7 +441,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[i][t] = icl_mfma_16x16x4(af[e][i], bf[e][t], acc[i][t]);
+          for (int t = 0; t < TN; ++t) acc[i][t] = icl_mfma_16x16x4(af[e][i], bf[e][t], acc[i][t]);
     }
   }
   // D register q of tile (i, t), lane (u, lg): A-side index 4 lg + q, B-side index u.
@@ -425,21 +451,58 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
   const int act = g.act & 15;
   const bool brow = (g.act & 16) != 0;
   const bool split = g.c_split_stride != 0 || g.nsplit > 1;
+  if constexpr (BK_) {
+    // k-contiguous B: a lane holds ONE column per tile (16 lanes = 64 contiguous bytes per row and store instruction, the access
+    // shape that streams at half the HBM rate).  The wave's 64 x WNC tile goes through a wave-private LDS buffer in two 32-row
+    // halves and leaves as 16-byte stores along the rows: 192 / 256 contiguous bytes per row and instruction.
+    constexpr int EP = WNC + 4, QW = WNC / 4;
+    const bool cvec = (g.ldc & 3) == 0 && (((unsigned long long)c) & 15ull) == 0;
+    __syncthreads();                                   // every wave is done with the operand tiles
+    float* ep = lds + wid * (32 * EP);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = m0 + wm * 64 + (AK ? 16 * i + 4 * lg + q : 4 * (4 * lg + q) + i);
-      if (row >= g.M) continue;
-      float* crow = c + (long)row * g.ldc;
-      if (BK_) {
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int col = n0 + wn * 64 + 16 * t + u;
-          if (col < g.N) crow[col] = split ? acc[i][t][q] : gemm_epilogue(acc[i][t][q], g.bias, brow ? row : col, act);
+        for (int q = 0; q < 4; ++q) {
+          const int lrow = AK ? 16 * i + 4 * lg + q : 4 * (4 * lg + q) + i;      // row inside the wave tile
+          if ((lrow >> 5) != h) continue;
+#pragma unroll
+          for (int t = 0; t < TN; ++t) ep[(lrow & 31) * EP + 16 * t + u] = acc[i][t][q];
         }
-      } else {
-        const int col = n0 + wn * 64 + 4 * u;
+      ICL_WAVE_SYNC();
+      for (int it = lane; it < 32 * QW; it += 64) {
+        const int r = it / QW, qd = it % QW;
+        const int row = m0 + wm * 64 + 32 * h + r, col = n0 + wn * WNC + 4 * qd;
+        if (row >= g.M || col >= g.N) continue;
+        float4 v = *reinterpret_cast<const float4*>(ep + r * EP + 4 * qd);
+        if (!split) {
+          v.x = gemm_epilogue(v.x, g.bias, brow ? row : col, act);
+          v.y = gemm_epilogue(v.y, col + 1 < g.N ? g.bias : nullptr, brow ? row : col + 1, act);
+          v.z = gemm_epilogue(v.z, col + 2 < g.N ? g.bias : nullptr, brow ? row : col + 2, act);
+          v.w = gemm_epilogue(v.w, col + 3 < g.N ? g.bias : nullptr, brow ? row : col + 3, act);
+        }
+        float* dst = c + (long)row * g.ldc + col;
+        if (cvec && col + 3 < g.N) {
+          *reinterpret_cast<float4*>(dst) = v;
+        } else {
+          dst[0] = v.x;
+          if (col + 1 < g.N) dst[1] = v.y;
+          if (col + 2 < g.N) dst[2] = v.z;
+          if (col + 3 < g.N) dst[3] = v.w;
+        }
+      }
+      ICL_WAVE_SYNC();
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m0 + wm * 64 + (AK ? 16 * i + 4 * lg + q : 4 * (4 * lg + q) + i);
+        if (row >= g.M) continue;
+        float* crow = c + (long)row * g.ldc;
+        const int col = n0 + wn * WNC + 4 * u;
         float v[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = (split || col + t >= g.N) ? acc[i][t][q] : gemm_epilogue(acc[i][t][q], g.bias, brow ? row : col + t, act);
@@ -451,7 +514,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
             if (col + t < g.N) crow[col + t] = v[t];
         }
       }
-    }
+  }
+  m0 += (int)gridDim.y * BM;
+  if (m0 >= g.M) break;
+  }   // row blocks
 }
 
 }  // namespace icl

@@ -35,6 +35,9 @@ def _rand(shape, seed):
     (5, 72, 40, 1),          # small weights: tiled product, ragged everything
     (300, 64, 136, 0),       # tall input, tiled product
     (40, 1536, 48, 0),       # split-K (few output tiles, deep K)
+    (200, 48, 144, 1),       # 48-column wave tiles: 128 x 144 block of six waves (Swin qkv), K tail
+    (300, 96, 96, 0),        # 128 x 96 block
+    (150, 192, 48, 0),       # 256 x 48 block
 ])
 def test_linear_forward_and_input_gradient(rows, i, o, act):
     x, w, b = _rand((rows, i), 1), _rand((o, i), 2) * 0.05, _rand((o,), 3)

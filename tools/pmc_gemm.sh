@@ -1,5 +1,7 @@
+# usage: bash tools/pmc_gemm.sh <tag> <rows> <in> <out> <fwd|dgrad|wgrad>   (two SQ counter passes, kernel-trace only)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD --kernel-trace -d $R/gpurun_out/pmc_gemm1 -o p --output-format csv -- python3 $R/tools/gemm_one.py 128 13824 13824 fwd 2 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --kernel-trace -d $R/gpurun_out/pmc_gemm2 -o p --output-format csv -- python3 $R/tools/gemm_one.py 128 13824 13824 fwd 2 > /dev/null 2>&1
-ls $R/gpurun_out/pmc_gemm1 $R/gpurun_out/pmc_gemm2
+TAG=$1; shift
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD --kernel-trace -d $R/gpurun_out/pmc_${TAG}_1 -o p --output-format csv -- python3 $R/tools/gemm_one.py "$@" 12 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR --kernel-trace -d $R/gpurun_out/pmc_${TAG}_2 -o p --output-format csv -- python3 $R/tools/gemm_one.py "$@" 12 > /dev/null 2>&1
+rm -f $R/gpurun_out/pmc_${TAG}_*/p_kernel_trace.csv
