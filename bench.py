@@ -74,14 +74,20 @@ def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
             "sample": f"{steps} full ICL step(s) of the same workload (2 volumes 96^3 each, nc={num_classes}) after a 32^3 conv warm-up: {t:.2f} s"}
 
 
+HBM_TRAFFIC_FILE = "profiles/r2_hbm_traffic.json"
+
+
 def hbm_traffic(kernel: str):
-    """HBM bytes per launch of the dominant kernel from the committed PMC run (profiles/r1_hbm_traffic.json: FETCH_SIZE and
-    WRITE_SIZE passes of rocprofv3 on one reference layer of that kernel, gfx950 correction applied) — counters cannot be
-    collected from inside this process, so the number is the one measured by that run, for the layer named in `shape`."""
+    """HBM bytes per launch of a kernel from the committed PMC run (FETCH_SIZE and WRITE_SIZE passes of rocprofv3 on one
+    reference layer of that kernel, gfx950 correction applied) — counters cannot be collected from inside this process, so the
+    number is a STATIC one, measured by that run for the layer named in `shape`; the JSON line says so (`source`)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, HBM_TRAFFIC_FILE)) as f:
             k = json.load(f)["kernels"].get(kernel)
-        return {kk: k[kk] for kk in ("shape", "hbm_bytes", "algorithmic_bytes")} if k else None
+        if not k:
+            return None
+        return {"source": f"static profile ({HBM_TRAFFIC_FILE}), not measured in this run",
+                **{kk: k[kk] for kk in ("shape", "hbm_bytes", "algorithmic_bytes")}}
     except (OSError, ValueError, KeyError):
         return None
 
@@ -214,7 +220,7 @@ def main():
             for _ in range(3):
                 trainer.step(vol, lab)
         summ = kt.summary()
-        conv = {k: v for k, v in summ.items() if k.startswith("conv3d_mfma")}
+        conv = {k: v for k, v in summ.items() if k.startswith("conv3d_")}
         if conv:
             # dominant kernel = the conv instantiation with the largest total time (same name as in rocprofv3's stats)
             # (forward/dgrad launches only: a wgrad call also runs its slab-reduction kernel inside the timed bracket)
@@ -228,6 +234,9 @@ def main():
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": traffic["hbm_bytes"] if traffic else None, "traffic_detail": traffic,
+                    # PMC (profiles/r2_pmc_conv.md, static): this kernel keeps the matrix pipe busy 81-85 % of its cycles; the rest of
+                    # the gap to the 2.4 GHz peak is the clock the chip holds under fp32-MFMA load (1.85-2.13 GHz)
+                    "matrix_pipe_busy_static_profile": 0.81,
                     "launches_per_step": n // 3, "avg_launch_us": round(ms * 1e3 / n, 2),
                     # what the event pair itself adds to a bracketed launch on the idle eager stream (NOT subtracted above: the raw
                     # durations are the conservative ones; rocprofv3's per-kernel averages in profiles/ are shorter by about this much)
@@ -238,6 +247,13 @@ def main():
                                  "hbm_frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
                     "per_kernel": {k: {"launches_per_step": v[0] // 3, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
                                        "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(conv.items())}}
+            st = {k: v for k, v in summ.items() if k.startswith("linear_stream")}
+            if st:   # the 13,824^2 token-axis MLP products: the weight matrix streamed once per launch (csrc/kernels/gemm.h)
+                roof["mlp2_weight_stream"] = {k: {"bound": "hbm", "launches_per_step": v[0] // 3, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
+                                                  "achieved": round(v[3] / (v[1] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                  "frac": round(v[3] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                                  "note": "launch = streaming kernel + slab sum; bytes = weight matrix"}
+                                              for k, v in sorted(st.items())}
             sg = summ.get("sgd_factored_kernel")
             if sg:   # the largest single kernel of the U-Net step by time: the factored SGD update of the four 13,824^2 matrices
                 gbs = sg[3] / (sg[1] * 1e-3) / 1e9

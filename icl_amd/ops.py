@@ -880,7 +880,8 @@ def linear_forward_raw(x2: torch.Tensor, weight: torch.Tensor, bias: Optional[to
     y = torch.empty((rows, o), dtype=torch.float32, device=x2.device)
     need = L.icl_linear_ws_bytes(rows, i, o, 0)
     ws = _ws(need, x2) if need else None
-    with _timed("linear_fwd", 2.0 * rows * i * o, 4.0 * (rows * (i + o) + i * o), x2):
+    big = rows <= 32 and i * o >= (1 << 26)      # the 13,824^2 matrices: reported separately (bench.py roofline.mlp2_weight_stream)
+    with _timed("linear_stream_fwd" if big else "linear_fwd", 2.0 * rows * i * o, 4.0 * (i * o if big else rows * (i + o) + i * o), x2):
         _lib.check(L.icl_linear_fwd(_ptr(x2), _ptr(weight), _ptr(bias), _ptr(y), _ptr(ws), rows, i, o, act, _stream(x2)), "linear_fwd")
     return y
 
@@ -894,7 +895,8 @@ def linear_dgrad_raw(g2: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     gx = torch.empty((rows, i), dtype=torch.float32, device=g2.device)
     need = L.icl_linear_ws_bytes(rows, i, o, 1)
     ws = _ws(need, g2) if need else None
-    with _timed("linear_dgrad", 2.0 * rows * i * o, 4.0 * (rows * (i + o) + i * o), g2):
+    big = rows <= 32 and i * o >= (1 << 26)
+    with _timed("linear_stream_dgrad" if big else "linear_dgrad", 2.0 * rows * i * o, 4.0 * (i * o if big else rows * (i + o) + i * o), g2):
         _lib.check(L.icl_linear_dgrad(_ptr(g2), _ptr(weight), _ptr(gx), _ptr(ws), rows, i, o, _stream(g2)), "linear_dgrad")
     return gx
 
