@@ -520,7 +520,7 @@ def test_sliding_window_validation_and_checkpoint_interop(dev):
     icl.eval(); plain.eval()
     x = synthetic_volume((1, 1, 96, 96, 96), 5).to(dev)
     with torch.no_grad():
-        # same weights, same kernels; the Cin-split layers accumulate with fp32 atomics, so compare to rounding
+        # same weights, same kernels, fixed-order slab sums: equal up to nothing but the order of the checks below
         assert rel_err(icl(x, inference=True).cpu(), plain(x).cpu()) < 1e-5
     patch = (96, 96, 96)
     for shape in [(100, 110, 120), (80, 100, 96)]:
@@ -665,10 +665,12 @@ def test_graph_replay_equals_eager_steps(dev):
         del tr, model
         torch.cuda.empty_cache()
     (w0, b0, l0), (w1, b1, l1) = finals
-    assert rel_err(w1.cpu(), w0.cpu()) < 1e-4 and rel_err(b1.cpu(), b0.cpu()) < 1e-4
-    # two EAGER runs already differ by ~1e-4 (step 3) .. 1e-3 (step 5): the Cin-split convolutions accumulate with fp32
-    # atomics and the training dynamics amplify that rounding noise; the replayed steps must sit inside the same band
-    assert np.allclose(l0, l1, rtol=5e-3), (l0, l1)
+    # Measured (tests/diag/replay_band.py, parity mode): step 3 is bit-identical across two eager runs and a replayed run, step 4
+    # differs by 3.6e-6 (eager vs eager) / 7e-6 (eager vs replay) in the loss and 1e-7 in the parameters.  The only run-to-run
+    # noise left in the step are the fp32 atomics of the LayerNorm gamma / beta gradients (csrc/kernels/token.h); convolutions
+    # (Cin-split and weight-gradient slabs) and the loss statistics are summed in a fixed order.  Band = 10x the measurement.
+    assert rel_err(w1.cpu(), w0.cpu()) < 1e-5 and rel_err(b1.cpu(), b0.cpu()) < 1e-5
+    assert np.allclose(l0, l1, rtol=1e-4), (l0, l1)
     # dropout under replay: the device-resident step counter changes the mask between replays
     ops.StepRNG.enable(dev)
     x = torch.ones(1 << 16, device=dev)
