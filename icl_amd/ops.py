@@ -1062,7 +1062,14 @@ class FactoredGrads:
 
     enabled = False
     min_elems = 1 << 21      # the four 13,824^2 and the four 1,728^2 token-axis matrices of the 3-D ICL models
-    max_rows = 512
+    max_rows = 512           # rows of ONE backward call
+    # Data-parallel crossover: the ranks all-gather the factor rows, so the update every rank applies has rows * world rows and is
+    # MFMA-bound beyond a few hundred (tools/sgd_probe.py, 13,824^2: 0.54 ms at 16 rows, 0.80 at 128, 2.1 at 512, 4.0 at 1024,
+    # 5.9 at 1536 — ~100 TFLOP/s).  The dense alternative costs the 764 MB gradient (0.5 ms to form), its all-reduce (>= 5 ms at the
+    # ~150 GB/s of one xGMI link per ring hop) and the 20 B/parameter update (0.64 ms): above ~1536 gathered rows the layer's
+    # gradient is formed densely instead.  ICLTrainer sets `world`.
+    world = 1
+    max_rows_gathered = 1536
 
     def __init__(self, on: bool = True):
         self.on = on
@@ -1106,7 +1113,9 @@ class _LinearFactored(torch.autograd.Function):
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], owner=None) -> torch.Tensor:
     """F.linear.  ``owner``: the module whose ``.weight`` this is — lets the gradient stay factored (see FactoredGrads)."""
     if (owner is not None and FactoredGrads.enabled and weight.requires_grad and weight.numel() >= FactoredGrads.min_elems
-            and x.numel() // x.shape[-1] <= FactoredGrads.max_rows and weight.shape[1] % 4 == 0 and torch.is_grad_enabled()):
+            and x.numel() // x.shape[-1] <= FactoredGrads.max_rows
+            and (x.numel() // x.shape[-1]) * FactoredGrads.world <= FactoredGrads.max_rows_gathered
+            and weight.shape[1] % 4 == 0 and torch.is_grad_enabled()):
         return _LinearFactored.apply(x, weight, bias, owner)
     return _Linear.apply(x, weight, bias, owner)
 

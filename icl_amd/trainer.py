@@ -78,6 +78,7 @@ class ICLTrainer:
         BatchNormAct.defer_counters()
         ops.DeferredBiasGrads.begin()
         try:
+            ops.FactoredGrads.world = self.ddp.world if (self.ddp is not None and self.ddp.active) else 1
             with ops.FactoredGrads(cfg.factored_mlp2_grads):
                 outputs = self.model(volume_batch[:cfg.labeled_bs], volume_batch[cfg.labeled_bs:])
                 loss, parts = self.compute_loss(outputs, label_batch)
