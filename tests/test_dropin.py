@@ -27,6 +27,7 @@ def test_compat_root_resolves_every_import_of_the_reference_trainers():
         "from networks.net_factory import net_factory\n"
         "from utils import losses, ramps\n"
         "from val_3D import test_all_case_base, test_all_case_amos\n"
+        "from val_2D import test_single_volume_ours\n"
         "from dataloaders.brats2019 import (BraTS2019, RandomCrop, RandomRotFlip, ToTensor, TwoStreamBatchSampler)\n"
         "import networks.net_factory_3d as f, icl_amd.networks.net_factory_3d as g\n"
         "assert f.net_factory_3d is g.net_factory_3d and losses.DiceLoss.__module__ == 'icl_amd.utils.losses'\n"
@@ -179,3 +180,37 @@ def test_monai_style_sliding_window_grid_and_averaging():
     lab = (vol > 0.5).long()                        # the loader yields [1, 1, D, H, W]
     m = test_all_case_amos(Net(), "unet_3D_icl", [{"image": vol, "label": lab}], num_classes=3)
     assert m[0][0][0] == 1.0 and m[1][0] == (1, 0)         # class 1 perfect, class 2 empty in both (the reference's (1, 0) convention)
+
+
+def test_2d_slice_validation_batches_slices_without_changing_the_procedure():
+    """val_2D.test_single_volume_ours: several slices per forward == the reference's slice-by-slice loop (zoom order 0 in, arg-max,
+    zoom order 0 back), and the empty-mask metric conventions."""
+    from scipy.ndimage import zoom
+    from icl_amd.val_2D import calculate_metric_percase, test_single_volume_ours
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.calls = []
+
+        def forward(self, x, inference=False):
+            self.calls.append((x.shape[0], inference))
+            return torch.cat([0.3 - x, x - 0.3, (x - 0.7) * 3], 1)      # 3 classes from the intensity
+
+    g = torch.Generator().manual_seed(3)
+    image = torch.rand(1, 7, 20, 26, generator=g)
+    label = (image[0] > 0.3).long() + (image[0] > 0.9).long()
+    net = Net()
+    got = test_single_volume_ours(image, label.unsqueeze(0), net, None, 0, classes=3, patch_size=[32, 24], slices_per_batch=4)
+    assert net.calls == [(4, True), (3, True)]
+    pred = np.zeros((7, 20, 26), dtype=np.int64)
+    for i in range(7):                                      # the reference loop (val_2D.py:38-50), one slice per forward
+        sl = zoom(image[0, i].numpy(), (32 / 20, 24 / 26), order=0)
+        out = torch.argmax(torch.softmax(net(torch.from_numpy(sl)[None, None].float(), inference=True), 1), 1)[0].numpy()
+        pred[i] = zoom(out, (20 / 32, 26 / 24), order=0)
+    want = [calculate_metric_percase(pred == c, label.numpy() == c) for c in (1, 2)]
+    assert got == want and 0 < got[0][0] <= 1
+    z = np.zeros((4, 4), bool)
+    o = z.copy(); o[1, 1] = True
+    assert calculate_metric_percase(z, z) == (1, 0) and calculate_metric_percase(o, z) == (0, 373.128664) == calculate_metric_percase(z, o)
