@@ -725,3 +725,67 @@ def test_aligner_side_stream_equals_single_stream(dev):
         for k, pairs in base[2].items():
             for (g0, x0), (g1, x1) in zip(pairs, facs[k]):
                 assert rel_err(g1.cpu(), g0.cpu()) < 2e-4 and rel_err(x1.cpu(), x0.cpu()) < 2e-4, k
+
+
+@pytest.mark.parametrize("rows,i,o,act", [
+    (16, 13824, 13824, 0),   # Class_Decoder.mlp2 at the finest scale: weight streaming, 9 slices
+    (8, 13824, 13824, 1),    # uscl (half row tile), GELU in the slab-sum epilogue
+    (24, 1728, 1728, 0),     # two row tiles (SwinUNETR aligner heads), mid-size plan
+    (4, 256, 1024, 1),       # aligner MLP.fc1: single slice, direct epilogue
+    (5, 72, 40, 0),          # ragged small
+    (27648, 64, 128, 0),     # fc_kv: tall, tiled product
+    (432, 6912, 256, 0),     # center.conv2 through im2col: split-K
+    (128, 13824, 1728, 0),   # 128-row products (nc = 16 class)
+    (3000, 48, 144, 1),      # 48-column wave tiles (Swin qkv), K tail
+    (1000, 37, 50, 0),       # nothing aligned: element-wise staging path
+])
+def test_linear_products_match_fp64(dev, rows, i, o, act):
+    """csrc/kernels/gemm.h on the GPU: forward, input gradient and (short inputs) weight gradient against an fp64 product."""
+    from icl_amd import ops
+    x, w, b = _rand((rows, i), 21), _rand((o, i), 22) * (1.0 / np.sqrt(i)), _rand((o,), 23)
+    g = _rand((rows, o), 24)
+    xd, wd, bd, gd = (t.to(dev) for t in (x, w, b, g))
+    y = ops.linear_forward_raw(xd, wd, bd, act)
+    ref = x.double() @ w.double().t() + b.double()
+    if act:
+        ref = F.gelu(ref)
+    assert rel_err(y.cpu(), ref) < 2e-5
+    assert rel_err(ops.linear_dgrad_raw(gd, wd).cpu(), g.double() @ w.double()) < 2e-5
+    if rows <= 3000:
+        dw, _ = ops._tall_atb(gd, xd, False)
+        assert rel_err(dw.cpu(), g.double().t() @ x.double()) < 2e-5
+
+
+def test_gemm_layouts_batch_and_final_conv_class(dev):
+    """Operand layouts of icl_gemm (transposed views consumed in place), batch sum, the k2s2 transposed convolution built on it and
+    the voxel-streaming 1x1x1 convolution of the `final` layer class, against torch on the CPU."""
+    from icl_amd import ops
+    for ak in (True, False):
+        for bk in (True, False):
+            m, n, k = 200, 136, 100
+            a = _rand((m, k), 31) if ak else _rand((k, m), 31)
+            b = _rand((n, k), 32) if bk else _rand((k, n), 32)
+            out = ops.gemm(a.to(dev), b.to(dev), m, n, k, a.shape[1], b.shape[1], ak, bk)
+            ref = (a if ak else a.t()).double() @ (b.t() if bk else b).double()
+            assert rel_err(out.cpu(), ref) < 2e-5, (ak, bk)
+    x = _rand((2, 96, 6, 6, 6), 33).to(dev).requires_grad_()
+    w = (_rand((96, 48, 2, 2, 2), 34) * 0.1).to(dev).requires_grad_()
+    y = ops.conv_transpose3d_k2s2(x, w)
+    gy = _rand(tuple(y.shape), 35).to(dev)
+    gx, gw = torch.autograd.grad(y, (x, w), gy)
+    xr, wr = x.detach().cpu().requires_grad_(), w.detach().cpu().requires_grad_()
+    yr = F.conv_transpose3d(xr, wr, stride=2)
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy.cpu())
+    assert rel_err(y.detach().cpu(), yr.detach()) < 2e-5 and rel_err(gx.cpu(), gxr) < 2e-5 and rel_err(gw.cpu(), gwr) < 2e-5
+    for cin, cout in ((16, 2), (16, 16), (5, 3), (40, 24)):      # <= 16 channels: conv1x1_stream_kernel; more: batched product
+        xc = _rand((2, cin, 48, 48, 48), 36).to(dev).requires_grad_()
+        wc = (_rand((cout, cin, 1, 1, 1), 37) * 0.3).to(dev).requires_grad_()
+        bc = _rand((cout,), 38).to(dev).requires_grad_()
+        yc = ops.conv3d(xc, wc, bc)
+        gyc = _rand(tuple(yc.shape), 39).to(dev)
+        gxc, gwc, gbc = torch.autograd.grad(yc, (xc, wc, bc), gyc)
+        xr, wr, br = (t.detach().cpu().requires_grad_() for t in (xc, wc, bc))
+        yr = F.conv3d(xr, wr, br)
+        gxr, gwr, gbr = torch.autograd.grad(yr, (xr, wr, br), gyc.cpu())
+        assert rel_err(yc.detach().cpu(), yr.detach()) < 2e-5 and rel_err(gxc.cpu(), gxr) < 2e-5, (cin, cout)
+        assert rel_err(gwc.cpu(), gwr) < 1e-4 and rel_err(gbc.cpu(), gbr) < 1e-4, (cin, cout)
