@@ -30,7 +30,7 @@ class GradientReducer:
     two graph replays with only the collectives issued eagerly in between."""
 
     def __init__(self, model: torch.nn.Module, world_size: int, bucket_bytes: int = 256 << 20, overlap_min_elems: int = 1 << 22,
-                 force: bool = False):
+                 force: bool = False, shard_min_rows: int = None):
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         self.world = world_size
         self.bucket_elems = max(1, bucket_bytes // 4)
@@ -43,6 +43,17 @@ class GradientReducer:
         self._fac = []           # [(param, G_all, X_all)]
         self._avg = dist.is_initialized() and dist.get_backend() == "nccl"   # RCCL averages in the collective
         self._send = self._recv = None   # all factor rows of a step, packed / gathered
+        # Crossover of the factored exchange: every rank applies the rank-(rows x W) update of a matrix, which is MFMA-bound beyond a
+        # few hundred gathered rows (13,824^2: 0.8 ms at 128, 2.1 at 512, 4.0 at 1024; tools/sgd_probe.py).  From `shard_min_rows`
+        # gathered rows on, rank r updates only rows [r N/W, (r+1) N/W) of the matrix (1/W of the product and of the p / m stream)
+        # and `post_update()` all-gathers the updated rows in place (764 MB per 13,824^2 matrix over xGMI).  Which side wins depends
+        # on the all-gather rate RCCL reaches on the node (2.2 ms per matrix at 300 GB/s per rank -> crossover ~600 rows; 1 TB/s ->
+        # ~100; one 153 GB/s link -> ~1300): default 768, ICL_DDP_SHARD_ROWS to tune on hardware, 0 = never.
+        if shard_min_rows is None:
+            import os
+            shard_min_rows = int(os.environ.get("ICL_DDP_SHARD_ROWS", "768"))
+        self.shard_min_rows = shard_min_rows
+        self._sharded = []       # parameters whose update of this step is row-sharded
 
     @property
     def active(self) -> bool:
@@ -147,8 +158,24 @@ class GradientReducer:
                 n = p.grad.numel()
                 p.grad = flat[off:off + n].view_as(p)
                 off += n
+        self._sharded = []
         for p, G, X in self._fac:
             p._icl_factors = [(G, X)]
+            shard = (self.world > 1 and self.shard_min_rows > 0 and G.shape[0] >= self.shard_min_rows and p.shape[0] % self.world == 0
+                     and p.is_contiguous())
+            p._icl_shard = (dist.get_rank(), self.world) if shard else None
+            if shard:
+                self._sharded.append(p)
+
+    def post_update(self):
+        """After the optimiser: the ranks exchange the rows of the matrices they updated row-sharded (in place, no staging copy)."""
+        for p in self._sharded:
+            rows = p.shape[0] // self.world
+            r = dist.get_rank()
+            if self._avg:      # RCCL: in-place all-gather, this rank's rows are already where they belong
+                dist.all_gather_into_tensor(p.data.view(-1), p.data[r * rows:(r + 1) * rows].reshape(-1))
+            else:
+                dist.all_gather([p.data[i * rows:(i + 1) * rows] for i in range(self.world)], p.data[r * rows:(r + 1) * rows].clone())
 
     def reduce_gradients(self):
         """Call after ``loss.backward()``: averages every gradient over the ranks (parameters whose grad is None are skipped)."""

@@ -47,10 +47,19 @@ class FusedSGD(torch.optim.Optimizer):
         m = st["momentum_buffer"]
         stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream) if p.is_cuda else None
         lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
+        pv, mv = p, m
+        shard = getattr(p, "_icl_shard", None)
+        if shard is not None:
+            # data-parallel crossover (ddp.GradientReducer): this rank updates only its block of rows from the gathered factors —
+            # 1/W of the MFMA-bound rank-(M W) product — and the ranks all-gather the updated rows afterwards (post_update)
+            rank, world = shard
+            r0, r1 = rank * (n // world), (rank + 1) * (n // world)
+            pv, mv, g = p[r0:r1], m[r0:r1], g[:, r0:r1]
+            n = r1 - r0
         g, x = g.contiguous(), x.contiguous()
         from . import ops   # KernelTimer bracket: the update streams p and m in and out (16 B per weight), HBM-bound
         with ops._timed("sgd_factored_kernel", 2.0 * g.shape[0] * n * k, 16.0 * n * k, p):
-            _lib.check(L.icl_sgd_step_factored(p.data_ptr(), m.data_ptr(), g.data_ptr(), x.data_ptr(), g.shape[0], n, k, lr, mom, wd,
+            _lib.check(L.icl_sgd_step_factored(pv.data_ptr(), mv.data_ptr(), g.data_ptr(), x.data_ptr(), g.shape[0], n, k, lr, mom, wd,
                                                first, lrp, stream), "sgd_step_factored")
 
     @torch.no_grad()

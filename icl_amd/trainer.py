@@ -100,6 +100,8 @@ class ICLTrainer:
         if self.ddp is not None:
             self.ddp.reduce_gradients()
         self._apply_update()
+        if self.ddp is not None:
+            self.ddp.post_update()        # row-sharded matrix updates: all-gather the updated rows
         return parts
 
     def _advance_lr(self):
@@ -127,6 +129,7 @@ class ICLTrainer:
             if self.graph_update is not None:    # data-parallel: collectives between the two graphs
                 self.ddp.communicate()
                 self.graph_update.replay()
+                self.ddp.post_update()
             parts = self.static_out
         else:
             parts = self._step_body(volume_batch, label_batch)

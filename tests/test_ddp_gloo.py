@@ -86,33 +86,41 @@ def _worker_factored(rank, world, port, tmp):
     from icl_amd.optim import FusedSGD
     _lib._use_library_for_tests(build_emu(), host_pointers=True)
     ops.FactoredGrads.min_elems = 1000
-    torch.manual_seed(3)
-    lin = Linear(64, 48)
-    red = GradientReducer(lin, world)
-    red.broadcast_parameters()
-    w0, b0 = lin.weight.detach().clone(), lin.bias.detach().clone()
-    torch.manual_seed(11)
-    data = torch.randn(world, 6, 64)
-    opt = FusedSGD(lin.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
-    opt.zero_grad()
-    with ops.FactoredGrads(True):
-        lin(data[rank]).pow(2).mean().backward()
-    assert lin.weight.grad is None and lin.weight._icl_factors
-    red.reduce_gradients()
-    assert lin.weight._icl_factors[0][0].shape[0] == 6 * world
-    opt.step()
-    # reference: dense gradients of every shard on one process, averaged, torch SGD
-    rw, rb = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
-    gw, gb = torch.zeros_like(rw), torch.zeros_like(rb)
-    for r in range(world):
-        rw.grad = rb.grad = None
-        torch.nn.functional.linear(data[r], rw, rb).pow(2).mean().backward()
-        gw += rw.grad / world
-        gb += rb.grad / world
-    rw.grad, rb.grad = gw, gb
-    torch.optim.SGD([rw, rb], lr=0.1, momentum=0.9, weight_decay=1e-2).step()
-    assert torch.allclose(lin.weight.detach(), rw.detach(), rtol=1e-5, atol=1e-6)
-    assert torch.allclose(lin.bias.detach(), rb.detach(), rtol=1e-5, atol=1e-6)
+    # two passes: every rank applies the whole gathered update / the crossover form (each rank updates its rows, then the ranks
+    # all-gather the updated rows: GradientReducer.post_update)
+    for shard_rows in (0, 1):
+        torch.manual_seed(3)
+        lin = Linear(64, 48)
+        red = GradientReducer(lin, world, shard_min_rows=shard_rows)
+        red.broadcast_parameters()
+        w0, b0 = lin.weight.detach().clone(), lin.bias.detach().clone()
+        torch.manual_seed(11)
+        data = torch.randn(world, 6, 64)
+        opt = FusedSGD(lin.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+        want_w, want_b = w0, b0
+        rw, rb = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
+        ref_opt = torch.optim.SGD([rw, rb], lr=0.1, momentum=0.9, weight_decay=1e-2)
+        for step in range(2):            # second step: momentum buffers of the (sharded) rows carry over
+            opt.zero_grad()
+            with ops.FactoredGrads(True):
+                lin(data[rank] + step).pow(2).mean().backward()
+            assert lin.weight.grad is None and lin.weight._icl_factors
+            red.reduce_gradients()
+            assert lin.weight._icl_factors[0][0].shape[0] == 6 * world
+            assert (lin.weight._icl_shard is not None) == bool(shard_rows)
+            opt.step()
+            red.post_update()
+            # reference: dense gradients of every shard on one process, averaged, torch SGD
+            gw, gb = torch.zeros_like(rw), torch.zeros_like(rb)
+            for r in range(world):
+                rw.grad = rb.grad = None
+                torch.nn.functional.linear(data[r] + step, rw, rb).pow(2).mean().backward()
+                gw += rw.grad / world
+                gb += rb.grad / world
+            rw.grad, rb.grad = gw, gb
+            ref_opt.step()
+            assert torch.allclose(lin.weight.detach(), rw.detach(), rtol=1e-5, atol=1e-6), (shard_rows, step)
+            assert torch.allclose(lin.bias.detach(), rb.detach(), rtol=1e-5, atol=1e-6)
     dist.destroy_process_group()
 
 
