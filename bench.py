@@ -254,8 +254,15 @@ def main():
                                                   "frac": round(v[3] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                                   "note": "launch = streaming kernel + slab sum; bytes = weight matrix"}
                                               for k, v in sorted(st.items())}
+            fu = summ.get("linear_dgrad_sgd_kernel")
+            if fu:   # single rank: input gradient + SGD step of the four 13,824^2 matrices, one pass over p and m (16 B per weight)
+                gbs = fu[3] / (fu[1] * 1e-3) / 1e9
+                roof["mlp2_dgrad_sgd_one_pass"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                   "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": fu[0] // 3,
+                                                   "avg_launch_us": round(fu[1] * 1e3 / fu[0], 2),
+                                                   "algorithmic_bytes_per_launch": int(fu[3] / fu[0])}
             sg = summ.get("sgd_factored_kernel")
-            if sg:   # the largest single kernel of the U-Net step by time: the factored SGD update of the four 13,824^2 matrices
+            if sg:   # the factored SGD update of the token-axis matrices that are not updated inside their backward (1,728^2; all, multi-rank)
                 gbs = sg[3] / (sg[1] * 1e-3) / 1e9
                 roof["sgd_factored_update"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": sg[0] // 3,

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "icl_linear_fwd": (c_int, [P, P, P, P, P, L, I, I, I, P]),
     "icl_linear_dgrad": (c_int, [P, P, P, P, L, I, I, P]),
     "icl_linear_wgrad_small": (c_int, [P, P, P, P, L, I, I, P]),
+    "icl_linear_dgrad_sgd": (c_int, [P, P, P, P, P, P, L, I, I, F, F, F, I, P, P]),
     "icl_gemm_ws_bytes": (c_int64, [L, I, I, I]),
     "icl_gemm": (c_int, [P, P, P, P, P, L, I, I, L, L, L, I, I, I, I, L, L, L, P]),
     "icl_linear_wgrad_ws_bytes": (c_int64, [L, I, I]),
@@ -78,7 +79,8 @@ _SIGNATURES = {
     "icl_window_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, F, P]),
     "icl_window_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
     "icl_layernorm_fwd": (c_int, [P, P, P, P, P, P, L, I, F, P]),
-    "icl_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, L, I, P]),
+    "icl_layernorm_bwd_ws_bytes": (c_int64, [L, I]),
+    "icl_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, L, I, P]),
     "icl_gelu_fwd": (c_int, [P, P, L, P]),
     "icl_gelu_bwd": (c_int, [P, P, P, L, P]),
     "icl_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, F, P]),

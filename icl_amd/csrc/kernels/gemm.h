@@ -182,6 +182,159 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------ input gradient + SGD update, one pass
+// The backward of a big skinny Linear and its optimiser step read the same 764 MB matrix twice (gx = gy W, then p / m in and
+// out of the update).  On one rank the factors of dW = gy^T x are complete the moment the layer's backward runs, so this kernel
+// does both while the weight tile is on chip: every 16 x 64 tile of p (and m) is loaded once, its contribution to gx is
+// accumulated from the OLD values (slab[s], summed by gemm_reduce_slabs_kernel as in linear_stream_kernel), then
+//     d = gy^T x (MFMA, 16 factor rows per step) + wd * p;   m = first ? d : momentum * m + d;   p -= lr * m
+// (torch.optim.SGD, optim.h) is applied to the tile and p / m go back with non-temporal stores: 16 B per weight of HBM traffic for
+// the layer's backward + update instead of 20.  Same grid / slices / units as linear_stream_kernel<MT, true>; x is [M][K] (the
+// layer input), gy [M][O]; each weight element belongs to exactly one wave.  Only legal when the weight is used once per step.
+template <int MT, int P>
+__global__ __launch_bounds__(512) void linear_dgrad_sgd_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ w,
+                                                               float* __restrict__ mom, float* __restrict__ slab, int M, int K, int O,
+                                                               int slice_len, int upw, float lr, float momentum, float wd, int first,
+                                                               const float* __restrict__ lr_dev) {
+  ICL_DYN_LDS(float, lds);
+  float* xl = lds;                                        // gy slice [16 MT][slice_len], quad q of row m stored at quad q ^ (m & 15)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, u = lane & 15, lg = lane >> 4;
+  float* wl = lds + 16 * MT * slice_len + wid * 1024;     // this wave's 16 x 64 tile buffer
+  if (lr_dev) lr = *lr_dev;
+  const int c0 = blockIdx.y * slice_len;
+  const int clen = c0 + slice_len < O ? slice_len : O - c0;
+  const int tpu = (clen + 15) / 16;
+  const int nunits = (K + 63) / 64;
+  const int unit0 = (blockIdx.x * 8 + wid) * upw;
+  int my_units = nunits - unit0;
+  if (my_units > upw) my_units = upw;
+  const int total = my_units > 0 ? my_units * tpu : 0;
+
+  float4 ring[P][4], mring[P][4];
+  int l_unit = unit0, l_t = 0;
+  auto issue = [&](int p, bool live) {
+    const int row0 = c0 + 16 * l_t, col = 64 * l_unit + 4 * u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = row0 + 4 * j + lg;
+      const bool ok = live && row < c0 + clen && col < K;
+      const long off = ok ? (long)row * K + col : 0L;
+      ring[p][j] = icl_nt_load4(w + off);
+      mring[p][j] = first ? make_float4(0.f, 0.f, 0.f, 0.f) : icl_nt_load4(mom + off);
+    }
+    if (++l_t == tpu) { l_t = 0; ++l_unit; }
+  };
+#pragma unroll
+  for (int p = 0; p < P; ++p) issue(p, p < total);
+
+  const int qpr = slice_len >> 2;
+  for (int it = tid; it < 16 * MT * qpr; it += 512) {
+    const int m = it / qpr, q = it % qpr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M && 4 * q < clen) v = *reinterpret_cast<const float4*>(gy + (long)m * O + c0 + 4 * q);
+    *reinterpret_cast<float4*>(xl + m * slice_len + 4 * (q ^ (m & 15))) = v;
+  }
+  __syncthreads();
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[t][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int c_unit = unit0, c_t = 0;
+  float* out = slab + (long)blockIdx.y * 16 * MT * K;
+  // x rows of the current 64-column strip as MFMA B operands of d = gy^T x: xq[s][c] = x[4 s + lg][64 unit + 16 c + u]
+  float xq[4 * MT][4];
+  auto load_x = [&](int unit) {
+#pragma unroll
+    for (int s = 0; s < 4 * MT; ++s)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int m = 4 * s + lg, col = 64 * unit + 16 * c + u;
+        xq[s][c] = (m < M && col < K) ? x[(long)m * K + col] : 0.f;
+      }
+  };
+  if (total > 0) load_x(c_unit);
+
+  for (int base = 0; base < total; base += P) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (base + p >= total) break;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(wl + (4 * j + lg) * 64 + 4 * u) = ring[p][j];
+      ICL_WAVE_SYNC();
+      // gx += gy[:, rows of the tile] * W_old[tile]
+      {
+        float4 b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = *reinterpret_cast<const float4*>(wl + (4 * lg + e) * 64 + 4 * u);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const float4 a = *reinterpret_cast<const float4*>(xl + (16 * t + u) * slice_len + 4 * ((4 * c_t + lg) ^ u));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float av = f4c(a, e);
+            acc[t][0] = icl_mfma_16x16x4(av, b[e].x, acc[t][0]);
+            acc[t][1] = icl_mfma_16x16x4(av, b[e].y, acc[t][1]);
+            acc[t][2] = icl_mfma_16x16x4(av, b[e].z, acc[t][2]);
+            acc[t][3] = icl_mfma_16x16x4(av, b[e].w, acc[t][3]);
+          }
+        }
+      }
+      // d tile = gy^T x: A[o = u][factor row 4 s + lg] from the resident gy slice, B = xq; D[o = 4 lg + q][col 16 c + u]
+      f32x4 dacc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4 * MT; ++s) {
+        const int m = 4 * s + lg;
+        const float av = xl[m * slice_len + 4 * ((4 * c_t + (u >> 2)) ^ (m & 15)) + (u & 3)];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dacc[c] = icl_mfma_16x16x4(av, xq[s][c], dacc[c]);
+      }
+      ICL_WAVE_SYNC();                                     // every lane has read its W fragments: the tile buffer is free
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wl[(4 * lg + q) * 64 + 16 * c + u] = dacc[c][q];
+      ICL_WAVE_SYNC();
+      {
+        const int row0 = c0 + 16 * c_t, col = 64 * c_unit + 4 * u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = row0 + 4 * j + lg;
+          if (row < c0 + clen && col < K) {
+            const float4 d = *reinterpret_cast<const float4*>(wl + (4 * j + lg) * 64 + 4 * u);
+            float4 pv = ring[p][j], mv = mring[p][j];
+            sgd_update4(pv, d, mv, lr, momentum, wd, first);
+            const long off = (long)row * K + col;
+            icl_nt_store4(w + off, pv);
+            icl_nt_store4(mom + off, mv);
+          }
+        }
+      }
+      ICL_WAVE_SYNC();                                     // the d tile has been read: the next tile may overwrite the buffer
+      issue(p, base + p + P < total);
+      if (++c_t == tpu) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int m = 16 * t + 4 * lg + q, col = 64 * c_unit + 4 * u;
+            if (col < K) *reinterpret_cast<float4*>(out + (long)m * K + col) = make_float4(acc[t][0][q], acc[t][1][q], acc[t][2][q], acc[t][3][q]);
+          }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        c_t = 0;
+        ++c_unit;
+        if (base + p + 1 < total) load_x(c_unit);
+      }
+    }
+  }
+}
+
 // out[m][n] = act(bias[n] + sum_s slab[s][m][n]) for m < M: fixed-order sum of split partials (bitwise reproducible).
 // slab rows have pitch `spitch` and slabs are `sstride` floats apart; out rows have pitch ldo.  N % 4 == 0.
 __global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, const float* __restrict__ bias,

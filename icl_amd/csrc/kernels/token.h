@@ -39,14 +39,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 template <bool BLOCKROW>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ gx, long rows, int C,
-                                                            float* __restrict__ zero0, float* __restrict__ zero1) {
+                                                            const float* __restrict__ rstd, float* __restrict__ gx, long rows, int C) {
   __shared__ float red[4];
-  // block 0 also clears the dgamma / dbeta accumulators of the layernorm_wgrad launch that follows on the same stream
-  // (saves a memset launch per LayerNorm backward; the step has dozens of them on tiny token tensors)
-  if (blockIdx.x == 0 && zero0) {
-    for (int c = threadIdx.x; c < C; c += 256) { zero0[c] = 0.f; zero1[c] = 0.f; }
-  }
   const int lane = BLOCKROW ? threadIdx.x : (threadIdx.x & 63);
   const int stride = BLOCKROW ? 256 : 64;
   const long r = BLOCKROW ? (long)blockIdx.x : (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -66,11 +60,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int c = lane; c < C; c += stride) o[c] = rs * ((gamma ? gr[c] * gamma[c] : gr[c]) - s1 - (xr[c] - m) * rs * s2);
 }
 
-// dgamma[c] += sum_rows gy*xhat, dbeta[c] += sum_rows gy  (pre-zeroed).  A workgroup covers `cols` = min(C,256)
-// columns x (256/cols) row lanes so that short rows still read full 256-byte lines; grid (ceil(C/cols), row chunks).
+// Partial sums of dgamma[c] = sum_rows gy*xhat and dbeta[c] = sum_rows gy: row chunk j (blockIdx.y) writes part_g[j][c] and
+// part_b[j][c]; colsum_multi_kernel adds the chunks in a fixed order (no float atomics: the step is bit-reproducible).  A workgroup
+// covers `cols` = min(C,256) columns x (256/cols) row lanes so that short rows still read full 256-byte lines; grid (ceil(C/cols), chunks).
 __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C,
+                                                              float* __restrict__ part_g, float* __restrict__ part_b, long rows, int C,
                                                               long rows_per_block, int cols) {
   const int lanes = 256 / cols;
   const int tc = threadIdx.x % cols;
@@ -105,7 +100,7 @@ __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __res
       b += g;
     }
   }
-  // one atomic per column and workgroup: fold the row lanes through LDS first
+  // one partial per column and workgroup: fold the row lanes through LDS first
   __shared__ float sa[256], sb[256];
   sa[threadIdx.x] = a;
   sb[threadIdx.x] = b;
@@ -115,8 +110,8 @@ __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __res
     a += sa[l * cols + tc];
     b += sb[l * cols + tc];
   }
-  atomicAdd(dgamma + c, a);
-  atomicAdd(dbeta + c, b);
+  part_g[(long)blockIdx.y * C + c] = a;
+  part_b[(long)blockIdx.y * C + c] = b;
 }
 
 // ---------------------------------------------------------------- GELU (exact erf form, nn.GELU default)

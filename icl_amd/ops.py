@@ -863,8 +863,8 @@ def drop_path(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Te
 
 # --------------------------------------------------------------------------------------
 # Aligner token ops (unet_3D_icl.py:244-315): LayerNorm, GELU and the prototype attention are HIP kernels
-# (csrc/kernels/token.h); the Linear layers (incl. the 13,824^2 mlp2) are plain library GEMMs on rocBLAS, which
-# measure 5.8 TB/s on the weight stream of the skinny mlp2 products (profiles/) — already at the HBM roofline.
+# (csrc/kernels/token.h); the Linear layers (incl. the 13,824^2 mlp2) run on csrc/kernels/gemm.h — the skinny mlp2 products
+# stream the weight matrix once per launch (5.4-5.8 TB/s, profiles/), the others use the LDS-tiled fp32 MFMA product.
 # --------------------------------------------------------------------------------------
 
 LINEAR_WGRAD_MIN_ROWS = 2048
@@ -1070,6 +1070,12 @@ class FactoredGrads:
     # gradient is formed densely instead.  ICLTrainer sets `world`.
     world = 1
     max_rows_gathered = 1536
+    # Single rank: the factors of a layer are complete when its backward runs, so the optimiser step of a weight that is used ONCE
+    # per step can ride on the pass that computes the input gradient (csrc/kernels/gemm.h linear_dgrad_sgd_kernel: the 764 MB
+    # matrix is read once for gx AND the update instead of twice).  ICLTrainer sets `fused_optimizer` (its FusedSGD) and resets the
+    # use counts at the start of each step; None = the update stays in FusedSGD.step().
+    fused_optimizer = None
+    uses = None
 
     def __init__(self, on: bool = True):
         self.on = on
@@ -1092,6 +1098,8 @@ class _LinearFactored(torch.autograd.Function):
         ctx.owner = owner
         ctx.has_bias = bias is not None
         ctx.x_shape = x.shape
+        if FactoredGrads.uses is not None:
+            FactoredGrads.uses[id(owner.weight)] = FactoredGrads.uses.get(id(owner.weight), 0) + 1
         return linear_forward_raw(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
@@ -1099,11 +1107,16 @@ class _LinearFactored(torch.autograd.Function):
         x2, weight = ctx.saved_tensors
         o, i = weight.shape
         g2 = gy.reshape(-1, o).contiguous()
-        gx = linear_dgrad_raw(g2, weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        param = ctx.owner.weight
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2] and not DeferredBiasGrads.defer(getattr(ctx.owner, "bias", None), g2):
             gb = g2.sum(0)
-        param = ctx.owner.weight
+        opt = FactoredGrads.fused_optimizer
+        if (opt is not None and ctx.needs_input_grad[0] and FactoredGrads.uses is not None and FactoredGrads.uses.get(id(param)) == 1
+                and weight.data_ptr() == param.data_ptr() and opt.can_update_in_backward(param, g2.shape[0])):
+            # input gradient from the old weight and the SGD step of the weight, one pass over the matrix
+            return opt.update_in_backward(param, g2, x2).view(ctx.x_shape), None, gb, None
+        gx = linear_dgrad_raw(g2, weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         if getattr(param, "_icl_factors", None) is None:
             param._icl_factors = []
         param._icl_factors.append((g2, x2))
@@ -1134,6 +1147,8 @@ class _LayerNorm(torch.autograd.Function):
         _lib.check(L.icl_layernorm_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(mean), _ptr(rstd), rows, c, eps, _stream(x)),
                    "layernorm_fwd")
         ctx.save_for_backward(x, weight, mean, rstd)
+        both = isinstance(weight, torch.nn.Parameter) and isinstance(bias, torch.nn.Parameter)
+        ctx.params = (weight, bias) if both and weight.requires_grad and bias.requires_grad else None
         return y
 
     @staticmethod
@@ -1144,12 +1159,22 @@ class _LayerNorm(torch.autograd.Function):
         c = x.shape[-1]
         rows = x.numel() // c
         gx = torch.empty_like(x)
-        dg = db = None       # no-affine: F.layer_norm(x, [C]) (swinunetr_icl.py:1214)
+        dg = db = ws = None       # no-affine: F.layer_norm(x, [C]) (swinunetr_icl.py:1214)
+        defer = False
         if weight is not None:
-            dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)   # [dgamma | dbeta] contiguous: zeroed by one memset
-            dg, db = dgb[0], dgb[1]
-        _lib.check(L.icl_layernorm_bwd(_ptr(gy), _ptr(x), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dg), _ptr(db), rows, c,
+            ws = _ws(L.icl_layernorm_bwd_ws_bytes(rows, c), x)
+            # inside ICLTrainer's step the chunk partials of all LayerNorm layers are summed by ONE launch at the end of backward
+            # (DeferredBiasGrads.flush); elsewhere on the spot.  Either way in a fixed order: no float atomics.
+            defer = DeferredBiasGrads.pending is not None and ctx.params is not None
+            if not defer:
+                dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+                dg, db = dgb[0], dgb[1]
+        _lib.check(L.icl_layernorm_bwd(_ptr(gy), _ptr(x), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dg), _ptr(db), _ptr(ws), rows, c,
                                        _stream(x)), "layernorm_bwd")
+        if defer:
+            part = ws[:(ws.numel() // (2 * c)) * 2 * c].view(2, -1, c)
+            DeferredBiasGrads.pending.append((ctx.params[0], part[0]))
+            DeferredBiasGrads.pending.append((ctx.params[1], part[1]))
         return gx, dg, db, None
 
 

@@ -22,6 +22,7 @@ class FusedSGD(torch.optim.Optimizer):
             raise ValueError("FusedSGD implements the momentum form used by the ICL trainers")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.lr_dev = None   # optional device scalar read by the kernels instead of group['lr'] (hipGraph replay)
+        self._groups = None  # id(parameter) -> its group (update_in_backward)
 
     def zero_grad(self, set_to_none: bool = True):
         for group in self.param_groups:
@@ -61,6 +62,44 @@ class FusedSGD(torch.optim.Optimizer):
         with ops._timed("sgd_factored_kernel", 2.0 * g.shape[0] * n * k, 16.0 * n * k, p):
             _lib.check(L.icl_sgd_step_factored(pv.data_ptr(), mv.data_ptr(), g.data_ptr(), x.data_ptr(), g.shape[0], n, k, lr, mom, wd,
                                                first, lrp, stream), "sgd_step_factored")
+
+    def can_update_in_backward(self, p, rows: int) -> bool:
+        n, k = p.shape
+        # 13,824^2: 0.55 ms for both against 0.13 + 0.54 apart; 1,728^2 matrices are launch-shaped (74 us against 41): left to step()
+        return (rows <= 32 and n * k >= (1 << 26) and n % 4 == 0 and k % 4 == 0 and p.is_contiguous() and p.dtype == torch.float32
+                and id(p) in self._group_of() and (p.is_cuda or _lib.host_pointers_ok()))
+
+    def _group_of(self):
+        if self._groups is None:
+            self._groups = {id(p): g for g in self.param_groups for p in g["params"]}
+        return self._groups
+
+    @torch.no_grad()
+    def update_in_backward(self, p, g, x):
+        """Called from the backward of a big skinny Linear whose weight is used once per step (ops.FactoredGrads.fused_optimizer):
+        returns gx = g W_old and applies this step's update of W from the factors (g, x) in the same pass over the matrix
+        (icl_linear_dgrad_sgd).  ``step()`` then skips the parameter: it has neither a dense nor a factored gradient."""
+        from . import ops
+        L = _lib.lib()
+        group = self._group_of()[id(p)]
+        lr, mom, wd = float(group["lr"]), float(group["momentum"]), float(group["weight_decay"])
+        n, k = p.shape
+        rows = g.shape[0]
+        st = self.state[p]
+        first = 0
+        if "momentum_buffer" not in st:
+            st["momentum_buffer"] = torch.empty_like(p)
+            first = 1
+        m = st["momentum_buffer"]
+        g, x = g.contiguous(), x.contiguous()
+        gx = torch.empty((rows, k), dtype=torch.float32, device=g.device)
+        ws = ops._ws(L.icl_linear_ws_bytes(rows, k, n, 3), g)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream) if p.is_cuda else None
+        lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
+        with ops._timed("linear_dgrad_sgd_kernel", 4.0 * rows * n * k, 16.0 * n * k, p):
+            _lib.check(L.icl_linear_dgrad_sgd(g.data_ptr(), x.data_ptr(), p.data_ptr(), m.data_ptr(), gx.data_ptr(), ws.data_ptr(), rows, k, n,
+                                              lr, mom, wd, first, lrp, stream), "linear_dgrad_sgd")
+        return gx
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -36,6 +36,7 @@ class ICLConfig:
     w_con: float = 10.0    # 50 in the 2-D trainer (train_inherent_consistent_unet_2D.py:127)
     patch_size: tuple = (96, 96, 96)   # (256, 256) selects the 2-D losses (AuxLoss / PseudoSoftLoss)
     factored_mlp2_grads: bool = True   # keep the 13,824^2 mlp2 weight gradients factored (ops.FactoredGrads)
+    update_in_backward: bool = True    # single rank: SGD step of those matrices inside their backward pass (one read of the matrix)
 
 
 class ICLTrainer:
@@ -79,11 +80,17 @@ class ICLTrainer:
         ops.DeferredBiasGrads.begin()
         try:
             ops.FactoredGrads.world = self.ddp.world if (self.ddp is not None and self.ddp.active) else 1
+            # without gradient exchange the factors of a layer are final when its backward runs: update there (FusedSGD.update_in_backward)
+            fuse = cfg.factored_mlp2_grads and cfg.update_in_backward and not (self.ddp is not None and self.ddp.active)
+            ops.FactoredGrads.fused_optimizer = self.optimizer if fuse else None
+            ops.FactoredGrads.uses = {} if fuse else None
             with ops.FactoredGrads(cfg.factored_mlp2_grads):
                 outputs = self.model(volume_batch[:cfg.labeled_bs], volume_batch[cfg.labeled_bs:])
                 loss, parts = self.compute_loss(outputs, label_batch)
                 loss.backward()
         finally:
+            ops.FactoredGrads.fused_optimizer = None
+            ops.FactoredGrads.uses = None
             BatchNormAct.flush_counters()     # all num_batches_tracked increments of the step in one launch
             ops.DeferredBiasGrads.flush()     # all small-Linear bias gradients of the step in one launch
         parts = {k: v.detach() for k, v in parts.items()}

@@ -133,11 +133,15 @@ int icl_loss_bwd(const float* a, const float* b, const int64_t* labels, const fl
 
 /* ---- aligner token operators (networks/unet_3D_icl.py:244-315)
  * LayerNorm over the last axis c of [rows, c] (nn.LayerNorm, eps 1e-5); mean/rstd [rows] are saved for the backward;
- * dgamma/dbeta (may both be NULL) are overwritten.  GELU is the exact erf form (nn.GELU default). */
+ * dgamma/dbeta (may both be NULL) are overwritten: row-chunk partial sums go to `ws` (icl_layernorm_bwd_ws_bytes) and are added in
+ * a fixed order (no float atomics).  dgamma NULL with ws given: only the partials are written — ws = part_g [chunks][c] followed by
+ * part_b [chunks][c], chunks = ws bytes / (8 c) — and the caller sums them later (icl_colsum_multi; ICLTrainer does that for all
+ * LayerNorm layers of a step in one launch).  GELU is the exact erf form (nn.GELU default). */
 int icl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows,
                       int c, float eps, void* stream);
+int64_t icl_layernorm_bwd_ws_bytes(int64_t rows, int c);
 int icl_layernorm_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* rstd, float* gx,
-                      float* dgamma, float* dbeta, int64_t rows, int c, void* stream);
+                      float* dgamma, float* dbeta, void* ws, int64_t rows, int c, void* stream);
 int icl_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int icl_gelu_bwd(const float* gy, const float* x, float* gx, int64_t n, void* stream);
 /* Prototype cross-attention of Query_Attention.forward (:283-297): q [B,h,nc,d] (reshape-quirk layout of fc_q's output),
@@ -188,12 +192,18 @@ int icl_space_to_depth2(const float* g, float* gt, int n, int d, int h, int w, i
  *   icl_linear_wgrad_small  dw[out, in] = gy^T x for few rows (tall inputs: icl_linear_wgrad above)
  * rows <= 32 with >= 2^20 weights (the 13,824^2 / 1,728^2 mlp2 matrices): the weight matrix is streamed from HBM exactly once
  * (HBM-bound); everything else runs on LDS-staged 64x64 wave tiles, split over K when the output has too few tiles to fill the chip.
- * ws: icl_linear_ws_bytes(rows, in, out, kind) bytes, kind 0 fwd / 1 dgrad / 2 wgrad_small (may be 0; NULL then allowed). */
+ * ws: icl_linear_ws_bytes(rows, in, out, kind) bytes, kind 0 fwd / 1 dgrad / 2 wgrad_small / 3 dgrad_sgd (may be 0; NULL then allowed). */
 int64_t icl_linear_ws_bytes(int64_t rows, int in, int out, int kind);
 int icl_linear_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, int64_t rows, int in, int out, int act,
                    void* stream);
 int icl_linear_dgrad(const float* gy, const float* w, float* gx, void* ws, int64_t rows, int in, int out, void* stream);
 int icl_linear_wgrad_small(const float* gy, const float* x, float* dw, void* ws, int64_t rows, int in, int out, void* stream);
+/* Backward + optimiser step of a big skinny Linear in ONE pass over its weight (single rank, the weight used once per step):
+ * gx[rows, in] = gy[rows, out] W_old, then W / momentum are updated from the factors of dW = gy^T x with the SGD rule of
+ * icl_sgd_step_factored (train_inherent_consistent_unet_3D_BraTS.py:85-86,113-115 on Class_Decoder.mlp2, unet_3D_icl.py:258-268).
+ * rows <= 32, in / out multiples of 4; ws: icl_linear_ws_bytes(rows, in, out, 3) bytes. */
+int icl_linear_dgrad_sgd(const float* gy, const float* x, float* w, float* mom, float* gx, void* ws, int64_t rows, int in, int out,
+                         float lr, float momentum, float weight_decay, int first, const float* lr_dev, void* stream);
 /* General (batched) product C[b] = act(A[b] B[b] + bias[n]), C [m, n] with row pitch ldc; act = activation (0 none, 1 GELU)
  * + 16 when the bias is indexed by the output row m instead of the column (1x1x1 convolution: rows are channels).  a_kcontig 1: A is row-major [m][lda]
  * (k contiguous), 0: A is given transposed [k][lda] (m contiguous); b_kcontig 1: B is [n][ldb] (k contiguous, "W^T"), 0: B is

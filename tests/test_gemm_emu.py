@@ -99,3 +99,73 @@ def test_conv_transpose_k2s2_is_one_product_on_the_channel_major_input():
     assert rel_err(y.detach(), ref.detach()) < 2e-5
     for got, want in ((x.grad, xr.grad), (w.grad, wr.grad), (skip.grad, sr.grad)):
         assert rel_err(got, want) < 2e-5
+
+
+@pytest.mark.parametrize("rows,i,o,first", [
+    (16, 1024, 1024, 1),     # one row tile, momentum initialised from the gradient
+    (12, 1088, 1040, 0),     # ragged rows, strip and slice tails
+    (24, 1024, 1056, 0),     # two row tiles
+    (2, 192, 132, 0),        # tiny: one slice, partial tiles everywhere
+])
+def test_input_gradient_and_sgd_update_in_one_pass(rows, i, o, first):
+    """icl_linear_dgrad_sgd == linear_dgrad (old weight) followed by torch.optim.SGD's momentum step on dW = g^T x."""
+    L = _lib.lib()
+    g, x = _rand((rows, o), 11), _rand((rows, i), 12)
+    w0, m0 = _rand((o, i), 13) * 0.05, _rand((o, i), 14) * 0.01
+    lr, mom, wd = 0.01, 0.9, 1e-4
+    w, m = w0.clone(), (torch.full_like(m0, float("nan")) if first else m0.clone())
+    gx = torch.empty(rows, i)
+    ws = torch.empty(max(1, L.icl_linear_ws_bytes(rows, i, o, 3) // 4))
+    lr_dev = torch.tensor([lr])
+    rc = L.icl_linear_dgrad_sgd(g.data_ptr(), x.data_ptr(), w.data_ptr(), m.data_ptr(), gx.data_ptr(), ws.data_ptr(), rows, i, o,
+                                123.0, mom, wd, first, lr_dev.data_ptr(), None)     # the device scalar overrides the host lr
+    assert rc == 0, _lib.last_error()
+    d = g.double().t() @ x.double() + wd * w0.double()
+    m_ref = d if first else mom * m0.double() + d
+    w_ref = w0.double() - lr * m_ref
+    assert rel_err(gx, (g.double() @ w0.double()).float()) < 2e-5
+    assert rel_err(m, m_ref.float()) < 2e-5
+    assert float((w - w_ref.float()).abs().max()) < 2e-6 * float(w_ref.abs().max()) + 1e-7
+
+
+def test_fused_update_matches_optimizer_step_through_autograd():
+    """ops.linear with FactoredGrads.fused_optimizer set: same gx, weight and momentum as backward + FusedSGD.step(); a weight used
+    twice in the step falls back to the factored update in step()."""
+    from icl_amd.optim import FusedSGD
+    torch.manual_seed(0)
+
+    def run(fuse, twice):
+        lin = torch.nn.Linear(1536, 1408)
+        with torch.no_grad():
+            lin.weight.copy_(_rand((1408, 1536), 21) * 0.05)
+            lin.bias.copy_(_rand((1408,), 22))
+        opt = FusedSGD(lin.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+        opt.can_update_in_backward = lambda p, rows: p.dim() == 2     # the product path only takes 2^26-element matrices
+        xs = []
+        for step in range(2):
+            x = _rand((6, 1536), 23 + step).requires_grad_()
+            opt.zero_grad()
+            ops.FactoredGrads.fused_optimizer = opt if fuse else None
+            ops.FactoredGrads.uses = {} if fuse else None
+            prev_min = ops.FactoredGrads.min_elems
+            try:
+                with ops.FactoredGrads(True):
+                    y = ops.linear(x, lin.weight, lin.bias, lin)
+                    if twice:
+                        y = y + ops.linear(x * 0.5, lin.weight, lin.bias, lin)
+                    (y * _rand(tuple(y.shape), 30 + step)).sum().backward()
+            finally:
+                ops.FactoredGrads.fused_optimizer = None
+                ops.FactoredGrads.uses = None
+                ops.FactoredGrads.min_elems = prev_min
+            if fuse and not twice:
+                assert lin.weight.grad is None and not getattr(lin.weight, "_icl_factors", None)
+            opt.step()
+            xs.append(x.grad.clone())
+        return xs, lin.weight.detach().clone(), opt.state[lin.weight]["momentum_buffer"].clone(), lin.bias.detach().clone()
+
+    for twice in (False, True):
+        a, b = run(True, twice), run(False, twice)
+        for ga, gb in zip(a[0], b[0]):
+            assert rel_err(ga, gb) < 2e-5
+        assert rel_err(a[1], b[1]) < 1e-6 and rel_err(a[2], b[2]) < 2e-5 and rel_err(a[3], b[3]) < 1e-6

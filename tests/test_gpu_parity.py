@@ -702,7 +702,8 @@ def test_aligner_side_stream_equals_single_stream(dev):
             fill_like_reference_init(list(model.named_parameters()))
             _parity_mode(model)
             model.train()
-            tr = ICLTrainer(model, ICLConfig(num_classes=2, labeled_bs=1, max_iterations=10))
+            # (update_in_backward off: this test reads the factors of the 13,824^2 matrices after the backward pass)
+            tr = ICLTrainer(model, ICLConfig(num_classes=2, labeled_bs=1, max_iterations=10, update_in_backward=False))
             parts = tr._forward_backward(vol, lab)
             torch.cuda.synchronize()
             grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
@@ -789,3 +790,74 @@ def test_gemm_layouts_batch_and_final_conv_class(dev):
         gxr, gwr, gbr = torch.autograd.grad(yr, (xr, wr, br), gyc.cpu())
         assert rel_err(yc.detach().cpu(), yr.detach()) < 2e-5 and rel_err(gxc.cpu(), gxr) < 2e-5, (cin, cout)
         assert rel_err(gwc.cpu(), gwr) < 1e-4 and rel_err(gbc.cpu(), gbr) < 1e-4, (cin, cout)
+
+
+@pytest.mark.gpu
+def test_update_inside_backward_equals_update_in_optimizer_step(dev):
+    """Single rank: the SGD step of the four 13,824^2 mlp2 matrices rides on their input-gradient pass (csrc/kernels/gemm.h
+    linear_dgrad_sgd_kernel, FusedSGD.update_in_backward).  Three steps with and without it: same losses, weights and momentum
+    (the first step initialises the momentum, the later ones use it)."""
+    from icl_amd import ops
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    vol = synthetic_volume((2, 1, 96, 96, 96), 77).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 78, 2).to(dev)
+    out = []
+    for fuse in (False, True):
+        ops.StepRNG.tensor = None
+        model = unet_3D_icl(n_classes=2, in_channels=1, device=dev)
+        fill_like_reference_init(list(model.named_parameters()))
+        _parity_mode(model)
+        model.train()
+        tr = ICLTrainer(model, ICLConfig(num_classes=2, labeled_bs=1, max_iterations=10, update_in_backward=fuse))
+        with ops.KernelTimer() as kt:
+            losses = [float(tr.step(vol, lab)["loss"]) for _ in range(3)]
+        n = kt.summary().get("linear_dgrad_sgd_kernel", (0,))[0]
+        assert n == (12 if fuse else 0), n                       # four matrices x three steps, or none
+        big = {k: p for k, p in model.named_parameters() if p.numel() >= 1 << 26}
+        assert len(big) == 4
+        out.append((losses, {k: p.detach().clone() for k, p in big.items()},
+                    {k: tr.optimizer.state[p]["momentum_buffer"].clone() for k, p in big.items()},
+                    {k: p.detach().clone() for k, p in model.named_parameters() if p.numel() < 1 << 26}))
+        del tr, model
+        torch.cuda.empty_cache()
+    a, b = out
+    for la, lb in zip(a[0], b[0]):
+        assert abs(la - lb) <= 1e-5 * abs(lb), (a[0], b[0])
+    for k in a[1]:
+        assert float((a[1][k] - b[1][k]).abs().max()) <= 1e-6 * float(b[1][k].abs().max()), k
+        assert rel_err(a[2][k].cpu(), b[2][k].cpu()) < 1e-4, k
+    for k in a[3]:
+        assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-4 * float(b[3][k].abs().max()) + 1e-7, k
+
+
+@pytest.mark.gpu
+def test_unet_icl_steps_are_bit_reproducible(dev):
+    """No kernel of the U-Net ICL step sums floats in a schedule-dependent order (split-K slabs, LayerNorm / bias partials and loss
+    partials are all added in a fixed order; nothing uses float atomics): two runs of three steps from the same state end in
+    bit-identical weights, momentum buffers, BatchNorm statistics and updated_Qs — with the aligner heads on their side stream."""
+    from icl_amd import ops
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    vol = synthetic_volume((2, 1, 96, 96, 96), 91).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 92, 2).to(dev)
+    runs = []
+    for _ in range(2):
+        ops.StepRNG.tensor = None
+        torch.manual_seed(20240917)                      # eager dropout seeds come from torch's CPU generator
+        model = unet_3D_icl(n_classes=2, in_channels=1, device=dev)
+        fill_like_reference_init(list(model.named_parameters()))
+        model.train()                                    # dropout and drop-path ON: the masks are a function of the seed
+        tr = ICLTrainer(model, ICLConfig(num_classes=2, labeled_bs=1, max_iterations=10))
+        losses = [tr.step(vol, lab)["loss"].clone() for _ in range(3)]
+        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        for k, p in model.named_parameters():
+            if p in tr.optimizer.state:
+                state["momentum " + k] = tr.optimizer.state[p]["momentum_buffer"].clone()
+        runs.append((losses, state))
+        del tr, model
+        torch.cuda.empty_cache()
+    (la, sa), (lb, sb) = runs
+    assert all(torch.equal(x, y) for x, y in zip(la, lb)), (la, lb)
+    differ = [k for k in sa if not torch.equal(sa[k], sb[k])]
+    assert not differ, differ[:10]

@@ -98,3 +98,38 @@ if which == "one":
     b = torch.randn(o, device=dev)
     f1 = t(lambda: ops.linear_forward_raw(x, w, b))
     print(f"[{rows},{i}]->{o} fwd {f1:7.1f} us ({2.0 * rows * i * o / 1e6 / f1:6.1f} TF)")
+
+if which in ("fused",):
+    # input gradient + SGD step of a token-axis matrix: one pass (linear_dgrad_sgd_kernel) vs linear_dgrad + sgd_factored_kernel
+    import ctypes
+    from icl_amd import _lib
+    L = _lib.lib()
+    for N in (13824, 1728):
+        w = torch.randn(N, N, device=dev) * 0.01
+        mo = torch.randn(N, N, device=dev) * 0.001
+        for m in (4, 8, 16, 32):
+            x = torch.randn(m, N, device=dev)
+            g = torch.randn(m, N, device=dev) * 0.01
+            gx = torch.empty(m, N, device=dev)
+            ws = torch.empty(max(1, L.icl_linear_ws_bytes(m, N, N, 3) // 4), device=dev)
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+            def fused():
+                _lib.check(L.icl_linear_dgrad_sgd(g.data_ptr(), x.data_ptr(), w.data_ptr(), mo.data_ptr(), gx.data_ptr(), ws.data_ptr(), m, N, N,
+                                                  1e-3, 0.9, 1e-4, 0, None, st), "fused")
+
+            def separate():
+                ops.linear_dgrad_raw(g, w)
+                _lib.check(L.icl_sgd_step_factored(w.data_ptr(), mo.data_ptr(), g.data_ptr(), x.data_ptr(), m, N, N, 1e-3, 0.9, 1e-4, 0, None, st), "sep")
+
+            w0, m0 = w.clone(), mo.clone()
+            fused()
+            wa, ma, gxa = w.clone(), mo.clone(), gx.clone()
+            w.copy_(w0), mo.copy_(m0)
+            gxb = ops.linear_dgrad_raw(g, w)
+            _lib.check(L.icl_sgd_step_factored(w.data_ptr(), mo.data_ptr(), g.data_ptr(), x.data_ptr(), m, N, N, 1e-3, 0.9, 1e-4, 0, None, st), "sep")
+            e = (err(gxa, gxb), err(wa, w), err(ma, mo))
+            tf, ts = t(fused), t(separate)
+            gb = 16.0 * N * N / 1e9
+            print(f"N={N:6d} M={m:3d}  one pass {tf:7.1f} us ({gb / tf * 1e3:5.2f} TB/s of 16 B/weight)   dgrad + update {ts:7.1f} us   err gx {e[0]:.1e} w {e[1]:.1e} m {e[2]:.1e}",
+                  flush=True)
