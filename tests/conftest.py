@@ -13,11 +13,42 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    # (no torch.set_num_threads here: the reference's golden vectors were made with torch's default thread count, and the
+    # rounding-noise-sized gradients of the oracle tests move with the number of threads torch's CPU kernels sum over)
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: multi-ten-second CPU test")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """CPU-only hosts: run the suite on four pytest-xdist workers unless -n was given (two oracle-against-reference tests run for
+    minutes on their own; the rest fits beside them).  On a GPU box nothing changes: one process, one device."""
+    if os.path.exists("/dev/kfd") or os.environ.get("ICL_TEST_WORKERS") == "0" or "PYTEST_XDIST_WORKER" in os.environ:
+        return None      # (an xdist worker runs this hook too: it must never start workers of its own)
+    if getattr(config.option, "numprocesses", "absent") is None and not config.getoption("usepdb", False):
+        config.option.numprocesses = int(os.environ.get("ICL_TEST_WORKERS", "4"))
+        config.option.dist = "worksteal"
+    return None
+
+
+# the tests that run for a minute or more on CPU, longest first (every xdist worker starts with one of them)
+LONG_TESTS = ("test_full_model_step_matches_reference", "test_2d_unet_icl_step_matches_reference",
+              "test_icl_trainer_with_gradient_reducer_world2", "test_swin_stage_matches_oracle")
+
+
 def pytest_collection_modifyitems(config, items):
+    workers = getattr(config.option, "numprocesses", None) or int(os.environ.get("PYTEST_XDIST_WORKER_COUNT", "0"))
+    if workers and workers > 1:
+        # worksteal hands every worker a contiguous block of the collection: put one long test at the head of each block
+        rank = {n: i for i, n in enumerate(LONG_TESTS)}
+        long = sorted((it for it in items if it.originalname in rank), key=lambda it: rank[it.originalname])
+        rest = [it for it in items if it.originalname not in rank]
+        block = max(1, (len(items) + workers - 1) // workers)
+        out = []
+        for w in range(workers):
+            out += long[w::workers] + rest[w * (block - 1):(w + 1) * (block - 1)]
+        out += [it for it in rest if it not in set(out)]
+        items[:] = out
     # GPU tests are skipped (not failed) when selected on a host without a GPU.
     if torch.cuda.is_available():
         return

