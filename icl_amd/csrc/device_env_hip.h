@@ -18,6 +18,14 @@ __device__ __forceinline__ f32x16 icl_mfma_32x32x2(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x32_bf16 — 16 cycles per SIMD.  Operands as 8 packed bf16 (uint4; low half of a dword = even element):
+// lane l: A[row l&15][k 8*(l>>4) .. +7], B[k 8*(l>>4) .. +7][col l&15]; D as icl_mfma_16x16x4.  bf16 x bf16 products are exact in
+// fp32; they are accumulated in fp32.
+typedef __bf16 icl_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 icl_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(icl_bf16x8, a), __builtin_bit_cast(icl_bf16x8, b), c, 0, 0, 0);
+}
+
 // v_exp_f32 based exp (2 instructions); the CPU emulation maps it to expf
 __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 

@@ -1,0 +1,249 @@
+// conv_bf16x3.h — 3x3x3 convolution (forward / input gradient) with fp32 operands split into three bf16 terms.
+//
+// The fp32 matrix pipe of gfx950 peaks at 157 TFLOP/s and the 3x3x3 convolutions of the U-Net are bound by it (profiles/r2_pmc_conv.md:
+// 81-85 % busy).  The bf16 pipe is 16x faster.  Every fp32 number is EXACTLY the sum of three bf16 numbers (8 + 8 + 8 mantissa bits,
+// truncation split: x = x1 + x2 + x3), so a product x*w is the sum of nine bf16 products; the six with the largest magnitude
+//     x1 w1 + (x1 w2 + x2 w1) + (x1 w3 + x2 w2 + x3 w1)
+// reproduce it to 2^-24 relative (the three dropped terms are below 2^-24 |x w|), which is the rounding error of an fp32 product.
+// Accumulation is fp32 inside v_mfma_f32_16x16x32_bf16, as in the fp32 kernels.  Six bf16 MFMAs of 16 cycles replace eight fp32 MFMAs
+// of 32 cycles for the same 16 x 16 x 32 block of multiply-adds: 2.67x the matrix rate at fp32 accuracy.
+//
+// GEMM view (same as conv_mfma_static.h): rows = 16 consecutive x positions, columns = 16 output channels, k = (tap, input channel).
+// One MFMA takes k = 32: two taps x 16 input channels; lane group lq = lane >> 4 supplies 8 consecutive k: tap (lq >> 1) of the
+// pair, channels 8 (lq & 1) .. + 7.  Both operands are therefore kept "8 channels contiguous" (16 bytes of bf16) in LDS and every
+// operand fragment is ONE ds_read_b128:
+//   Xs[split 3][half 2][position][8 ch]   halo tile of (TZ+2) x (TY+2) x 18 positions of a 16-channel chunk
+//   Ws[split 3][half 2][slot 10][cout][8 ch]   the 9 taps of one dz plane (5 pairs, slot 9 is zero) for the cout block
+// The fp32 NCDHW input is split and transposed while it is staged (a thread reads one position of 8 channel planes, 3 ds_write_b128);
+// the weights come from the fp32 pack of the fp32 kernels (PackedWeights) and are split the same way, one dz plane at a time.  A workgroup (8 waves) owns output tiles of 4 x 8 x 16 voxels and
+// walks a list of tiles; the global loads of the next (tile, channel chunk) are in flight while the current one is multiplied.
+// Reference op: nn.Conv3d(k=3, pad=1) inside UnetConv3 (/root/reference/code/networks/utils.py:104,107) and its input gradient.
+#pragma once
+
+namespace icl {
+
+struct Bf3Geom {
+  int Cin, Cout, CinP, CoutP; // Cin % 16 == 0; CinP / CoutP: extents of the packed weights wp[27 taps][CinP][CoutP] (conv_mfma.h)
+  int D, H, W;                // W % 4 == 0
+  int ntz, nty, ntx, ntiles;  // tiles per sample, ntiles = batch * ntz * nty * ntx
+  int nchunks;                // Cin / 16
+  long x_bstride, y_bstride;
+};
+
+// Output tile 4 x TY x 16 voxels, one wave per four (z, y) rows: TY = 8 -> 8 waves, 120-150 KB of LDS (one workgroup per CU);
+// TY = 4 -> 4 waves, 78 KB with one cout block: two workgroups per CU whose staging and multiply phases interleave.
+struct Bf3Base { static constexpr int SLOTS = 10; };
+template <int TY_>
+struct Bf3T : Bf3Base {
+  static constexpr int TZ = 4, TY = TY_, TX = 16, PZ = TZ + 2, PY = TY + 2, PX = TX + 2;
+  static constexpr int NPOS = PZ * PY * PX;
+  static constexpr int NPOSP = (NPOS + 1 + 15) / 16 * 16;        // the zero slot of the last pair reads one position past the tile;
+                                                                 // a multiple of 16 keeps the two channel halves 256 B apart (banks)
+  static constexpr int NW = TZ * TY / 4, NT = 64 * NW, ITEMS = 2 * NPOS, ROUNDS = (ITEMS + NT - 1) / NT;
+  static constexpr int XS_U4 = 6 * NPOSP;                        // uint4 (8 bf16) units
+  static constexpr int ws_u4(int nb) { return 6 * SLOTS * nb; }
+  static constexpr size_t lds_bytes(int nbt) { return (size_t)(XS_U4 + ws_u4(16 * nbt)) * 16; }
+};
+typedef Bf3Base Bf3;
+
+// fp32 -> three bf16 by truncation: v = s1 + s2 + s3 exactly (24 mantissa bits = 3 x 8).  Packs 8 values per split.
+__device__ __forceinline__ void bf3_split8(const float (&v)[8], uint4& o1, uint4& o2, uint4& o3) {
+  unsigned h1[8], h2[8], h3[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned u = __float_as_uint(v[c]);
+    h1[c] = u & 0xffff0000u;
+    const float r = v[c] - __uint_as_float(h1[c]);
+    h2[c] = __float_as_uint(r) & 0xffff0000u;
+    const float r2 = r - __uint_as_float(h2[c]);
+    h3[c] = __float_as_uint(r2) & 0xffff0000u;
+  }
+  o1 = make_uint4((h1[0] >> 16) | h1[1], (h1[2] >> 16) | h1[3], (h1[4] >> 16) | h1[5], (h1[6] >> 16) | h1[7]);
+  o2 = make_uint4((h2[0] >> 16) | h2[1], (h2[2] >> 16) | h2[3], (h2[4] >> 16) | h2[5], (h2[6] >> 16) | h2[7]);
+  o3 = make_uint4((h3[0] >> 16) | h3[1], (h3[2] >> 16) | h3[3], (h3[4] >> 16) | h3[5], (h3[6] >> 16) | h3[7]);
+}
+
+template <int NBT, int TY>
+__global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {
+  typedef Bf3T<TY> TC;
+  constexpr int NB = 16 * NBT, PX = TC::PX, PY = TC::PY, NPOSP = TC::NPOSP, ROUNDS = TC::ROUNDS, NT = TC::NT;
+  constexpr int WITEMS = 2 * Bf3::SLOTS * NB, WU = (WITEMS + NT - 1) / NT;      // weight items (slot, half, cout) per dz plane
+  ICL_DYN_LDS(uint4, lds);
+  uint4* Xs = lds;
+  uint4* Ws = lds + TC::XS_U4;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int half = lq & 1, tp = lq >> 1;
+  const int n0 = blockIdx.y * NB;
+  const long HW = (long)g.H * g.W, DHW = g.D * HW;
+  const int tiles_per = g.ntz * g.nty * g.ntx;
+
+  // zero the pad positions once (read by the zero slot: garbage * 0 must not be NaN)
+  for (int i = tid; i < 6 * (NPOSP - TC::NPOS); i += NT)
+    Xs[(i / (NPOSP - TC::NPOS)) * NPOSP + TC::NPOS + (i % (NPOSP - TC::NPOS))] = make_uint4(0u, 0u, 0u, 0u);
+
+  // ---- staging: item = (channel octet, halo position); lanes walk the positions of the tile in LDS order, so the three 16-byte
+  // writes of an item land on consecutive LDS slots across the lanes (no bank conflicts) and the 8 loads of a wave-instruction
+  // read runs of 18 consecutive floats.  Tile-invariant part of the addressing:
+  int s_rel[ROUNDS], s_zyx[ROUNDS], s_dst[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int it = tid + r * NT;
+    const int o = it / TC::NPOS, pos = it % TC::NPOS;
+    const int px = pos % PX, row = pos / PX, py = row % PY, pz = row / PY;
+    s_zyx[r] = it < TC::ITEMS ? (pz << 16) | (py << 8) | px : -1;
+    s_rel[r] = o * 8;                                   // first channel of the octet; the spatial offset is added per tile
+    s_dst[r] = o * NPOSP + pos;
+  }
+  float xv[ROUNDS][8];
+  auto load_x = [&](int tile, int chunk) {
+    const int b = tile / tiles_per, bt = tile % tiles_per;
+    const int x0 = (bt % g.ntx) * TC::TX, y0 = ((bt / g.ntx) % g.nty) * TC::TY, z0 = (bt / (g.ntx * g.nty)) * TC::TZ;
+    const float* xb = x + (long)b * g.x_bstride + (long)chunk * 16 * DHW;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int gz = z0 - 1 + (s_zyx[r] >> 16), gy = y0 - 1 + ((s_zyx[r] >> 8) & 255), gx = x0 - 1 + (s_zyx[r] & 255);
+      const bool ok = s_zyx[r] >= 0 && gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+      const float* p = xb + (long)s_rel[r] * DHW + (ok ? gz * HW + (long)gy * g.W + gx : 0L);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xv[r][c] = ok ? p[c * DHW] : 0.f;
+    }
+  };
+  auto store_x = [&]() {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      if (s_zyx[r] < 0) continue;
+      uint4 o1, o2, o3;
+      bf3_split8(xv[r], o1, o2, o3);
+      uint4* d = Xs + s_dst[r];
+      d[0] = o1;
+      d[2 * NPOSP] = o2;
+      d[4 * NPOSP] = o3;
+    }
+  };
+  // weights: the fp32 pack of the forward / input-gradient kernels, wp[tap][CinP][CoutP]; an item = 8 input channels of one
+  // (tap slot, cout), split on the way into LDS (slot 9 of a dz plane is the zero partner of its ninth tap)
+  float wv[WU][8];
+  auto load_w = [&](int chunk, int dz) {
+#pragma unroll
+    for (int i = 0; i < WU; ++i) {
+      const int it = tid + i * NT;
+      const int co = it % NB, hs = it / NB, slot = hs % Bf3::SLOTS, hf = hs / Bf3::SLOTS;
+      const bool ok = it < WITEMS && slot < 9 && n0 + co < g.CoutP;
+      const float* p = wp + (ok ? ((long)(dz * 9 + slot) * g.CinP + chunk * 16 + hf * 8) * g.CoutP + n0 + co : 0L);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) wv[i][c] = ok ? p[(long)c * g.CoutP] : 0.f;
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < WU; ++i) {
+      const int it = tid + i * NT;
+      if (it >= WITEMS) continue;
+      uint4 o1, o2, o3;
+      bf3_split8(wv[i], o1, o2, o3);
+      Ws[it] = o1;                                  // it = (half * SLOTS + slot) * NB + cout: plane `half` of split 0
+      Ws[it + 2 * Bf3::SLOTS * NB] = o2;
+      Ws[it + 4 * Bf3::SLOTS * NB] = o3;
+    }
+  };
+
+  // ---- operand bases: wave w owns the (z, y) rows 4 w .. 4 w + 3 of the tile
+  const int wz = (4 * wid) / TY, wy = (4 * wid) % TY;
+  const int lanepos = (wz * PY + wy) * PX + lr;
+  const uint4* xa = Xs + half * NPOSP + lanepos;        // + split * 2 * NPOSP + tap offset
+  const uint4* xa1 = xa + tp;                            // pairs whose second tap is one position further
+  const uint4* xa16 = xa + tp * 16;                      // the (dy0 dx2, dy1 dx0) pair: 16 positions further
+  const uint4* wb = Ws + (half * Bf3::SLOTS + tp) * NB + lr;
+
+  f32x4 acc[4][NBT];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int tile = blockIdx.x, chunk = 0;
+  if (tile < g.ntiles) {
+    load_w(0, 0);
+    load_x(tile, 0);
+  }
+  while (tile < g.ntiles) {
+    int ntile = tile, nchunk = chunk + 1;
+    if (nchunk == g.nchunks) { nchunk = 0; ntile = tile + gridDim.x; }
+    __syncthreads();                       // everyone has finished reading the previous halo tile and weight plane
+#if !defined(BF3_DEBUG) || !(BF3_DEBUG & 2)
+    store_x();
+#endif
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz) {
+      if (dz > 0) __syncthreads();         // the previous plane's weights are no longer read
+      store_w();
+      __syncthreads();
+      // global loads one phase ahead: the next weight plane first (older in the in-order vmcnt queue: waiting for it leaves the
+      // halo tile of the next work item in flight), then — once per work item — that halo tile
+      if (dz < 2) load_w(chunk, dz + 1);
+      else if (ntile < g.ntiles) load_w(nchunk, 0);
+      if (dz == 0 && ntile < g.ntiles) load_x(ntile, nchunk);
+      const int zo = dz * PY * PX;
+#pragma unroll
+      for (int pair = 0; pair < 5; ++pair) {
+        constexpr int offA[5] = {0, 2, PX + 1, 2 * PX, 2 * PX + 2};
+        const uint4* xp = (pair == 1 ? xa16 : xa1) + zo + offA[pair];
+        // all operand fragments of the pair first, then its 24 NBT MFMAs: the other wave of the SIMD multiplies while this one waits
+        uint4 b[3][NBT], a[4][3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int j = 0; j < NBT; ++j) b[s][j] = wb[(s * 2 * Bf3::SLOTS + pair * 2) * NB + j * 16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int s = 0; s < 3; ++s) a[m][s] = xp[2 * s * NPOSP + m * PX];
+        ICL_SCHED_BARRIER();
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          // (a split, b split) of the six products, smallest terms first; consecutive MFMAs go to different accumulators
+          constexpr int sa[6] = {2, 1, 0, 1, 0, 0}, sb[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < NBT; ++j) {
+#if defined(BF3_DEBUG) && (BF3_DEBUG & 1)
+              acc[m][j][0] += __uint_as_float(a[m][sa[t]].x ^ b[sb[t]][j].y);
+#else
+              acc[m][j] = icl_mfma_16x16x32_bf16(a[m][sa[t]], b[sb[t]][j], acc[m][j]);
+#endif
+            }
+        }
+        ICL_SCHED_BARRIER();
+      }
+    }
+    if (chunk == g.nchunks - 1) {
+      // ---- epilogue: lane holds x = 4 lq + r of row (wid, m), column co = n0 + 16 j + lr
+      const int b = tile / tiles_per, bt = tile % tiles_per;
+      const int x0 = (bt % g.ntx) * TC::TX, y0 = ((bt / g.ntx) % g.nty) * TC::TY, z0 = (bt / (g.ntx * g.nty)) * TC::TZ;
+      const int gz = z0 + wz, gx = x0 + 4 * lq;
+      float* yb = y + (long)b * g.y_bstride;
+#pragma unroll
+      for (int j = 0; j < NBT; ++j) {
+        const int co = n0 + j * 16 + lr;
+        const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int gy = y0 + wy + m;
+#if defined(BF3_DEBUG) && (BF3_DEBUG & 4)
+          if (acc[m][j][0] == 12345.678f)
+#endif
+          if (co < g.Cout && gz < g.D && gy < g.H && gx < g.W)
+            *reinterpret_cast<float4*>(yb + (long)co * DHW + gz * HW + (long)gy * g.W + gx) =
+                make_float4(acc[m][j][0] + bv, acc[m][j][1] + bv, acc[m][j][2] + bv, acc[m][j][3] + bv);
+          acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    tile = ntile;
+    chunk = nchunk;
+  }
+}
+
+}  // namespace icl

@@ -29,6 +29,10 @@ struct dim3 {
 };
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 typedef float f32x4 __attribute__((vector_size(16)));
@@ -279,6 +283,31 @@ static inline f32x4 icl_mfma_16x16x4(float a, float b, f32x4 c) {
     d[r] = acc;
   }
   hipemu::wave_done();
+  return d;
+}
+
+// v_mfma_f32_16x16x32_bf16: lane l holds A[row l&15][k 8*(l>>4)+j], B[k 8*(l>>4)+j][col l&15] as 8 packed bf16 (low half of a dword =
+// even element); D as icl_mfma_16x16x4.  Products of two bf16 are exact in fp32; the 32 products of one instruction are summed
+// here in double and rounded to fp32 once together with C (the hardware's internal order is not documented; tests hold tolerances).
+static inline f32x4 icl_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
+  uint32_t ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w};
+  const int l = hipemu_lane(), col = l & 15;
+  uint32_t arow[4][4][4], bcol[4][4];      // [r][k block][dword], [k block][dword]
+  hipemu::wave_publish(ua, 4);
+  for (int r = 0; r < 4; ++r)
+    for (int kb = 0; kb < 4; ++kb) memcpy(arow[r][kb], hipemu::wave_peer(kb * 16 + (l >> 4) * 4 + r), 16);
+  hipemu::wave_done();
+  hipemu::wave_publish(ub, 4);
+  for (int kb = 0; kb < 4; ++kb) memcpy(bcol[kb], hipemu::wave_peer(kb * 16 + col), 16);
+  hipemu::wave_done();
+  auto bf = [](uint32_t dw, int odd) { uint32_t u = odd ? (dw & 0xffff0000u) : (dw << 16); float f; memcpy(&f, &u, 4); return f; };
+  f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    double acc = c[r];
+    for (int kb = 0; kb < 4; ++kb)
+      for (int j = 0; j < 8; ++j) acc += (double)bf(arow[r][kb][j >> 1], j & 1) * (double)bf(bcol[kb][j >> 1], j & 1);
+    d[r] = (float)acc;
+  }
   return d;
 }
 

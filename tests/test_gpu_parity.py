@@ -861,3 +861,32 @@ def test_unet_icl_steps_are_bit_reproducible(dev):
     assert all(torch.equal(x, y) for x, y in zip(la, lb)), (la, lb)
     differ = [k for k in sa if not torch.equal(sa[k], sb[k])]
     assert not differ, differ[:10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,r", [(32, 32, 48), (16, 48, 48)])
+def test_split_bf16_convolution_is_as_accurate_as_the_fp32_mfma_path(dev, monkeypatch, cin, cout, r):
+    """csrc/kernels/conv_bf16x3.h (3x3x3 forward / input gradient on the bf16 matrix pipe, every fp32 operand split EXACTLY into three
+    bf16 terms, six MFMA terms per product, fp32 accumulation): on a real layer shape its distance to the fp64 convolution is that of
+    the exact-fp32-MFMA kernels (ICL_CONV_SPLIT=0), forward and input gradient, and far inside the 1e-3 of BASELINE.json."""
+    from icl_amd import ops
+    x = synthetic_volume((1, cin, r, r, r), 301)
+    w = synthetic_volume((cout, cin, 3, 3, 3), 302) * 0.1
+    gy = synthetic_volume((1, cout, r, r, r), 303)
+    xr = x.double().requires_grad_()
+    yr = torch.nn.functional.conv3d(xr, w.double(), None, padding=1)
+    yr.backward(gy.double())
+    out = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("ICL_CONV_SPLIT", split)
+        with ops.KernelTimer() as kt:
+            xg = x.to(dev).requires_grad_()
+            y = ops.conv3d(xg, w.to(dev), None)
+            y.backward(gy.to(dev))
+        names = [k for k in kt.summary() if k.startswith("conv3d_") and "_fwd_" in k]
+        assert all(("bf16x3" in k) == (split == "1") for k in names) and names, names
+        out[split] = (float((y.detach().cpu().double() - yr.detach()).abs().max() / yr.detach().abs().max()),
+                      float((xg.grad.cpu().double() - xr.grad).abs().max() / xr.grad.abs().max()))
+    (ef1, eb1), (ef0, eb0) = out["1"], out["0"]
+    assert ef1 < 2e-6 and eb1 < 2e-6, out
+    assert ef1 <= 2.0 * ef0 + 1e-7 and eb1 <= 2.0 * eb0 + 1e-7, out

@@ -61,6 +61,29 @@ def test_conv3d_wgrad_row_window_kernel(monkeypatch, mode, n, cin, cout, d, h, w
     _conv_check(n, cin, cout, d, h, w, 3)
 
 
+@pytest.mark.parametrize("n,cin,cout,d,h,w", [
+    (1, 16, 16, 4, 8, 16),      # one tile, one cout block
+    (2, 32, 20, 5, 9, 20),      # two 16-channel chunks, ragged cout, partial tiles in z / y / x, two samples
+    (1, 16, 48, 3, 4, 12),      # three cout blocks per workgroup, a volume smaller than one tile
+    (1, 48, 40, 2, 8, 16),      # two cout blocks, the second one ragged; three chunks
+])
+def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w):
+    """conv_bf16x3.h: forward and input gradient with each fp32 operand split exactly into three bf16 terms (six bf16 MFMA terms per
+    product, fp32 accumulation) — same tolerance as the fp32-MFMA kernels, and the two paths agree to fp32 rounding."""
+    monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
+    monkeypatch.setenv("ICL_CONV_SPLIT", "1")
+    _conv_check(n, cin, cout, d, h, w, 3)
+    x = _rand((n, cin, d, h, w), 11)
+    wt = _rand((cout, cin, 3, 3, 3), 12) * 0.2
+    with torch.no_grad():
+        y1 = ops.conv3d(x, wt, None)
+        monkeypatch.setenv("ICL_CONV_SPLIT", "0")
+        y0 = ops.conv3d(x, wt, None)
+    ref = F.conv3d(x.double(), wt.double(), None, padding=1)
+    e1, e0 = float((y1.double() - ref).abs().max()), float((y0.double() - ref).abs().max())
+    assert e1 <= 4.0 * e0 + 2e-7 * float(ref.abs().max()), (e1, e0)     # about as close to the fp64 result as the fp32-MFMA path
+
+
 def test_conv3d_forced_big_tile(monkeypatch):
     monkeypatch.setenv("ICL_CONV_FORCE_TILE", "48")
     _conv_check(1, 16, 16, 6, 8, 16, 3)

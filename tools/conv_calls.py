@@ -9,7 +9,12 @@ from icl_amd.trainer import ICLConfig, ICLTrainer
 from icl_amd.utils.hashfill import synthetic_labels, synthetic_volume
 dev = torch.device("cuda", 0)
 nc = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-model = unet_3D_icl(n_classes=nc, in_channels=1, device=dev); model.train()
+if len(sys.argv) > 2 and sys.argv[2] == "swinunetr_icl":
+    from icl_amd.networks.swinunetr_icl import SwinUNETR_icl
+    model = SwinUNETR_icl(img_size=(96, 96, 96), in_channels=1, out_channels=nc, feature_size=48, device=dev)
+else:
+    model = unet_3D_icl(n_classes=nc, in_channels=1, device=dev)
+model.train()
 tr = ICLTrainer(model, ICLConfig(num_classes=nc, labeled_bs=1))
 vol = synthetic_volume((2, 1, 96, 96, 96), 1337, device=dev); lab = synthetic_labels((1, 96, 96, 96), 4242, nc, device=dev)
 for _ in range(3): tr.step(vol, lab)
@@ -23,5 +28,5 @@ for name, e0, e1, fl, by in kt.records:
 tot = 0
 for (name, mf, mb), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     tot += us
-    print(f"{us:9.1f} us  x{n:<3d} {mf:9d} MFLOP {mb:9.2f} MB  {name}")
+    print(f"{us:9.1f} us  x{n:<3d} {mf:9d} MFLOP {mb:9.2f} MB  {mf * n / us:7.1f} TF  {name}")
 print("total conv us", round(tot))

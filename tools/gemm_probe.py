@@ -34,7 +34,7 @@ if which in ("all", "stream"):
         w = torch.randn(N, N, device=dev) * 0.01
         b = torch.randn(N, device=dev)
         gb = w.numel() * 4 / 1e9
-        for m in (8, 16, 32):
+        for m in (8, 12, 16, 24, 32):
             x = torch.randn(m, N, device=dev)
             g = torch.randn(m, N, device=dev)
             y, yr = ops.linear_forward_raw(x, w, b), torch.nn.functional.linear(x, w, b)
