@@ -15,7 +15,7 @@
 //   Xs[split 3][half 2][position][8 ch]   halo tile of (TZ+2) x (TY+2) x 18 positions of a 16-channel chunk
 //   Ws[split 3][half 2][slot 10][cout][8 ch]   the 9 taps of one dz plane (5 pairs, slot 9 is zero) for the cout block
 // The fp32 NCDHW input is split and transposed while it is staged (a thread reads one position of 8 channel planes, 3 ds_write_b128);
-// the weights come from the fp32 pack of the fp32 kernels (PackedWeights) and are split the same way, one dz plane at a time.  A workgroup (8 waves) owns output tiles of 4 x 8 x 16 voxels and
+// the weights come from the fp32 pack of the fp32 kernels (PackedWeights), split by a small kernel in front of the convolution.  A workgroup (8 waves) owns output tiles of 4 x 8 x 16 voxels and
 // walks a list of tiles; the global loads of the next (tile, channel chunk) are in flight while the current one is multiplied.
 // Reference op: nn.Conv3d(k=3, pad=1) inside UnetConv3 (/root/reference/code/networks/utils.py:104,107) and its input gradient.
 #pragma once
@@ -63,12 +63,40 @@ __device__ __forceinline__ void bf3_split8(const float (&v)[8], uint4& o1, uint4
   o3 = make_uint4((h3[0] >> 16) | h3[1], (h3[2] >> 16) | h3[3], (h3[4] >> 16) | h3[5], (h3[6] >> 16) | h3[7]);
 }
 
+// Split weights, ready for LDS: ws[chunk][dz][split * 2 + half][slot 10][CoutP] of 8 packed bf16, from the fp32 pack wp[tap][CinP][CoutP]
+// of the fp32 kernels (slot = tap within its dz plane; slot 9 is the zero partner of the ninth tap).  One small launch in front of
+// the convolution (the matrices are 7 KB .. 1.3 MB): splitting them inside the convolution, once per tile and dz plane, cost as
+// many VALU instructions as splitting the activations.
+__global__ __launch_bounds__(256) void conv_bf16x3_split_weights_kernel(const float* __restrict__ wp, uint4* __restrict__ ws, int cinP, int coutP,
+                                                                        int nchunks) {
+  const long total = (long)nchunks * 3 * 2 * Bf3::SLOTS * coutP;
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(it % coutP);
+    long r = it / coutP;
+    const int slot = (int)(r % Bf3::SLOTS);
+    r /= Bf3::SLOTS;
+    const int hf = (int)(r % 2);
+    r /= 2;
+    const int dz = (int)(r % 3), chunk = (int)(r / 3);
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = slot < 9 ? wp[((long)(dz * 9 + slot) * cinP + chunk * 16 + hf * 8 + c) * coutP + co] : 0.f;
+    uint4 o1, o2, o3;
+    bf3_split8(v, o1, o2, o3);
+    const long plane = (long)Bf3::SLOTS * coutP;
+    uint4* d = ws + ((long)(chunk * 3 + dz) * 6 + hf) * plane + (long)slot * coutP + co;
+    d[0] = o1;
+    d[2 * plane] = o2;
+    d[4 * plane] = o3;
+  }
+}
+
 template <int NBT, int TY>
-__global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {
   typedef Bf3T<TY> TC;
   constexpr int NB = 16 * NBT, PX = TC::PX, PY = TC::PY, NPOSP = TC::NPOSP, ROUNDS = TC::ROUNDS, NT = TC::NT;
-  constexpr int WITEMS = 2 * Bf3::SLOTS * NB, WU = (WITEMS + NT - 1) / NT;      // weight items (slot, half, cout) per dz plane
+  constexpr int WITEMS = 6 * Bf3::SLOTS * NB, WU = (WITEMS + NT - 1) / NT;      // 16-byte weight slots per dz plane
   ICL_DYN_LDS(uint4, lds);
   uint4* Xs = lds;
   uint4* Ws = lds + TC::XS_U4;
@@ -85,14 +113,14 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   // ---- staging: item = (channel octet, halo position); lanes walk the positions of the tile in LDS order, so the three 16-byte
   // writes of an item land on consecutive LDS slots across the lanes (no bank conflicts) and the 8 loads of a wave-instruction
   // read runs of 18 consecutive floats.  Tile-invariant part of the addressing:
-  int s_rel[ROUNDS], s_zyx[ROUNDS], s_dst[ROUNDS];
+  int s_zyx[ROUNDS], s_dst[ROUNDS], s_ch[ROUNDS];
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int it = tid + r * NT;
     const int o = it / TC::NPOS, pos = it % TC::NPOS;
     const int px = pos % PX, row = pos / PX, py = row % PY, pz = row / PY;
     s_zyx[r] = it < TC::ITEMS ? (pz << 16) | (py << 8) | px : -1;
-    s_rel[r] = o * 8;                                   // first channel of the octet; the spatial offset is added per tile
+    s_ch[r] = o * 8;                                    // first channel of the octet
     s_dst[r] = o * NPOSP + pos;
   }
   float xv[ROUNDS][8];
@@ -104,9 +132,10 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
     for (int r = 0; r < ROUNDS; ++r) {
       const int gz = z0 - 1 + (s_zyx[r] >> 16), gy = y0 - 1 + ((s_zyx[r] >> 8) & 255), gx = x0 - 1 + (s_zyx[r] & 255);
       const bool ok = s_zyx[r] >= 0 && gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
-      const float* p = xb + (long)s_rel[r] * DHW + (ok ? gz * HW + (long)gy * g.W + gx : 0L);
+      // 32-bit lane offset against a wave-uniform channel base (16 channels x D*H*W < 2^31 elements, checked by the launcher)
+      const int off = ok ? s_ch[r] * (int)DHW + gz * (int)HW + gy * g.W + gx : 0;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) xv[r][c] = ok ? p[c * DHW] : 0.f;
+      for (int c = 0; c < 8; ++c) xv[r][c] = ok ? (xb + c * DHW)[off] : 0.f;
     }
   };
   auto store_x = [&]() {
@@ -121,30 +150,22 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       d[4 * NPOSP] = o3;
     }
   };
-  // weights: the fp32 pack of the forward / input-gradient kernels, wp[tap][CinP][CoutP]; an item = 8 input channels of one
-  // (tap slot, cout), split on the way into LDS (slot 9 of a dz plane is the zero partner of its ninth tap)
-  float wv[WU][8];
+  // weights: already split (conv_bf16x3_split_weights_kernel): one dz plane = 60 NB slots of 16 bytes, copied through registers
+  uint4 wv[WU];
   auto load_w = [&](int chunk, int dz) {
+    const uint4* src = wsplit + (long)(chunk * 3 + dz) * 6 * Bf3::SLOTS * g.CoutP + n0;
 #pragma unroll
     for (int i = 0; i < WU; ++i) {
       const int it = tid + i * NT;
-      const int co = it % NB, hs = it / NB, slot = hs % Bf3::SLOTS, hf = hs / Bf3::SLOTS;
-      const bool ok = it < WITEMS && slot < 9 && n0 + co < g.CoutP;
-      const float* p = wp + (ok ? ((long)(dz * 9 + slot) * g.CinP + chunk * 16 + hf * 8) * g.CoutP + n0 + co : 0L);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) wv[i][c] = ok ? p[(long)c * g.CoutP] : 0.f;
+      wv[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (it < WITEMS && n0 + it % NB < g.CoutP) wv[i] = src[(long)(it / NB) * g.CoutP + it % NB];
     }
   };
   auto store_w = [&]() {
 #pragma unroll
     for (int i = 0; i < WU; ++i) {
       const int it = tid + i * NT;
-      if (it >= WITEMS) continue;
-      uint4 o1, o2, o3;
-      bf3_split8(wv[i], o1, o2, o3);
-      Ws[it] = o1;                                  // it = (half * SLOTS + slot) * NB + cout: plane `half` of split 0
-      Ws[it + 2 * Bf3::SLOTS * NB] = o2;
-      Ws[it + 4 * Bf3::SLOTS * NB] = o3;
+      if (it < WITEMS) Ws[it] = wv[i];
     }
   };
 
@@ -162,14 +183,21 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #pragma unroll
     for (int j = 0; j < NBT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int tile = blockIdx.x, chunk = 0;
+  // Tile order: workgroup b runs on XCD b % 8 (its own L2).  Every XCD walks its own contiguous eighth of the tile list, the
+  // workgroups of an XCD side by side in it, so that tiles which share halo planes are staged through the same L2 at about the
+  // same time (FETCH_SIZE: the halo re-reads otherwise all go to HBM / MALL).  Needs gridDim.x % 8 == 0 (launcher).
+  const int per_xcd = (g.ntiles + 7) / 8, xcd = blockIdx.x & 7, wgs_per_xcd = gridDim.x >> 3;
+  const int xcd_end = (xcd + 1) * per_xcd < g.ntiles ? (xcd + 1) * per_xcd : g.ntiles;
+  auto next_tile = [&](int t) { return t + wgs_per_xcd < xcd_end ? t + wgs_per_xcd : g.ntiles; };
+  int tile = xcd * per_xcd + (blockIdx.x >> 3), chunk = 0;
+  if (tile >= xcd_end) tile = g.ntiles;
   if (tile < g.ntiles) {
     load_w(0, 0);
     load_x(tile, 0);
   }
   while (tile < g.ntiles) {
     int ntile = tile, nchunk = chunk + 1;
-    if (nchunk == g.nchunks) { nchunk = 0; ntile = tile + gridDim.x; }
+    if (nchunk == g.nchunks) { nchunk = 0; ntile = next_tile(tile); }
     __syncthreads();                       // everyone has finished reading the previous halo tile and weight plane
 #if !defined(BF3_DEBUG) || !(BF3_DEBUG & 2)
     store_x();

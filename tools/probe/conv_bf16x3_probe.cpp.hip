@@ -13,13 +13,13 @@
 
 static int g_wgs = 256;
 template <int NBT, int TY>
-void launch(const float* x, const float* wp, const float* bias, float* y, icl::Bf3Geom g, hipStream_t st) {
+void launch(const float* x, const uint4* wp, const float* bias, float* y, icl::Bf3Geom g, hipStream_t st) {
   const size_t lds = icl::Bf3T<TY>::lds_bytes(NBT);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_bf16x3_fwd_kernel<NBT, TY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int gy = (g.CoutP + 16 * NBT - 1) / (16 * NBT);
   g.nty = (g.H + TY - 1) / TY;
   g.ntiles = 2 * g.ntz * g.nty * g.ntx;
-  int gx = g.ntiles < g_wgs ? g.ntiles : g_wgs;
+  int gx = g.ntiles < g_wgs ? (g.ntiles + 7) / 8 * 8 : g_wgs;
   hipLaunchKernelGGL((icl::conv3d_bf16x3_fwd_kernel<NBT, TY>), dim3(gx, gy), dim3(64 * TY), lds, st, x, wp, bias, y, g);
 }
 
@@ -46,6 +46,8 @@ int main(int argc, char** argv) {
       for (int t = 0; t < 27; ++t) hwp[((size_t)t * cinP + ci) * coutP + co] = hw[((size_t)co * cin + ci) * 27 + t];
   CK(hipMalloc(&dx, hx.size() * 4)); CK(hipMalloc(&dw, hw.size() * 4)); CK(hipMalloc(&db, hb.size() * 4));
   CK(hipMalloc(&dy, (size_t)N * cout * S * 4)); CK(hipMalloc(&dwp, wpn * 4)); CK(hipMemcpy(dwp, hwp.data(), wpn * 4, hipMemcpyHostToDevice));
+  uint4* dws; const long items = (long)(cin / 16) * 3 * 2 * icl::Bf3::SLOTS * coutP; CK(hipMalloc(&dws, items * 3 * 16));
+  hipLaunchKernelGGL(icl::conv_bf16x3_split_weights_kernel, dim3(64), dim3(256), 0, 0, dwp, dws, cinP, coutP, cin / 16);
   CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
@@ -55,8 +57,8 @@ int main(int argc, char** argv) {
   g.ntz = (D + 3) / 4; g.nty = (H + 7) / 8; g.ntx = (W + 15) / 16; g.ntiles = N * g.ntz * g.nty * g.ntx;
   g.nchunks = cin / 16; g.x_bstride = cin * S; g.y_bstride = cout * S;
   auto go = [&]() {
-    if (ty == 4) { if (nbt == 1) launch<1, 4>(dx, dwp, db, dy, g, 0); else if (nbt == 2) launch<2, 4>(dx, dwp, db, dy, g, 0); else launch<3, 4>(dx, dwp, db, dy, g, 0); }
-    else { if (nbt == 1) launch<1, 8>(dx, dwp, db, dy, g, 0); else if (nbt == 2) launch<2, 8>(dx, dwp, db, dy, g, 0); else launch<3, 8>(dx, dwp, db, dy, g, 0); }
+    if (ty == 4) { if (nbt == 1) launch<1, 4>(dx, dws, db, dy, g, 0); else if (nbt == 2) launch<2, 4>(dx, dws, db, dy, g, 0); else launch<3, 4>(dx, dws, db, dy, g, 0); }
+    else { if (nbt == 1) launch<1, 8>(dx, dws, db, dy, g, 0); else if (nbt == 2) launch<2, 8>(dx, dws, db, dy, g, 0); else launch<3, 8>(dx, dws, db, dy, g, 0); }
   };
   go();
   CK(hipDeviceSynchronize());
