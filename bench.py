@@ -34,6 +34,13 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md dense bf16 matrix peak
+# csrc/kernels/conv_bf16x3.h multiplies fp32 operands as exact three-way bf16 splits: SIX bf16 MFMA terms per fp32 product.  Its
+# speed of light in ALGORITHMIC (fp32) FLOP/s is therefore the bf16 peak / 6.
+SPLIT_TERMS = 6
+# matrix-pipe busy fraction of the kernel's cycles, PMC (profiles/r2_pmc_conv.md), static
+PIPE_BUSY = {"conv3d_mfma_fwd_static_kernel": 0.81, "conv3d_bf16x3_fwd_kernel<1, 8>": 0.46, "conv3d_bf16x3_fwd_kernel<2, 8>": 0.52,
+             "conv3d_bf16x3_fwd_kernel<3, 8>": 0.62}
 
 
 def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
@@ -102,6 +109,8 @@ def main():
                     help="unet_3D_icl = BASELINE configs[1] (the headline line); swinunetr_icl = configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-exact-compare", action="store_true",
+                    help="skip the reference timing of the same step with the convolutions on the exact-fp32 MFMA kernels")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph"],
                     help="one rank: auto = after capture, time 3 replayed and 3 eager steps and run the timed region in the faster mode "
@@ -211,6 +220,36 @@ def main():
     volumes = 2 * world * args.steps
     value = volumes / dt
 
+    exact = None
+    if rank == 0 and world == 1 and not args.no_exact_compare and os.environ.get("ICL_CONV_SPLIT", "1") != "0":
+        # the same step with every convolution on the exact-fp32 MFMA kernels (ICL_CONV_SPLIT=0), for reference: a second model and
+        # trainer (own capture), timed the same way, after the headline region
+        os.environ["ICL_CONV_SPLIT"] = "0"
+        try:
+            torch.manual_seed(1337 + rank)
+            if args.model == "swinunetr_icl":
+                model2 = SwinUNETR_icl(img_size=(96, 96, 96), in_channels=1, out_channels=nc, feature_size=48, device=dev)
+            else:
+                model2 = unet_3D_icl(n_classes=nc, in_channels=1, device=dev)
+            model2.train()
+            tr2 = ICLTrainer(model2, cfg, None)
+            if not args.no_graph:
+                tr2.capture(vol, lab, warmup=max(args.warmup, 2))
+            for _ in range(2):
+                tr2.step(vol, lab)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                tr2.step(vol, lab)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            exact = {"ms_per_step": round(dt2 / args.steps * 1e3, 3), "value": round(2 * args.steps / dt2, 3),
+                     "note": "same step with ICL_CONV_SPLIT=0 (3x3x3 forward / input gradient on v_mfma_f32_16x16x4_f32)"}
+            del tr2, model2
+            torch.cuda.empty_cache()
+        finally:
+            os.environ["ICL_CONV_SPLIT"] = "1"
+
     roof = None
     if rank == 0 and not args.no_kernel_timer:
         trainer.graph = trainer.graph_update = None   # per-kernel HIP-event timing needs eager launches ...
@@ -227,22 +266,31 @@ def main():
             fwd_only = {k: v for k, v in conv.items() if "_fwd_" in k}
             name, (n, ms, fl, by) = max(fwd_only.items(), key=lambda kv: kv[1][1])
             ach = fl / (ms * 1e-3) / 1e12
+            split = "bf16x3" in name
+            peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS if split else PEAK_F32_MFMA_TFLOPS
+            busy = PIPE_BUSY.get(name, PIPE_BUSY.get(name.split("<")[0]))
             tot_ms = sum(v[1] for v in conv.values())
             tot_fl = sum(v[2] for v in conv.values())
             tot_by = sum(v[3] for v in conv.values())
             traffic = hbm_traffic(name)
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": round(peak, 1),
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    # achieved = algorithmic fp32 FLOPs (2 * 27 * Cin * Cout per voxel) / launch time.  The split-product kernel
+                    # issues 6 bf16 MFMA terms per fp32 product (exact 3-way operand splits, fp32 accumulate): its roofline is the
+                    # dense bf16 peak / 6; the exact-fp32 kernels are priced against the fp32 matrix peak.
+                    "peak_basis": (f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} / {SPLIT_TERMS} terms per fp32 product"
+                                   if split else "dense fp32 MFMA peak"),
+                    "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": traffic["hbm_bytes"] if traffic else None, "traffic_detail": traffic,
-                    # PMC (profiles/r2_pmc_conv.md, static): this kernel keeps the matrix pipe busy 81-85 % of its cycles; the rest of
-                    # the gap to the 2.4 GHz peak is the clock the chip holds under fp32-MFMA load (1.85-2.13 GHz)
-                    "matrix_pipe_busy_static_profile": 0.81,
+                    # PMC (profiles/r2_pmc_conv.md, static): fraction of the kernel's cycles with the matrix pipe busy; the rest of
+                    # the gap to the 2.4 GHz peak is the clock the chip holds under matrix load (1.8-2.1 GHz)
+                    "matrix_pipe_busy_static_profile": busy,
                     "launches_per_step": n // 3, "avg_launch_us": round(ms * 1e3 / n, 2),
                     # what the event pair itself adds to a bracketed launch on the idle eager stream (NOT subtracted above: the raw
                     # durations are the conservative ones; rocprofv3's per-kernel averages in profiles/ are shorter by about this much)
                     "event_bracket_overhead_us": round(ops.event_bracket_overhead_us(dev), 2),
                     "all_conv": {"ms_per_step": round(tot_ms / 3, 3), "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 3),
-                                 "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                 "vs_fp32_mfma_peak": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                  "algorithmic_gbs": round(tot_by / (tot_ms * 1e-3) / 1e9, 1),
                                  "hbm_frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
                     "per_kernel": {k: {"launches_per_step": v[0] // 3, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
@@ -285,7 +333,14 @@ def main():
                        "global_batch": 2 * world, "parallelism": f"dp{world}",
                        "launch": ("eager" if not graphed else "hipGraph replay" if ddp is None else
                                   "hipGraph replay (forward/backward, optimiser) + eager RCCL collectives"),
-                       **({"launch_probe": launch_probe} if launch_probe else {})},
+                       **({"launch_probe": launch_probe} if launch_probe else {}),
+                       # every tensor, accumulator and result is fp32.  With ICL_CONV_SPLIT on (default) the 3x3x3 forward / input-
+                       # gradient products of the large layers are formed from exact three-way bf16 splits of the fp32 operands (six
+                       # bf16 MFMA terms per product, fp32 accumulate): same error against fp64 as the fp32 MFMA kernels
+                       # (tests/test_gpu_parity.py::test_split_bf16_convolution_is_as_accurate_as_the_fp32_mfma_path)
+                       "conv_products": ("exact 3-way bf16 splits of fp32 operands, 6 MFMA terms, fp32 accumulate (ICL_CONV_SPLIT=1)"
+                                         if os.environ.get("ICL_CONV_SPLIT", "1") != "0" else "v_mfma_f32_16x16x4_f32"),
+                       **({"exact_fp32_mfma_convolutions": exact} if exact else {})},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -40,7 +40,12 @@ int icl_conv3d_pack_weights_multi(const void* const* w, void* const* wp_fwd, voi
  * x = dY, cin/cout swapped, bias NULL.  Batch strides in elements; channel stride is D*H*W.
  * ws: icl_conv3d_fwd_ws_bytes(...) bytes (0 for most shapes): launches with too few output tiles to fill the chip
  * split their Cin range over workgroups, each split writes a partial-output slab there and a fixed-order reduction adds
- * them (bitwise reproducible); ws may be NULL, the launch then runs unsplit. */
+ * them (bitwise reproducible); ws may be NULL, the launch then runs unsplit.
+ * Arithmetic: fp32 operands, fp32 accumulation, fp32 result.  3x3x3 layers with Cin % 16 == 0, W % 4 == 0 and >= 48^3 voxels
+ * form their products on the bf16 matrix pipe from exact three-way bf16 splits of both operands (six MFMA terms per product,
+ * csrc/kernels/conv_bf16x3.h: the error against fp64 equals that of v_mfma_f32_16x16x4_f32); the split weights live in
+ * ws (counted by icl_conv3d_fwd_ws_bytes; without ws the fp32 MFMA kernels run).  Environment: ICL_CONV_SPLIT=0 selects the fp32
+ * MFMA kernels for every shape. */
 int64_t icl_conv3d_fwd_ws_bytes(int n, int cin, int cout, int d, int h, int w, int ks);
 int icl_conv3d_fwd(const float* x, const float* wp, const float* bias, float* y, void* ws, int n, int cin, int cout, int d, int h,
                    int w, int ks, int64_t x_bstride, int64_t y_bstride, void* stream);

@@ -4,8 +4,8 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 python3 $R/bench.py > $O/r2_bench.json 2> $O/r2_bench.err
 python3 $R/bench.py --num-classes 16 --no-cpu-baseline > $O/r2_nc16_bench.json 2>/dev/null
 python3 $R/bench.py --model swinunetr_icl > $O/r2_swin_bench.json 2>/dev/null
-python3 $R/bench.py --no-cpu-baseline --force-ddp > $O/r2_ddp_one_rank_bench.json 2>/dev/null
-rocprofv3 --kernel-trace --stats -d $O/r2_prof_unet -o b --output-format csv -- python3 $R/bench.py --no-cpu-baseline --launch graph > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d $O/r2_prof_swin -o b --output-format csv -- python3 $R/bench.py --no-cpu-baseline --launch graph --model swinunetr_icl > /dev/null 2>&1
+python3 $R/bench.py --no-cpu-baseline --force-ddp 2>/dev/null | tail -1 > $O/r2_ddp_one_rank_bench.json
+rocprofv3 --kernel-trace --stats -d $O/r2_prof_unet -o b --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-exact-compare --launch graph > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $O/r2_prof_swin -o b --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-exact-compare --launch graph --model swinunetr_icl > /dev/null 2>&1
 rm -f $O/r2_prof_unet/b_kernel_trace.csv $O/r2_prof_swin/b_kernel_trace.csv
 cut -c1-300 $O/r2_bench.json; cut -c1-200 $O/r2_nc16_bench.json; cut -c1-200 $O/r2_swin_bench.json; cut -c1-200 $O/r2_ddp_one_rank_bench.json
