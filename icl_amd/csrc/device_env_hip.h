@@ -26,6 +26,9 @@ __device__ __forceinline__ f32x4 icl_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(icl_bf16x8, a), __builtin_bit_cast(icl_bf16x8, b), c, 0, 0, 0);
 }
 
+// v_alignbit_b32: bits [sh, sh + 32) of the 64-bit value {hi, lo}
+__device__ __forceinline__ unsigned icl_alignbit(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+
 // v_exp_f32 based exp (2 instructions); the CPU emulation maps it to expf
 __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 

@@ -47,7 +47,7 @@ struct Bf3T : Bf3Base {
 typedef Bf3Base Bf3;
 
 // fp32 -> three bf16 by truncation: v = s1 + s2 + s3 exactly (24 mantissa bits = 3 x 8).  Packs 8 values per split.
-__device__ __forceinline__ void bf3_split8(const float (&v)[8], uint4& o1, uint4& o2, uint4& o3) {
+__device__ __forceinline__ void bf3_split8(const float* v, uint4& o1, uint4& o2, uint4& o3) {
   unsigned h1[8], h2[8], h3[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
@@ -271,6 +271,231 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
     }
     tile = ntile;
     chunk = nchunk;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient, split products
+// dW[co][ci][tap] = sum over voxels of dY[co][p] * x[ci][p + tap - 1] with the same exact three-way splits.  GEMM view per tap:
+// rows = 16 output channels, columns = 16 input channels, k = 32 voxels = two (z, y) rows x 16 x.  Lane group lq supplies 8
+// consecutive x of row (lq >> 1), half (lq & 1) — which is how NCDHW stores both tensors, so no transposition: LDS holds
+//   Gs[split 3][tile row 32][half 2][cout 16][8 x]                     dY of a 4 x 8 x 16 voxel tile
+//   Xs[split 3][halo row 60][half 2][cin 16][8 x] + [cin 16] edge dwords   x rows with the neighbours x0-1 | x0+16 packed per row
+// The dx = 1 tap reads its B fragment as stored; dx = 0 / 2 are the same 16 bytes shifted by one bf16 with the last / first element
+// of the neighbouring segment (v_alignbit: 4 per fragment).  A wave owns ALL 27 taps (108 accumulator registers) for four of the 16
+// k-steps of a tile — no tap split, so every staged value feeds 27 taps x 6 terms; four waves per workgroup, one per SIMD, so that a
+// wave may use the whole 512-entry register file (accumulators in AGPRs) — and the waves add their accumulators
+// through LDS after the workgroup's run of tiles; one packed slab per workgroup, summed by reduce_unpack_wgrad_kernel in a fixed
+// order as for the fp32 kernels.  One (16 cout, 16 cin) block pair per workgroup (grid.y).
+struct Bf3WGeom {
+  int Cin, Cout, CinP, CoutP, D, H, W;
+  int ntz, nty, ntx, ntiles;      // tiles per sample; ntiles = batch * ntz * nty * ntx
+  int tiles_per_wg;               // contiguous run of tiles per workgroup (blockIdx.x)
+  long x_bstride, gy_bstride;
+};
+
+struct Bf3W {
+  static constexpr int TZ = 4, TY = 8, TX = 16, PZ = 6, PY = 10, HROWS = PZ * PY, TROWS = TZ * TY, NW = 4, NT = 256;
+  static constexpr int XROW = 36, GROW = 32;                         // uint4 per row: 2 x 16 segments (+ 16 edge dwords)
+  static constexpr int XS_U4 = 3 * HROWS * XROW, GS_U4 = 3 * TROWS * GROW;
+  static constexpr size_t LDS_BYTES = (size_t)(XS_U4 + GS_U4) * 16;
+  static constexpr int XITEMS = HROWS * 32, GITEMS = TROWS * 32;
+  static constexpr int XR = (XITEMS + NT - 1) / NT, GR = (GITEMS + NT - 1) / NT;
+};
+
+// one fp32 -> its three bf16 terms as the high halves of three dwords
+__device__ __forceinline__ void bf3_split1(float v, unsigned& h1, unsigned& h2, unsigned& h3) {
+  h1 = __float_as_uint(v) & 0xffff0000u;
+  const float r = v - __uint_as_float(h1);
+  h2 = __float_as_uint(r) & 0xffff0000u;
+  h3 = __float_as_uint(r - __uint_as_float(h2)) & 0xffff0000u;
+}
+
+__global__ __launch_bounds__(256) void conv3d_bf16x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                  float* __restrict__ gwp, Bf3WGeom g) {
+  typedef Bf3W C;
+  ICL_DYN_LDS(uint4, lds);
+  uint4* Xs = lds;
+  uint4* Gs = lds + C::XS_U4;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int hf = lq & 1, rsel = lq >> 1;
+  const int ncb = (g.CinP + 15) / 16;
+  const int co0 = (blockIdx.y / ncb) * 16, c0 = (blockIdx.y % ncb) * 16;
+  const long HW = (long)g.H * g.W, DHW = g.D * HW;
+  const int tiles_per = g.ntz * g.nty * g.ntx;
+
+  // ---- staging tables (tile-invariant): item -> (row, half, channel)
+  float xv[C::XR][9], gv[C::GR][8];      // xv[.][8]: the neighbour of the row segment pair (x0 - 1 for half 0, x0 + 16 for half 1)
+  auto tile_origin = [&](int tile, int& b, int& x0, int& y0, int& z0) {
+    b = tile / tiles_per;
+    const int bt = tile % tiles_per;
+    x0 = (bt % g.ntx) * C::TX; y0 = ((bt / g.ntx) % g.nty) * C::TY; z0 = (bt / (g.ntx * g.nty)) * C::TZ;
+  };
+  auto load_tile = [&](int tile) {
+    int b, x0, y0, z0;
+    tile_origin(tile, b, x0, y0, z0);
+    const float* xb = x + (long)b * g.x_bstride + (long)c0 * DHW;
+    const float* gb = gy + (long)b * g.gy_bstride + (long)co0 * DHW;
+#pragma unroll
+    for (int r = 0; r < C::XR; ++r) {
+      const int it = tid + r * C::NT, ci = it & 15, h = (it >> 4) & 1, R = it >> 5;
+      const int gz = z0 - 1 + R / C::PY, gyy = y0 - 1 + R % C::PY, gx = x0 + 8 * h;
+      const bool ok = it < C::XITEMS && c0 + ci < g.Cin && gz >= 0 && gz < g.D && gyy >= 0 && gyy < g.H && gx + 7 < g.W;
+      const float* p = xb + (ok ? (long)ci * DHW + gz * HW + (long)gyy * g.W + gx : 0L);
+      // unconditional loads from an always-valid address (p points at the block's first element when the item is outside), then a
+      // select: straight-line code, all loads of the tile in flight together (a predicated load is a branch per load)
+      const float4 lo = *reinterpret_cast<const float4*>(p);
+      const float4 hi = *reinterpret_cast<const float4*>(p + 4);
+      xv[r][0] = ok ? lo.x : 0.f; xv[r][1] = ok ? lo.y : 0.f; xv[r][2] = ok ? lo.z : 0.f; xv[r][3] = ok ? lo.w : 0.f;
+      xv[r][4] = ok ? hi.x : 0.f; xv[r][5] = ok ? hi.y : 0.f; xv[r][6] = ok ? hi.z : 0.f; xv[r][7] = ok ? hi.w : 0.f;
+      // the element next to the 16-wide row: the aligned quad in front of half 0 / behind half 1 (contiguous with the segment)
+      const int ex = h ? x0 + 16 : x0 - 4;
+      const bool eok = ok && ex >= 0 && ex + 3 < g.W;
+      const float4 e4 = *reinterpret_cast<const float4*>(p + (eok ? (h ? 8 : -4) : 0));
+      xv[r][8] = eok ? (h ? e4.x : e4.w) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < C::GR; ++r) {
+      const int it = tid + r * C::NT, co = it & 15, h = (it >> 4) & 1, row = it >> 5;
+      const int gz = z0 + row / C::TY, gyy = y0 + row % C::TY, gx = x0 + 8 * h;
+      const bool ok = it < C::GITEMS && co0 + co < g.Cout && gz < g.D && gyy < g.H && gx + 7 < g.W;
+      const float* p = gb + (ok ? (long)co * DHW + gz * HW + (long)gyy * g.W + gx : 0L);
+      const float4 lo = *reinterpret_cast<const float4*>(p);
+      const float4 hi = *reinterpret_cast<const float4*>(p + 4);
+      gv[r][0] = ok ? lo.x : 0.f; gv[r][1] = ok ? lo.y : 0.f; gv[r][2] = ok ? lo.z : 0.f; gv[r][3] = ok ? lo.w : 0.f;
+      gv[r][4] = ok ? hi.x : 0.f; gv[r][5] = ok ? hi.y : 0.f; gv[r][6] = ok ? hi.z : 0.f; gv[r][7] = ok ? hi.w : 0.f;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int r = 0; r < C::XR; ++r) {
+      const int it = tid + r * C::NT, ci = it & 15, h = (it >> 4) & 1, R = it >> 5;
+      if (it >= C::XITEMS) continue;
+      uint4 o1, o2, o3;
+      bf3_split8(xv[r], o1, o2, o3);
+      uint4* d = Xs + R * C::XROW + h * 16 + ci;
+      d[0] = o1;
+      d[C::HROWS * C::XROW] = o2;
+      d[2 * C::HROWS * C::XROW] = o3;
+      // edge dword of (row, channel): low half = x0 + 16 (written by the half-1 item), high half = x0 - 1 (half-0 item)
+      unsigned e1, e2, e3;
+      bf3_split1(xv[r][8], e1, e2, e3);
+      unsigned short* e = reinterpret_cast<unsigned short*>(Xs + R * C::XROW + 32) + 2 * ci + (h ? 0 : 1);
+      e[0] = (unsigned short)(e1 >> 16);
+      e[C::HROWS * C::XROW * 8] = (unsigned short)(e2 >> 16);
+      e[2 * C::HROWS * C::XROW * 8] = (unsigned short)(e3 >> 16);
+    }
+#pragma unroll
+    for (int r = 0; r < C::GR; ++r) {
+      const int it = tid + r * C::NT, co = it & 15, h = (it >> 4) & 1, row = it >> 5;
+      if (it >= C::GITEMS) continue;
+      uint4 o1, o2, o3;
+      bf3_split8(gv[r], o1, o2, o3);
+      uint4* d = Gs + row * C::GROW + h * 16 + co;
+      d[0] = o1;
+      d[C::TROWS * C::GROW] = o2;
+      d[2 * C::TROWS * C::GROW] = o3;
+    }
+  };
+
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane pointers: segment of this lane's half, and the dwords holding the neighbours x - 1 (high half) / x + 8 (low half)
+  const unsigned* xdw = reinterpret_cast<const unsigned*>(Xs);
+  const int seg_off = hf * 16 + lr;                                                   // uint4 index inside a row
+  const int prev_off = hf ? (0 * 16 + lr) * 4 + 3 : 32 * 4 + lr;                       // dword index inside a row
+  const int next_off = hf ? 32 * 4 + lr : (1 * 16 + lr) * 4 + 0;
+
+  const int t_begin = blockIdx.x * g.tiles_per_wg;
+  const int t_end = t_begin + g.tiles_per_wg < g.ntiles ? t_begin + g.tiles_per_wg : g.ntiles;
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();
+#if !defined(BF3W_DEBUG) || !(BF3W_DEBUG & 2)
+    store_tile();
+#endif
+    __syncthreads();
+#if !defined(BF3W_DEBUG) || !(BF3W_DEBUG & 4)
+    if (tile + 1 < t_end) load_tile(tile + 1);
+#endif
+#pragma unroll 1
+    for (int kk = 0; kk < C::TROWS / 2 / C::NW; ++kk) {
+      const int rr0 = 2 * (wid + C::NW * kk);             // first tile row of the k-step
+      const int trow = rr0 + rsel;                        // this lane's tile row
+      const int tz = trow / C::TY, ty = trow % C::TY;
+      uint4 a[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) a[s] = Gs[(s * C::TROWS + trow) * C::GROW + hf * 16 + lr];
+      // raw fragments of tap row unit u + 1 are read while unit u is multiplied (one wave per SIMD: nobody else hides the LDS latency)
+      uint4 m[2][3];
+      unsigned pv[2][3], nx[2][3];
+      auto read_unit = [&](int buf, int u) {
+        const int R = (tz + u / 3) * C::PY + ty + u % 3;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int row = (s * C::HROWS + R) * C::XROW;
+          m[buf][s] = Xs[row + seg_off];
+          pv[buf][s] = xdw[row * 4 + prev_off];
+          nx[buf][s] = xdw[row * 4 + next_off];
+        }
+      };
+      read_unit(0, 0);
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const int cur = u & 1;
+        if (u < 8) read_unit(cur ^ 1, u + 1);
+        ICL_SCHED_BARRIER();
+        uint4 b[3][3];                                     // [dx][split]
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          b[0][s] = make_uint4(icl_alignbit(m[cur][s].x, pv[cur][s], 16), icl_alignbit(m[cur][s].y, m[cur][s].x, 16), icl_alignbit(m[cur][s].z, m[cur][s].y, 16),
+                               icl_alignbit(m[cur][s].w, m[cur][s].z, 16));
+          b[1][s] = m[cur][s];
+          b[2][s] = make_uint4(icl_alignbit(m[cur][s].y, m[cur][s].x, 16), icl_alignbit(m[cur][s].z, m[cur][s].y, 16), icl_alignbit(m[cur][s].w, m[cur][s].z, 16),
+                               icl_alignbit(nx[cur][s], m[cur][s].w, 16));
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          // (dY split, x split) of the six terms, smallest first; consecutive MFMAs go to the three dx accumulators
+          constexpr int sa[6] = {2, 1, 0, 1, 0, 0}, sb[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+#if defined(BF3W_DEBUG) && (BF3W_DEBUG & 1)
+          for (int dx = 0; dx < 3; ++dx) acc[u * 3 + dx][0] += __uint_as_float(a[sa[t]].x ^ b[dx][sb[t]].y);
+#else
+          for (int dx = 0; dx < 3; ++dx) acc[u * 3 + dx] = icl_mfma_16x16x32_bf16(a[sa[t]], b[dx][sb[t]], acc[u * 3 + dx]);
+#endif
+        }
+      }
+    }
+  }
+
+  // ---- sum the waves' accumulators through LDS (2 + 1 writers), wave 0 stores the slab
+  float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int step = C::NW / 2; step >= 1; step >>= 1) {
+    __syncthreads();
+    if (wid >= step && wid < 2 * step) {
+      float* d = red + (long)(wid - step) * (27 * 4 * 64) + lane;
+#pragma unroll
+      for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[(t * 4 + r) * 64] = acc[t][r];
+    }
+    __syncthreads();
+    if (wid < step) {
+      const float* d = red + (long)wid * (27 * 4 * 64) + lane;
+#pragma unroll
+      for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += d[(t * 4 + r) * 64];
+    }
+  }
+  if (wid == 0 && c0 + lr < g.CinP) {
+    float* dst = gwp + (long)blockIdx.x * (27L * g.CinP * g.CoutP) + (long)(c0 + lr) * g.CoutP + co0 + 4 * lq;
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+      *reinterpret_cast<float4*>(dst + (long)t * g.CinP * g.CoutP) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
   }
 }
 

@@ -31,6 +31,7 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
+static inline unsigned icl_alignbit(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)((((uint64_t)hi << 32) | lo) >> sh); }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }

@@ -66,12 +66,15 @@ def test_conv3d_wgrad_row_window_kernel(monkeypatch, mode, n, cin, cout, d, h, w
     (2, 32, 20, 5, 9, 20),      # two 16-channel chunks, ragged cout, partial tiles in z / y / x, two samples
     (1, 16, 48, 3, 4, 12),      # three cout blocks per workgroup, a volume smaller than one tile
     (1, 48, 40, 2, 8, 16),      # two cout blocks, the second one ragged; three chunks
+    (2, 20, 12, 5, 9, 24),      # weight gradient on split products (one cout block): ragged cin block, partial tiles in z / y / x
+    (1, 32, 16, 4, 8, 16),      # weight gradient: two cin blocks, forward and input gradient split as well
 ])
 def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w):
     """conv_bf16x3.h: forward and input gradient with each fp32 operand split exactly into three bf16 terms (six bf16 MFMA terms per
     product, fp32 accumulation) — same tolerance as the fp32-MFMA kernels, and the two paths agree to fp32 rounding."""
     monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
     monkeypatch.setenv("ICL_CONV_SPLIT", "1")
+    monkeypatch.setenv("ICL_WGRAD_SPLIT", "1")      # the (opt-in) split-product weight gradient for single-cout-block layers
     _conv_check(n, cin, cout, d, h, w, 3)
     x = _rand((n, cin, d, h, w), 11)
     wt = _rand((cout, cin, 3, 3, 3), 12) * 0.2
