@@ -275,4 +275,138 @@ __global__ __launch_bounds__(256) void sgd_factored_kernel(float* __restrict__ p
   }
 }
 
+// ------------------------------------------------------------------------------------------------ factored update, split products
+// d = g^T x of the many-row case (gathered factors of a data-parallel step: M = rows per rank x ranks; nc = 16: 64 / 128 rows) is the
+// fp32-MFMA part of sgd_factored_kernel and makes it compute-bound from ~64 rows (0.86 ms at M = 128 against 0.54 ms of pure
+// streaming).  Here the products come from the bf16 matrix pipe with exact three-way splits of both factors (six MFMA terms per
+// product, fp32 accumulation: fp32 accuracy, see kernels/conv_bf16x3.h): a 32-row chunk is ONE k = 32 MFMA step.
+//
+// factor_split_kernel: g [M][N], x [M][K] -> gs / xs [split 3][row block MB = ceil(M / 8)][column] of 8 packed bf16 (the 8 rows of the
+// block for one column: the k-contiguous 16 bytes an MFMA lane group needs); rows >= M are zero.
+__global__ __launch_bounds__(256) void factor_split_kernel(const float* __restrict__ g, const float* __restrict__ x, uint4* __restrict__ gs,
+                                                           uint4* __restrict__ xs, int M, int N, int K) {
+  const int MB = (M + 7) / 8;
+  const long total = (long)MB * (N + K);
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const int mb = (int)(it / (N + K)), c = (int)(it % (N + K));
+    const bool isx = c >= N;
+    const int col = isx ? c - N : c, ld = isx ? K : N;
+    const float* src = (isx ? x : g) + col;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 8 * mb + j < M ? src[(long)(8 * mb + j) * ld] : 0.f;
+    uint4 o1, o2, o3;
+    bf3_split8(v, o1, o2, o3);
+    uint4* d = (isx ? xs : gs) + (long)mb * ld + col;
+    const long plane = (long)MB * ld;
+    d[0] = o1;
+    d[plane] = o2;
+    d[2 * plane] = o3;
+  }
+}
+
+// Same block structure, grid and update stream as sgd_factored_kernel; the operand slices of a 32-row chunk (4 row blocks x 3 splits:
+// 48 KB of x, 12 KB of g) alias the d-tile buffer.  K % 4 == 0.
+__global__ __launch_bounds__(256) void sgd_factored_split_kernel(float* __restrict__ p, float* __restrict__ mom, const uint4* __restrict__ gs,
+                                                                 const uint4* __restrict__ xs, int M, int N, int K, float lr, float momentum,
+                                                                 float wd, int first, const float* __restrict__ lr_dev) {
+  ICL_DYN_LDS(float, lds);
+  uint4* xl = reinterpret_cast<uint4*>(lds);              // [split 3][row block 4][column 256]
+  uint4* gl = xl + 3 * 4 * kSfCols;                       // [split 3][row block 4][row n 64]
+  static_assert((3 * 4 * kSfCols + 3 * 4 * kSfRows) * 16 <= kSfLdsFloats * 4, "operand slices must fit in the d-tile buffer");
+  if (lr_dev) lr = *lr_dev;
+  const int n0 = blockIdx.y * kSfRows, k0 = blockIdx.x * kSfCols;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr_ = lane & 15, lg = lane >> 4;
+  const int wc = wid * 64;
+  const int MB = (M + 7) / 8;
+  const long xplane = (long)MB * K, gplane = (long)MB * N;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int XV = 3 * 4 * kSfCols / 256, GV = 3 * 4 * kSfRows / 256;      // 12 + 3 uint4 per thread and chunk
+  uint4 xv[XV], gv[GV];
+  auto fetch = [&](int mb0) {
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int it = threadIdx.x + j * 256, c = it % kSfCols, sb = it / kSfCols, blk = sb % 4, s = sb / 4;
+      const bool ok = mb0 + blk < MB && k0 + c < K;
+      xv[j] = xs[ok ? s * xplane + (long)(mb0 + blk) * K + k0 + c : 0L];
+      if (!ok) xv[j] = make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int it = threadIdx.x + j * 256, r = it % kSfRows, sb = it / kSfRows, blk = sb % 4, s = sb / 4;
+      const bool ok = mb0 + blk < MB && n0 + r < N;
+      gv[j] = gs[ok ? s * gplane + (long)(mb0 + blk) * N + n0 + r : 0L];
+      if (!ok) gv[j] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  fetch(0);
+  for (int mb0 = 0; mb0 < MB; mb0 += 4) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < XV; ++j) xl[threadIdx.x + j * 256] = xv[j];
+#pragma unroll
+    for (int j = 0; j < GV; ++j) gl[threadIdx.x + j * 256] = gv[j];
+    __syncthreads();
+    if (mb0 + 4 < MB) fetch(mb0 + 4);
+    // one MFMA k-step: lane group lg = row block of the chunk; A[n][rows] = g, B[rows][k] = x
+    uint4 af[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) af[a][s] = gl[(s * 4 + lg) * kSfRows + a * 16 + lr_];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      uint4 bf[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) bf[s] = xl[(s * 4 + lg) * kSfCols + wc + b * 16 + lr_];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        constexpr int sa[6] = {2, 1, 0, 1, 0, 0}, sb[6] = {0, 1, 2, 0, 1, 0};     // smallest terms first
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][b] = icl_mfma_16x16x32_bf16(af[a][sa[t]], bf[sb[t]], acc[a][b]);
+      }
+    }
+  }
+  // d block -> LDS (row-major), then the streaming update (as sgd_factored_kernel)
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[(a * 16 + lg * 4 + r) * kSfDp + wc + b * 16 + lr_] = acc[a][b][r];
+  __syncthreads();
+  const int kq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  if (k0 + kq * 4 >= K) return;
+  constexpr int RB = 8;
+#pragma unroll
+  for (int j0 = 0; j0 < kSfRows / 4; j0 += RB) {
+    float4 pv[RB], mv[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int n = n0 + rl + 4 * (j0 + j);
+      pv[j] = mv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) {
+        const long idx = (long)n * K + k0 + kq * 4;
+        pv[j] = icl_nt_load4(p + idx);
+        if (!first) mv[j] = icl_nt_load4(mom + idx);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int row = rl + 4 * (j0 + j), n = n0 + row;
+      if (n >= N) continue;
+      const long idx = (long)n * K + k0 + kq * 4;
+      const float4 d = *reinterpret_cast<const float4*>(lds + row * kSfDp + kq * 4);
+      sgd_update4(pv[j], d, mv[j], lr, momentum, wd, first);
+      icl_nt_store4(p + idx, pv[j]);
+      icl_nt_store4(mom + idx, mv[j]);
+    }
+  }
+}
+
 }  // namespace icl

@@ -8,12 +8,15 @@ trainers' ``for g in optimizer.param_groups: g['lr'] = lr_`` schedule (:117-119)
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
 from . import _lib
 
 _BIG = 1 << 20
+SPLIT_MIN_ROWS = 192    # factor rows from which d = g^T x runs on split products (tools/sgd_probe.py, 13,824^2: 128 rows 769 -> 720 us
+                        # but +2 small launches: a wash inside the step; 256 rows 1244 -> 1029 us, 512 rows 2158 -> 1770 us)
 
 
 class FusedSGD(torch.optim.Optimizer):
@@ -59,9 +62,17 @@ class FusedSGD(torch.optim.Optimizer):
             n = r1 - r0
         g, x = g.contiguous(), x.contiguous()
         from . import ops   # KernelTimer bracket: the update streams p and m in and out (16 B per weight), HBM-bound
-        with ops._timed("sgd_factored_kernel", 2.0 * g.shape[0] * n * k, 16.0 * n * k, p):
-            _lib.check(L.icl_sgd_step_factored(pv.data_ptr(), mv.data_ptr(), g.data_ptr(), x.data_ptr(), g.shape[0], n, k, lr, mom, wd,
-                                               first, lrp, stream), "sgd_step_factored")
+        rows = g.shape[0]
+        with ops._timed("sgd_factored_kernel", 2.0 * rows * n * k, 16.0 * n * k, p):
+            if rows >= SPLIT_MIN_ROWS and (n * k) >= (1 << 22) and os.environ.get("ICL_SGD_SPLIT", "1") != "0":
+                # many factor rows (gathered factors of a data-parallel step; nc = 16): d = g^T x from exact bf16 splits on the bf16
+                # matrix pipe (csrc/kernels/optim.h sgd_factored_split_kernel) so that the update stays an HBM stream
+                ws = ops._ws(L.icl_sgd_factored_split_ws_bytes(rows, n, k), p)
+                _lib.check(L.icl_sgd_step_factored_split(pv.data_ptr(), mv.data_ptr(), g.data_ptr(), x.data_ptr(), ws.data_ptr(), rows, n, k,
+                                                         lr, mom, wd, first, lrp, stream), "sgd_step_factored_split")
+            else:
+                _lib.check(L.icl_sgd_step_factored(pv.data_ptr(), mv.data_ptr(), g.data_ptr(), x.data_ptr(), rows, n, k, lr, mom, wd,
+                                                   first, lrp, stream), "sgd_step_factored")
 
     def can_update_in_backward(self, p, rows: int) -> bool:
         n, k = p.shape

@@ -474,6 +474,32 @@ def test_factored_gradient_sgd_matches_dense(monkeypatch, rows1):
     assert lin.weight.grad is not None and lin.weight._icl_factors is None
 
 
+@pytest.mark.parametrize("rows,n,k,first", [(70, 70, 300, 0), (128, 130, 264, 1), (33, 64, 256, 0)])
+def test_factored_sgd_on_split_products(rows, n, k, first):
+    """icl_sgd_step_factored_split (gathered factors / nc = 16: many rows): d = g^T x from exact three-way bf16 splits on the bf16
+    matrix pipe, then the SGD rule — against fp64, with the tolerance of the fp32-MFMA kernel; ragged row block, partial 64-row and
+    256-column blocks, momentum initialisation."""
+    L = _lib.lib()
+    g, x = _rand((rows, n), 201) * 0.3, _rand((rows, k), 202)
+    p0, m0 = _rand((n, k), 203) * 0.05, _rand((n, k), 204) * 0.01
+    lr, mom, wd = 0.02, 0.9, 1e-3
+    p, m = p0.clone(), (torch.full_like(m0, float("nan")) if first else m0.clone())
+    ws = torch.empty(max(1, L.icl_sgd_factored_split_ws_bytes(rows, n, k) // 4))
+    rc = L.icl_sgd_step_factored_split(p.data_ptr(), m.data_ptr(), g.data_ptr(), x.data_ptr(), ws.data_ptr(), rows, n, k, lr, mom, wd, first,
+                                       None, None)
+    assert rc == 0, _lib.last_error()
+    d = g.double().t() @ x.double() + wd * p0.double()
+    m_ref = d if first else mom * m0.double() + d
+    p_ref = p0.double() - lr * m_ref
+    assert rel_err(m, m_ref.float()) < 2e-6
+    assert float((p - p_ref.float()).abs().max()) < 2e-6 * float(p_ref.abs().max()) + 1e-7
+    # and the fp32-MFMA kernel on the same data is no closer
+    p2, m2 = p0.clone(), (torch.full_like(m0, float("nan")) if first else m0.clone())
+    assert L.icl_sgd_step_factored(p2.data_ptr(), m2.data_ptr(), g.data_ptr(), x.data_ptr(), rows, n, k, lr, mom, wd, first, None, None) == 0
+    e_split, e_fp32 = float((m.double() - m_ref).abs().max()), float((m2.double() - m_ref).abs().max())
+    assert e_split <= 4.0 * e_fp32 + 1e-7 * float(m_ref.abs().max()), (e_split, e_fp32)
+
+
 def test_layernorm_gelu():
     x = (_rand((3, 5, 37), 61) * 2 + 0.3).requires_grad_()
     w = (1 + 0.1 * _rand((37,), 62)).requires_grad_()
