@@ -281,6 +281,8 @@ def main():
                     "peak_basis": (f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} / {SPLIT_TERMS} terms per fp32 product"
                                    if split else "dense fp32 MFMA peak"),
                     "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    **({"launch_note": "a timed launch = conv_bf16x3_split_weights_kernel (2-5 us) + the convolution kernel; rocprofv3 "
+                                       "lists them separately (profiles/r2_bench_kernel_stats.csv)"} if split else {}),
                     "traffic": traffic["hbm_bytes"] if traffic else None, "traffic_detail": traffic,
                     # PMC (profiles/r2_pmc_conv.md, static): fraction of the kernel's cycles with the matrix pipe busy; the rest of
                     # the gap to the 2.4 GHz peak is the clock the chip holds under matrix load (1.8-2.1 GHz)
