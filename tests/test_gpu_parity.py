@@ -909,7 +909,7 @@ def test_split_bf16_weight_gradient_opt_in(dev, monkeypatch):
         with ops.KernelTimer():
             wg = w.to(dev).requires_grad_()
             ops.conv3d(x.to(dev), wg, None).backward(gy.to(dev))
-        name = _lib_last_kernel()
+        assert ("bf16x3_wgrad" in _lib_last_kernel()) == (split == "1"), _lib_last_kernel()     # the path under test really ran
         errs[split] = float((wg.grad.cpu().double() - wr.grad).abs().max() / wr.grad.abs().max())
     assert errs["1"] < 5e-6 and errs["1"] <= 3.0 * errs["0"] + 2e-7, errs
 
