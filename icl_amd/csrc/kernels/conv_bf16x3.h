@@ -13,7 +13,7 @@
 // pair, channels 8 (lq & 1) .. + 7.  Both operands are therefore kept "8 channels contiguous" (16 bytes of bf16) in LDS and every
 // operand fragment is ONE ds_read_b128:
 //   Xs[split 3][half 2][position][8 ch]   halo tile of (TZ+2) x (TY+2) x 18 positions of a 16-channel chunk
-//   Ws[split 3][half 2][slot 10][cout][8 ch]   the 9 taps of one dz plane (5 pairs, slot 9 is zero) for the cout block
+//   Ws[split 3][half 2][slot 10][cout][8 ch]   ten consecutive taps (one of three stages: 27 taps + a zero slot = 14 pairs) for the cout block
 // The fp32 NCDHW input is split and transposed while it is staged (a thread reads one position of 8 channel planes, 3 ds_write_b128);
 // the weights come from the fp32 pack of the fp32 kernels (PackedWeights), split by a small kernel in front of the convolution.  A workgroup (8 waves) owns output tiles of 4 x 8 x 16 voxels and
 // walks a list of tiles; the global loads of the next (tile, channel chunk) are in flight while the current one is multiplied.
@@ -63,8 +63,9 @@ __device__ __forceinline__ void bf3_split8(const float* v, uint4& o1, uint4& o2,
   o3 = make_uint4((h3[0] >> 16) | h3[1], (h3[2] >> 16) | h3[3], (h3[4] >> 16) | h3[5], (h3[6] >> 16) | h3[7]);
 }
 
-// Split weights, ready for LDS: ws[chunk][dz][split * 2 + half][slot 10][CoutP] of 8 packed bf16, from the fp32 pack wp[tap][CinP][CoutP]
-// of the fp32 kernels (slot = tap within its dz plane; slot 9 is the zero partner of the ninth tap).  One small launch in front of
+// Split weights, ready for LDS: ws[chunk][stage 3][split * 2 + half][slot 10][CoutP] of 8 packed bf16, from the fp32 pack
+// wp[tap][CinP][CoutP] of the fp32 kernels: slot s of stage g is tap 10 g + s; the 28th slot (stage 2, slot 7) is the zero partner of
+// tap 26, slots 8 / 9 of stage 2 are unused.  One small launch in front of
 // the convolution (the matrices are 7 KB .. 1.3 MB): splitting them inside the convolution, once per tile and dz plane, cost as
 // many VALU instructions as splitting the activations.
 __global__ __launch_bounds__(256) void conv_bf16x3_split_weights_kernel(const float* __restrict__ wp, uint4* __restrict__ ws, int cinP, int coutP,
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_bf16x3_split_weights_kernel(const fl
     const int dz = (int)(r % 3), chunk = (int)(r / 3);
     float v[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) v[c] = slot < 9 ? wp[((long)(dz * 9 + slot) * cinP + chunk * 16 + hf * 8 + c) * coutP + co] : 0.f;
+    for (int c = 0; c < 8; ++c) v[c] = 10 * dz + slot < 27 ? wp[((long)(10 * dz + slot) * cinP + chunk * 16 + hf * 8 + c) * coutP + co] : 0.f;
     uint4 o1, o2, o3;
     bf3_split8(v, o1, o2, o3);
     const long plane = (long)Bf3::SLOTS * coutP;
@@ -173,8 +174,6 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   const int wz = (4 * wid) / TY, wy = (4 * wid) % TY;
   const int lanepos = (wz * PY + wy) * PX + lr;
   const uint4* xa = Xs + half * NPOSP + lanepos;        // + split * 2 * NPOSP + tap offset
-  const uint4* xa1 = xa + tp;                            // pairs whose second tap is one position further
-  const uint4* xa16 = xa + tp * 16;                      // the (dy0 dx2, dy1 dx0) pair: 16 positions further
   const uint4* wb = Ws + (half * Bf3::SLOTS + tp) * NB + lr;
 
   f32x4 acc[4][NBT];
@@ -212,11 +211,13 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       if (dz < 2) load_w(chunk, dz + 1);
       else if (ntile < g.ntiles) load_w(nchunk, 0);
       if (dz == 0 && ntile < g.ntiles) load_x(ntile, nchunk);
-      const int zo = dz * PY * PX;
+      // stage dz holds the tap slots 10 dz .. 10 dz + 9 (27 taps + one zero slot = 14 pairs in stages of 5 / 5 / 4: a pair may
+      // straddle two dz planes); lane group tp takes the first or the second tap of the pair: its halo offset is a select
 #pragma unroll
-      for (int pair = 0; pair < 5; ++pair) {
-        constexpr int offA[5] = {0, 2, PX + 1, 2 * PX, 2 * PX + 2};
-        const uint4* xp = (pair == 1 ? xa16 : xa1) + zo + offA[pair];
+      for (int pair = 0; pair < (dz < 2 ? 5 : 4); ++pair) {
+        const int tA = 10 * dz + 2 * pair, tB = tA + 1 < 27 ? tA + 1 : 26;      // the zero slot multiplies any valid position
+        const int offA = (tA / 9) * PY * PX + ((tA / 3) % 3) * PX + tA % 3, offB = (tB / 9) * PY * PX + ((tB / 3) % 3) * PX + tB % 3;
+        const uint4* xp = xa + (tp ? offB : offA);
         // all operand fragments of the pair first, then its 24 NBT MFMAs: the other wave of the SIMD multiplies while this one waits
         uint4 b[3][NBT], a[4][3];
 #pragma unroll
