@@ -294,14 +294,19 @@ struct Bf3WGeom {
   long x_bstride, gy_bstride;
 };
 
-struct Bf3W {
-  static constexpr int TZ = 4, TY = 8, TX = 16, PZ = 6, PY = 10, HROWS = PZ * PY, TROWS = TZ * TY, NW = 4, NT = 256;
-  static constexpr int XROW = 36, GROW = 32;                         // uint4 per row: 2 x 16 segments (+ 16 edge dwords)
+// NCB cout blocks of 16 per workgroup (every staged x value then feeds NCB x 27 x 6 MFMA terms) on a TZ x 8 x 16 voxel tile:
+// <1, 4>: 152 KB of LDS, 108 accumulator registers; <2, 2>: 118 KB, 216 accumulator registers (AGPRs).
+template <int NCB_, int TZ_>
+struct Bf3WT {
+  static constexpr int NCB = NCB_, TZ = TZ_, TY = 8, TX = 16, PZ = TZ + 2, PY = 10, HROWS = PZ * PY, TROWS = TZ * TY, NW = 4, NT = 256;
+  static constexpr int XROW = 36, GROW = 32 * NCB;                   // uint4 per row: 2 x 16 segments (+ 16 edge dwords) / 2 x 16 NCB
   static constexpr int XS_U4 = 3 * HROWS * XROW, GS_U4 = 3 * TROWS * GROW;
   static constexpr size_t LDS_BYTES = (size_t)(XS_U4 + GS_U4) * 16;
-  static constexpr int XITEMS = HROWS * 32, GITEMS = TROWS * 32;
+  static constexpr int XITEMS = HROWS * 32, GITEMS = TROWS * GROW;
   static constexpr int XR = (XITEMS + NT - 1) / NT, GR = (GITEMS + NT - 1) / NT;
+  static_assert((size_t)(NW / 2) * 27 * 4 * NCB * 64 * 4 <= LDS_BYTES, "the cross-wave sum must fit in the tile buffers");
 };
+typedef Bf3WT<1, 4> Bf3W;
 
 // one fp32 -> its three bf16 terms as the high halves of three dwords
 __device__ __forceinline__ void bf3_split1(float v, unsigned& h1, unsigned& h2, unsigned& h3) {
@@ -311,16 +316,17 @@ __device__ __forceinline__ void bf3_split1(float v, unsigned& h1, unsigned& h2, 
   h3 = __float_as_uint(r - __uint_as_float(h2)) & 0xffff0000u;
 }
 
+template <int NCB, int TZ>
 __global__ __launch_bounds__(256) void conv3d_bf16x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                   float* __restrict__ gwp, Bf3WGeom g) {
-  typedef Bf3W C;
+  typedef Bf3WT<NCB, TZ> C;
   ICL_DYN_LDS(uint4, lds);
   uint4* Xs = lds;
   uint4* Gs = lds + C::XS_U4;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lq = lane >> 4;
   const int hf = lq & 1, rsel = lq >> 1;
   const int ncb = (g.CinP + 15) / 16;
-  const int co0 = (blockIdx.y / ncb) * 16, c0 = (blockIdx.y % ncb) * 16;
+  const int co0 = (blockIdx.y / ncb) * 16 * NCB, c0 = (blockIdx.y % ncb) * 16;
   const long HW = (long)g.H * g.W, DHW = g.D * HW;
   const int tiles_per = g.ntz * g.nty * g.ntx;
 
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_wgrad_kernel(const float* _
     }
 #pragma unroll
     for (int r = 0; r < C::GR; ++r) {
-      const int it = tid + r * C::NT, co = it & 15, h = (it >> 4) & 1, row = it >> 5;
+      const int it = tid + r * C::NT, co = it % (16 * NCB), h = (it / (16 * NCB)) & 1, row = it / (32 * NCB);
       const int gz = z0 + row / C::TY, gyy = y0 + row % C::TY, gx = x0 + 8 * h;
       const bool ok = it < C::GITEMS && co0 + co < g.Cout && gz < g.D && gyy < g.H && gx + 7 < g.W;
       const float* p = gb + (ok ? (long)co * DHW + gz * HW + (long)gyy * g.W + gx : 0L);
@@ -387,20 +393,22 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_wgrad_kernel(const float* _
     }
 #pragma unroll
     for (int r = 0; r < C::GR; ++r) {
-      const int it = tid + r * C::NT, co = it & 15, h = (it >> 4) & 1, row = it >> 5;
+      const int it = tid + r * C::NT, co = it % (16 * NCB), h = (it / (16 * NCB)) & 1, row = it / (32 * NCB);
       if (it >= C::GITEMS) continue;
       uint4 o1, o2, o3;
       bf3_split8(gv[r], o1, o2, o3);
-      uint4* d = Gs + row * C::GROW + h * 16 + co;
+      uint4* d = Gs + row * C::GROW + h * 16 * NCB + co;
       d[0] = o1;
       d[C::TROWS * C::GROW] = o2;
       d[2 * C::TROWS * C::GROW] = o3;
     }
   };
 
-  f32x4 acc[27];
+  f32x4 acc[NCB][27];
 #pragma unroll
-  for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // lane pointers: segment of this lane's half, and the dwords holding the neighbours x - 1 (high half) / x + 8 (low half)
   const unsigned* xdw = reinterpret_cast<const unsigned*>(Xs);
@@ -425,9 +433,11 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_wgrad_kernel(const float* _
       const int rr0 = 2 * (wid + C::NW * kk);             // first tile row of the k-step
       const int trow = rr0 + rsel;                        // this lane's tile row
       const int tz = trow / C::TY, ty = trow % C::TY;
-      uint4 a[3];
+      uint4 a[NCB][3];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) a[s] = Gs[(s * C::TROWS + trow) * C::GROW + hf * 16 + lr];
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a[cb][s] = Gs[(s * C::TROWS + trow) * C::GROW + hf * 16 * NCB + cb * 16 + lr];
       // raw fragments of tap row unit u + 1 are read while unit u is multiplied (one wave per SIMD: nobody else hides the LDS latency)
       uint4 m[2][3];
       unsigned pv[2][3], nx[2][3];
@@ -461,10 +471,13 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_wgrad_kernel(const float* _
           // (dY split, x split) of the six terms, smallest first; consecutive MFMAs go to the three dx accumulators
           constexpr int sa[6] = {2, 1, 0, 1, 0, 0}, sb[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
 #if defined(BF3W_DEBUG) && (BF3W_DEBUG & 1)
-          for (int dx = 0; dx < 3; ++dx) acc[u * 3 + dx][0] += __uint_as_float(a[sa[t]].x ^ b[dx][sb[t]].y);
+              acc[cb][u * 3 + dx][0] += __uint_as_float(a[cb][sa[t]].x ^ b[dx][sb[t]].y);
 #else
-          for (int dx = 0; dx < 3; ++dx) acc[u * 3 + dx] = icl_mfma_16x16x32_bf16(a[sa[t]], b[dx][sb[t]], acc[u * 3 + dx]);
+              acc[cb][u * 3 + dx] = icl_mfma_16x16x32_bf16(a[cb][sa[t]], b[dx][sb[t]], acc[cb][u * 3 + dx]);
 #endif
         }
       }
@@ -477,26 +490,34 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_wgrad_kernel(const float* _
   for (int step = C::NW / 2; step >= 1; step >>= 1) {
     __syncthreads();
     if (wid >= step && wid < 2 * step) {
-      float* d = red + (long)(wid - step) * (27 * 4 * 64) + lane;
+      float* d = red + (long)(wid - step) * (NCB * 27 * 4 * 64) + lane;
 #pragma unroll
-      for (int t = 0; t < 27; ++t)
+      for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[(t * 4 + r) * 64] = acc[t][r];
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d[((cb * 27 + t) * 4 + r) * 64] = acc[cb][t][r];
     }
     __syncthreads();
     if (wid < step) {
-      const float* d = red + (long)wid * (27 * 4 * 64) + lane;
+      const float* d = red + (long)wid * (NCB * 27 * 4 * 64) + lane;
 #pragma unroll
-      for (int t = 0; t < 27; ++t)
+      for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] += d[(t * 4 + r) * 64];
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[cb][t][r] += d[((cb * 27 + t) * 4 + r) * 64];
     }
   }
   if (wid == 0 && c0 + lr < g.CinP) {
     float* dst = gwp + (long)blockIdx.x * (27L * g.CinP * g.CoutP) + (long)(c0 + lr) * g.CoutP + co0 + 4 * lq;
 #pragma unroll
-    for (int t = 0; t < 27; ++t)
-      *reinterpret_cast<float4*>(dst + (long)t * g.CinP * g.CoutP) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int t = 0; t < 27; ++t)
+        if (co0 + cb * 16 < g.CoutP)
+          *reinterpret_cast<float4*>(dst + (long)t * g.CinP * g.CoutP + cb * 16) =
+              make_float4(acc[cb][t][0], acc[cb][t][1], acc[cb][t][2], acc[cb][t][3]);
   }
 }
 

@@ -893,11 +893,12 @@ def test_split_bf16_convolution_is_as_accurate_as_the_fp32_mfma_path(dev, monkey
 
 
 @pytest.mark.gpu
-def test_split_bf16_weight_gradient_opt_in(dev, monkeypatch):
-    """conv3d_bf16x3_wgrad_kernel (ICL_WGRAD_SPLIT=1, experimental): the weight gradient of a 16-channel layer from split products is
-    as close to the fp64 gradient as the fp32-MFMA kernels' (both sum 110,592 voxels per element in fp32)."""
+@pytest.mark.parametrize("cin,cout", [(32, 16), (32, 32), (16, 64)])
+def test_split_bf16_weight_gradient(dev, monkeypatch, cin, cout):
+    """conv3d_bf16x3_wgrad_kernel<1, 4> / <2, 2> (ICL_WGRAD_SPLIT=1, the default): the weight gradient from split products is as close
+    to the fp64 gradient as the fp32-MFMA kernels' (both sum 110,592 voxels per element in fp32)."""
     from icl_amd import ops
-    cin, cout, r = 32, 16, 48
+    r = 48
     x = synthetic_volume((1, cin, r, r, r), 311)
     w = synthetic_volume((cout, cin, 3, 3, 3), 312) * 0.1
     gy = synthetic_volume((1, cout, r, r, r), 313)

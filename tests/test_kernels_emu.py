@@ -68,13 +68,15 @@ def test_conv3d_wgrad_row_window_kernel(monkeypatch, mode, n, cin, cout, d, h, w
     (1, 48, 40, 2, 8, 16),      # two cout blocks, the second one ragged; three chunks
     (2, 20, 12, 5, 9, 24),      # weight gradient on split products (one cout block): ragged cin block, partial tiles in z / y / x
     (1, 32, 16, 4, 8, 16),      # weight gradient: two cin blocks, forward and input gradient split as well
+    (1, 20, 32, 3, 9, 24),      # weight gradient with two cout blocks per workgroup (2 x 8 x 16 tiles): ragged cin block, partial tiles
+    (2, 16, 60, 2, 8, 16),      # ... two such workgroup columns, the last cout block ragged (60 -> 64), two samples
 ])
 def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w):
     """conv_bf16x3.h: forward and input gradient with each fp32 operand split exactly into three bf16 terms (six bf16 MFMA terms per
     product, fp32 accumulation) — same tolerance as the fp32-MFMA kernels, and the two paths agree to fp32 rounding."""
     monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
     monkeypatch.setenv("ICL_CONV_SPLIT", "1")
-    monkeypatch.setenv("ICL_WGRAD_SPLIT", "1")      # the (opt-in) split-product weight gradient for single-cout-block layers
+    monkeypatch.setenv("ICL_WGRAD_SPLIT", "1")      # split-product weight gradient: 16-cout layers and layers with Cout % 32 == 0
     _conv_check(n, cin, cout, d, h, w, 3)
     x = _rand((n, cin, d, h, w), 11)
     wt = _rand((cout, cin, 3, 3, 3), 12) * 0.2

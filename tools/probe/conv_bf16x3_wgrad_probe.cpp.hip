@@ -22,9 +22,10 @@ int main(int argc, char** argv) {
   for (auto& v : hg) v = rnd() * 0.01f;
   icl::Bf3WGeom g{};
   g.Cin = cin; g.Cout = cout; g.CinP = (cin + 15) / 16 * 16; g.CoutP = (cout + 15) / 16 * 16; g.D = D; g.H = H; g.W = W;
-  g.ntz = (D + 3) / 4; g.nty = (H + 7) / 8; g.ntx = (W + 15) / 16; g.ntiles = N * g.ntz * g.nty * g.ntx;
-  const int pairs = (g.CinP / 16) * (g.CoutP / 16);
-  int nsplit = argc > 4 ? atoi(argv[4]) : (256 + pairs - 1) / pairs;
+  const int ncbk = argc > 5 ? atoi(argv[5]) : (g.CoutP % 32 == 0 ? 2 : 1), tz = ncbk == 2 ? 2 : 4;
+  g.ntz = (D + tz - 1) / tz; g.nty = (H + 7) / 8; g.ntx = (W + 15) / 16; g.ntiles = N * g.ntz * g.nty * g.ntx;
+  const int pairs = (g.CinP / 16) * ((g.CoutP + 16 * ncbk - 1) / (16 * ncbk));
+  int nsplit = argc > 4 && atoi(argv[4]) > 0 ? atoi(argv[4]) : (256 + pairs - 1) / pairs;
   if (nsplit > g.ntiles) nsplit = g.ntiles;
   g.tiles_per_wg = (g.ntiles + nsplit - 1) / nsplit;
   nsplit = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
@@ -35,8 +36,13 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dg, hg.data(), hg.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemset(dslab, 0xff, (size_t)nsplit * pe * 4));
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_bf16x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)icl::Bf3W::LDS_BYTES));
-  auto go = [&]() { hipLaunchKernelGGL(icl::conv3d_bf16x3_wgrad_kernel, dim3(nsplit, pairs), dim3(256), icl::Bf3W::LDS_BYTES, 0, dx, dg, dslab, g); };
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_bf16x3_wgrad_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)icl::Bf3WT<1, 4>::LDS_BYTES));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_bf16x3_wgrad_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)icl::Bf3WT<2, 2>::LDS_BYTES));
+  const size_t lds1 = icl::Bf3WT<1, 4>::LDS_BYTES, lds2 = icl::Bf3WT<2, 2>::LDS_BYTES;
+  auto go = [&]() {
+    if (ncbk == 2) hipLaunchKernelGGL((icl::conv3d_bf16x3_wgrad_kernel<2, 2>), dim3(nsplit, pairs), dim3(256), lds2, 0, dx, dg, dslab, g);
+    else hipLaunchKernelGGL((icl::conv3d_bf16x3_wgrad_kernel<1, 4>), dim3(nsplit, pairs), dim3(256), lds1, 0, dx, dg, dslab, g);
+  };
   go();
   CK(hipDeviceSynchronize());
   CK(hipGetLastError());
