@@ -304,7 +304,7 @@ struct Bf3WT {
   static constexpr size_t LDS_BYTES = (size_t)(XS_U4 + GS_U4) * 16;
   static constexpr int XITEMS = HROWS * 32, GITEMS = TROWS * GROW;
   static constexpr int XR = (XITEMS + NT - 1) / NT, GR = (GITEMS + NT - 1) / NT;
-  static_assert((size_t)(NW / 2) * 27 * 4 * NCB * 64 * 4 <= LDS_BYTES, "the cross-wave sum must fit in the tile buffers");
+  static_assert((size_t)(NW / 2) * 27 * 4 * 64 * 4 <= LDS_BYTES, "the cross-wave sum (one cout block at a time) must fit in the tile buffers");
 };
 typedef Bf3WT<1, 4> Bf3W;
 
@@ -484,29 +484,28 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_wgrad_kernel(const float* _
     }
   }
 
-  // ---- sum the waves' accumulators through LDS (2 + 1 writers), wave 0 stores the slab
+  // ---- sum the waves' accumulators through LDS (2 + 1 writers, one cout block at a time), wave 0 stores the slab
   float* red = reinterpret_cast<float*>(lds);
 #pragma unroll
   for (int step = C::NW / 2; step >= 1; step >>= 1) {
-    __syncthreads();
-    if (wid >= step && wid < 2 * step) {
-      float* d = red + (long)(wid - step) * (NCB * 27 * 4 * 64) + lane;
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int t = 0; t < 27; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) d[((cb * 27 + t) * 4 + r) * 64] = acc[cb][t][r];
-    }
-    __syncthreads();
-    if (wid < step) {
-      const float* d = red + (long)wid * (NCB * 27 * 4 * 64) + lane;
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
+    for (int cb = 0; cb < NCB; ++cb) {
+      __syncthreads();
+      if (wid >= step && wid < 2 * step) {
+        float* d = red + (long)(wid - step) * (27 * 4 * 64) + lane;
 #pragma unroll
         for (int t = 0; t < 27; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[cb][t][r] += d[((cb * 27 + t) * 4 + r) * 64];
+          for (int r = 0; r < 4; ++r) d[(t * 4 + r) * 64] = acc[cb][t][r];
+      }
+      __syncthreads();
+      if (wid < step) {
+        const float* d = red + (long)wid * (27 * 4 * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[cb][t][r] += d[(t * 4 + r) * 64];
+      }
     }
   }
   if (wid == 0 && c0 + lr < g.CinP) {

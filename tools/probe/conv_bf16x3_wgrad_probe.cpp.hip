@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
   for (auto& v : hg) v = rnd() * 0.01f;
   icl::Bf3WGeom g{};
   g.Cin = cin; g.Cout = cout; g.CinP = (cin + 15) / 16 * 16; g.CoutP = (cout + 15) / 16 * 16; g.D = D; g.H = H; g.W = W;
-  const int ncbk = argc > 5 ? atoi(argv[5]) : (g.CoutP % 32 == 0 ? 2 : 1), tz = ncbk == 2 ? 2 : 4;
+  const int ncbk = argc > 5 ? atoi(argv[5]) : (g.CoutP % 32 == 0 ? 2 : 1), tz = ncbk >= 2 ? 2 : 4;
   g.ntz = (D + tz - 1) / tz; g.nty = (H + 7) / 8; g.ntx = (W + 15) / 16; g.ntiles = N * g.ntz * g.nty * g.ntx;
   const int pairs = (g.CinP / 16) * ((g.CoutP + 16 * ncbk - 1) / (16 * ncbk));
   int nsplit = argc > 4 && atoi(argv[4]) > 0 ? atoi(argv[4]) : (256 + pairs - 1) / pairs;
