@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
   const int ncbk = argc > 5 ? atoi(argv[5]) : (g.CoutP % 32 == 0 ? 2 : 1), tz = ncbk >= 2 ? 2 : 4;
   g.ntz = (D + tz - 1) / tz; g.nty = (H + 7) / 8; g.ntx = (W + 15) / 16; g.ntiles = N * g.ntz * g.nty * g.ntx;
   const int pairs = (g.CinP / 16) * ((g.CoutP + 16 * ncbk - 1) / (16 * ncbk));
-  int nsplit = argc > 4 && atoi(argv[4]) > 0 ? atoi(argv[4]) : (256 + pairs - 1) / pairs;
+  int nsplit = argc > 4 && atoi(argv[4]) > 0 ? atoi(argv[4]) : (256 / pairs > 0 ? 256 / pairs : 1);   // at most one workgroup per CU
   if (nsplit > g.ntiles) nsplit = g.ntiles;
   g.tiles_per_wg = (g.ntiles + nsplit - 1) / nsplit;
   nsplit = (g.ntiles + g.tiles_per_wg - 1) / g.tiles_per_wg;
