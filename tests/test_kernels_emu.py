@@ -76,7 +76,7 @@ def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w):
     product, fp32 accumulation) — same tolerance as the fp32-MFMA kernels, and the two paths agree to fp32 rounding."""
     monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
     monkeypatch.setenv("ICL_CONV_SPLIT", "1")
-    monkeypatch.setenv("ICL_WGRAD_SPLIT", "1")      # split-product weight gradient: 16-cout layers and layers with Cout % 32 == 0
+    monkeypatch.setenv("ICL_WGRAD_SPLIT", "2")      # split-product weight gradient for every Cout (the default)
     _conv_check(n, cin, cout, d, h, w, 3)
     x = _rand((n, cin, d, h, w), 11)
     wt = _rand((cout, cin, 3, 3, 3), 12) * 0.2
