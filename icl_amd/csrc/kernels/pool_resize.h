@@ -216,33 +216,36 @@ __device__ __forceinline__ void up2_adj_weights(int i, int n, float w[4]) {
   w[3] = i < n - 1 ? 0.25f : 0.f;
 }
 
+// One thread = four consecutive input x of kUpSeg consecutive input z: the fine planes 2 iz + 1 and 2 iz + 2 it reduces for input
+// plane iz are the planes 2 (iz + 1) - 1 and 2 (iz + 1) of the next one, so every fine row is loaded once per thread (32 instead of
+// 64 loads per output quad; the remaining 2x re-read across neighbouring iy comes out of L1 / L2).
+constexpr int kUpSeg = 8;
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int N, int C, int Di,
                                                              int Hi, int Wi, long gy_bstride) {
   const unsigned wq = (unsigned)Wi >> 2;
-  const unsigned total = (unsigned)N * C * Di * Hi * wq;
-  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  const unsigned nseg = ((unsigned)Di + kUpSeg - 1) / kUpSeg;
+  const unsigned total = (unsigned)N * C * nseg * Hi * wq;
+  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
   for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const unsigned xq = e % wq;
     unsigned t = e / wq;
     const int iy = (int)(t % (unsigned)Hi);
     t /= (unsigned)Hi;
-    const int iz = (int)(t % (unsigned)Di);
-    t /= (unsigned)Di;
+    const int seg = (int)(t % nseg);
+    t /= nseg;
     const int c = (int)(t % (unsigned)C);
     const int n = (int)(t / (unsigned)C);
     const int ix = (int)xq * 4, ox0 = ix * 2;
-    float wz[4], wy[4], wx[4][4];
-    up2_adj_weights(iz, Di, wz);
+    float wy[4], wx[4][4];
     up2_adj_weights(iy, Hi, wy);
 #pragma unroll
     for (int k = 0; k < 4; ++k) up2_adj_weights(ix + k, Wi, wx[k]);
-    const float* g = gy + (long)n * gy_bstride + (long)c * (2 * Di) * Ho * Wo;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* g = gy + (long)n * gy_bstride + (long)c * Do * Ho * Wo;
+    // x- and y-reduced values of fine plane oz for the four inputs of this thread (zeros outside the volume)
+    auto plane = [&](int oz, float (&tz)[4]) {
 #pragma unroll
-    for (int dz = 0; dz < 4; ++dz) {
-      const int oz = 2 * iz - 1 + dz;
-      if (wz[dz] == 0.f) continue;
-      float tz[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < 4; ++k) tz[k] = 0.f;
+      if (oz < 0 || oz >= Do) return;
 #pragma unroll
       for (int dy = 0; dy < 4; ++dy) {
         const int oy = 2 * iy - 1 + dy;
@@ -257,10 +260,29 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
           tz[k] += wy[dy] * xr;
         }
       }
+    };
+    const int z0 = seg * kUpSeg, z1 = z0 + kUpSeg < Di ? z0 + kUpSeg : Di;
+    float pm[4], p0[4], p1[4], p2[4];
+    plane(2 * z0 - 1, pm);
+    plane(2 * z0, p0);
+    for (int iz = z0; iz < z1; ++iz) {
+      float wz[4];
+      up2_adj_weights(iz, Di, wz);
+      plane(2 * iz + 1, p1);
+      plane(2 * iz + 2, p2);
+      float acc[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] += wz[dz] * tz[k];
+      for (int k = 0; k < 4; ++k) {
+        acc[k] = wz[0] * pm[k];
+        acc[k] += wz[1] * p0[k];
+        acc[k] += wz[2] * p1[k];
+        acc[k] += wz[3] * p2[k];
+        pm[k] = p1[k];
+        p0[k] = p2[k];
+      }
+      const long o = ((((long)n * C + c) * Di + iz) * Hi + iy) * wq + xq;
+      reinterpret_cast<float4*>(gx)[o] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
-    reinterpret_cast<float4*>(gx)[e] = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
 }
 
