@@ -673,4 +673,68 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
   }   // row blocks
 }
 
+// ------------------------------------------------------------------------------------------------ tall, skinny Linear: weights in registers
+// y[rows][N] = act(x[rows][K] W^T + bias) for the token Linear layers of SwinUNETR's first stage: 221,184 / 235,298 rows, K, N in
+// {48, 144, 192}: 42-170 MB of activations against 9-37 KB of weights.  The LDS-tiled product re-stages the weight tile for every
+// 128-row block and keeps the matrix pipe 23 % busy (profiles/r2_pmc_gemm.md); here a wave keeps the WHOLE weight matrix as MFMA B
+// fragments in registers (N K / 64 of them: 108-144) and streams 16-row blocks: K / 16 float4 loads of x per lane (the lane's four
+// consecutive k feed four MFMAs: the k index of an MFMA is only a label that A and B must agree on), (N / 16) (K / 4) MFMAs, the
+// 16 x N result transposed through a wave-private LDS tile and stored as whole rows.  No barrier, no weight traffic after the
+// prologue.  KQ = K / 16, NT = N / 16.  WT: the weight is given as [K][N] (the input gradient g W of a weight stored [out][in]).
+template <int KQ, int NT, bool WT>
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ y, long rows, int act) {
+  constexpr int K = 16 * KQ, N = 16 * NT, LDP = N + 4;
+  ICL_DYN_LDS(float, lds);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+  float* tl = lds + wid * 16 * LDP;                              // this wave's 16 x N output tile
+  // B fragments: lane (column n = 16 t + lr, k quad lq + 4 j) holds W[n][4 (lq + 4 j) .. + 3]
+  float4 bw[NT][KQ];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+      const int n = 16 * t + lr, k = 4 * (lq + 4 * j);
+      if (!WT) bw[t][j] = *reinterpret_cast<const float4*>(w + (long)n * K + k);
+      else bw[t][j] = make_float4(w[(long)k * N + n], w[(long)(k + 1) * N + n], w[(long)(k + 2) * N + n], w[(long)(k + 3) * N + n]);
+    }
+  float bv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bv[t] = bias ? bias[16 * t + lr] : 0.f;
+  const long nblocks = (rows + 15) / 16;
+  for (long b = (long)blockIdx.x * 4 + wid; b < nblocks; b += (long)gridDim.x * 4) {
+    const long row = b * 16 + lr < rows ? b * 16 + lr : rows - 1;   // rows past the end repeat the last one (never stored)
+    float4 a[KQ];
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) a[j] = *reinterpret_cast<const float4*>(x + row * K + 4 * (lq + 4 * j));
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KQ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float av = f4c(a[j], i);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = icl_mfma_16x16x4(av, f4c(bw[t][j], i), acc[t]);
+      }
+    // D[row 4 lq + r][column 16 t + lr] -> LDS tile -> whole rows
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[t][r] + bv[t];
+        if (act == 1) v = gelu_erf(v);
+        tl[(4 * lq + r) * LDP + 16 * t + lr] = v;
+      }
+    ICL_WAVE_SYNC();
+#pragma unroll
+    for (int it = lane; it < 16 * (N / 4); it += 64) {
+      const int r = it / (N / 4), q = it % (N / 4);
+      if (b * 16 + r < rows) *reinterpret_cast<float4*>(y + (b * 16 + r) * N + 4 * q) = *reinterpret_cast<const float4*>(tl + r * LDP + 4 * q);
+    }
+    ICL_WAVE_SYNC();
+  }
+}
+
 }  // namespace icl

@@ -169,3 +169,20 @@ def test_fused_update_matches_optimizer_step_through_autograd():
         for ga, gb in zip(a[0], b[0]):
             assert rel_err(ga, gb) < 2e-5
         assert rel_err(a[1], b[1]) < 1e-6 and rel_err(a[2], b[2]) < 2e-5 and rel_err(a[3], b[3]) < 1e-6
+
+
+@pytest.mark.parametrize("rows,i,o,act", [(16400, 48, 144, 0), (16390, 48, 192, 1), (16385, 192, 48, 0), (16384, 96, 96, 1)])
+def test_tall_skinny_linear_with_weights_in_registers(rows, i, o, act):
+    """linear_rows_kernel (>= 16,384 rows, the token layers of SwinUNETR stage 0): forward with bias / GELU and the input gradient
+    (weight read as [K][N]), ragged last 16-row block."""
+    x, w, b = _rand((rows, i), 31), _rand((o, i), 32) * 0.1, _rand((o,), 33)
+    y = ops.linear_forward_raw(x, w, b, act)
+    assert "linear_rows_kernel" in _lib.lib().icl_last_kernel_name().decode()
+    ref = F.linear(x, w, b)
+    if act:
+        ref = F.gelu(ref)
+    assert rel_err(y, ref) < 2e-5
+    g = _rand((rows, o), 34)
+    gx = ops.linear_dgrad_raw(g, w)
+    assert "linear_rows_kernel" in _lib.lib().icl_last_kernel_name().decode()
+    assert rel_err(gx, g @ w) < 2e-5
