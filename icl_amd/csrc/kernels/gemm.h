@@ -681,13 +681,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 // consecutive k feed four MFMAs: the k index of an MFMA is only a label that A and B must agree on), (N / 16) (K / 4) MFMAs, the
 // 16 x N result transposed through a wave-private LDS tile and stored as whole rows.  No barrier, no weight traffic after the
 // prologue.  KQ = K / 16, NT = N / 16.  WT: the weight is given as [K][N] (the input gradient g W of a weight stored [out][in]).
-template <int KQ, int NT, bool WT>
+// NH: the N / 16 column tiles are dealt to NH waves (each re-reads the x rows, from L1 / L2): a third / half of the B fragments per
+// wave, i.e. 60-100 instead of 170-220 registers on the 144- / 192-wide layers and twice the waves per SIMD.
+template <int KQ, int NTALL, bool WT, int NH = 1>
 __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ y, long rows, int act) {
-  constexpr int K = 16 * KQ, N = 16 * NT, LDP = N + 4;
+  static_assert(NTALL % NH == 0, "column tiles must split evenly over the waves of a row block");
+  constexpr int NT = NTALL / NH, K = 16 * KQ, NALL = 16 * NTALL, N = 16 * NT, LDP = N + 4;
   ICL_DYN_LDS(float, lds);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
   float* tl = lds + wid * 16 * LDP;                              // this wave's 16 x N output tile
+  const long gw = (long)blockIdx.x * 4 + wid;                    // global wave: column part gw % NH of row-block stream gw / NH
+  const int c0 = (int)(gw % NH) * N;
+  w += WT ? c0 : (long)c0 * K;
+  if (bias) bias += c0;
   // B fragments: lane (column n = 16 t + lr, k quad lq + 4 j) holds W[n][4 (lq + 4 j) .. + 3]
   float4 bw[NT][KQ];
 #pragma unroll
@@ -696,13 +703,13 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
     for (int j = 0; j < KQ; ++j) {
       const int n = 16 * t + lr, k = 4 * (lq + 4 * j);
       if (!WT) bw[t][j] = *reinterpret_cast<const float4*>(w + (long)n * K + k);
-      else bw[t][j] = make_float4(w[(long)k * N + n], w[(long)(k + 1) * N + n], w[(long)(k + 2) * N + n], w[(long)(k + 3) * N + n]);
+      else bw[t][j] = make_float4(w[(long)k * NALL + n], w[(long)(k + 1) * NALL + n], w[(long)(k + 2) * NALL + n], w[(long)(k + 3) * NALL + n]);
     }
   float bv[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) bv[t] = bias ? bias[16 * t + lr] : 0.f;
   const long nblocks = (rows + 15) / 16;
-  for (long b = (long)blockIdx.x * 4 + wid; b < nblocks; b += (long)gridDim.x * 4) {
+  for (long b = gw / NH; b < nblocks; b += (long)gridDim.x * 4 / NH) {
     const long row = b * 16 + lr < rows ? b * 16 + lr : rows - 1;   // rows past the end repeat the last one (never stored)
     float4 a[KQ];
 #pragma unroll
@@ -731,7 +738,8 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
 #pragma unroll
     for (int it = lane; it < 16 * (N / 4); it += 64) {
       const int r = it / (N / 4), q = it % (N / 4);
-      if (b * 16 + r < rows) *reinterpret_cast<float4*>(y + (b * 16 + r) * N + 4 * q) = *reinterpret_cast<const float4*>(tl + r * LDP + 4 * q);
+      if (b * 16 + r < rows)
+        *reinterpret_cast<float4*>(y + (b * 16 + r) * NALL + c0 + 4 * q) = *reinterpret_cast<const float4*>(tl + r * LDP + 4 * q);
     }
     ICL_WAVE_SYNC();
   }
