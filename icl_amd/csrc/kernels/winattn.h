@@ -92,8 +92,7 @@ template <int DH> struct WaFrag {
 
 // acc += A . B over the DH dims held in two fragments (A rows = the lanes' lr of fragment a, B columns = lr of fragment b)
 template <int DH>
-__device__ __forceinline__ f32x4 wa_dot(const WaFrag<DH>& a, const WaFrag<DH>& b) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ f32x4 wa_dot(const WaFrag<DH>& a, const WaFrag<DH>& b, f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}) {
 #pragma unroll
   for (int i = 0; i < DH / 4; ++i) acc = icl_mfma_16x16x4(a.v[i], b.v[i], acc);
   return acc;
@@ -105,9 +104,9 @@ __device__ __forceinline__ f32x4 wa_scores_t(const float* Ks, int kb, int lr, in
                                              const int* rid, int rq, bool masked) {
   WaFrag<DH> kf;
   kf.load(Ks + (kb * 16 + lr) * WaCfg<DH>::LD, lg);
-  f32x4 acc = wa_dot<DH>(kf, qf);
+  // the relative-position bias enters as the accumulator of the MFMA chain (no separate adds)
   const float4 b4 = *reinterpret_cast<const float4*>(brow + kb * 16 + lg * 4);
-  acc[0] += b4.x; acc[1] += b4.y; acc[2] += b4.z; acc[3] += b4.w;
+  f32x4 acc = wa_dot<DH>(kf, qf, f32x4{b4.x, b4.y, b4.z, b4.w});
   if (masked) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
