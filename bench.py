@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — ICL training-step throughput on MI355X (BASELINE.json metric: 3D volumes/sec/node).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without WORLD_SIZE in the environment: bench.py starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py ...` itself, as a CHILD process and before anything touches the GPU (no exec),
+relays rank 0's JSON line and exits with the child's return code.  Launched by torch.distributed.run (the driver's N > 1 form),
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment and nothing is spawned.
 
 A "step" is one full ICL iteration of the reference trainer (train_inherent_consistent_unet_3D_BraTS.py:99-121)
 on a synthetic BraTS-shaped batch resident in HBM: per GPU 1 labeled + 1 unlabeled 96^3 volume (BASELINE.json
@@ -12,8 +17,9 @@ DropPath 0.02 are active as in training.  value = volumes processed by all ranks
 Extra objects on the JSON line (tier contract ④):
   roofline      dominant kernel = the forward/input-gradient convolution instantiation with the largest total time
                 (named exactly as rocprofv3 --stats lists it; the C ABI reports which template its launcher picked):
-                algorithmic FLOPs of its launches / their HIP-event durations (events on the launch stream), against
-                the 157.3 TFLOP/s fp32 MFMA peak (MI355X_MICROARCH.md).  `all_conv` aggregates every conv launch of a
+                algorithmic FLOPs of its launches / their HIP-event durations (events on the launch stream), against the
+                kernel's matrix peak (MI355X_MICROARCH.md): dense bf16 peak / 6 terms = 416.7 TFLOP/s for the split-product
+                kernels (`peak_basis`), 157.3 TFLOP/s for the exact-fp32 MFMA kernels.  `all_conv` aggregates every conv launch of a
                 step (fwd + dgrad + wgrad) and also gives the algorithmic-bytes fraction of the 8 TB/s HBM peak;
                 `per_kernel` lists each instantiation for cross-checking against profiles/.
   cpu_baseline  the CPU oracle (oracle/icl_oracle.py, torch-CPU restatement of the reference) timed on rank 0
@@ -99,6 +105,56 @@ def hbm_traffic(kernel: str):
         return None
 
 
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start torch.distributed.run as a child process (one rank per
+    GPU, rendezvous on 127.0.0.1) BEFORE anything initialises the GPU in this process — `torch.cuda.device_count()` does not — and
+    never by exec.  The child ranks inherit stdout, so rank 0's JSON line is the last line this command prints; the return code is
+    the launcher's."""
+    import socket
+    import subprocess
+    if not args.launcher_selftest:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py --gpus {args.gpus}: this node shows {have} HIP device(s); one rank per GPU is the only supported "
+                  f"placement (RCCL refuses two ranks on one device).  Nothing was run.", file=sys.stderr, flush=True)
+            return 2
+    with socket.socket() as s:      # a free rendezvous port (the driver passes its own when it launches the ranks itself)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] self-launch: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launcher_selftest(args, world: int, rank: int) -> int:
+    """The rank-side protocol of the timed region without a GPU: gloo group, W untimed and K timed 'steps' (a sleep that is longer on
+    the last rank), barrier on both sides, MAX over ranks, ONE JSON line from rank 0."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    assert dist.get_world_size() == world and dist.get_rank() == rank
+    step_s = 0.002 * (1 + (rank == world - 1))
+    for _ in range(args.warmup):
+        time.sleep(step_s)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(step_s)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        dt = float(t.item())
+        print(json.dumps({"metric": "launcher selftest (no kernels)", "value": round(2 * world * args.steps / dt, 3), "unit": "sleeps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "config": {"workload": "sleep", "ranks": dist.get_world_size(), "backend": "gloo"}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,14 +173,20 @@ def main():
                          "(with the aligner heads on their own stream an eager step beats the replay when the host keeps up); "
                          "graph = always replay.  N > 1 always replays.")
     ap.add_argument("--force-ddp", action="store_true", help="with --gpus 1: run the data-parallel step on a one-rank RCCL group")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="exercise ONLY the multi-rank plumbing (self-launch, rendezvous, barrier-bracketed timing, MAX over ranks, "
+                         "rank-0 JSON relay) on a gloo group with a sleep as the step: no GPU, no kernels; used by tests/")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} does not match WORLD_SIZE={world} of the launcher")
+    if args.launcher_selftest:
+        raise SystemExit(launcher_selftest(args, world, rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -333,6 +395,8 @@ def main():
             "config": {"workload": f"{'SwinUNETR' if args.model == 'swinunetr_icl' else '3D U-Net'} ICL BraTS-shape synthetic 96x96x96, num_classes={nc}, "
                                    f"batch=2 per GPU (1 labeled + 1 unlabeled), full ICL step incl. SGD",
                        "global_batch": 2 * world, "parallelism": f"dp{world}",
+                       **({"rccl_ranks": torch.distributed.get_world_size(), "collective_backend": torch.distributed.get_backend()}
+                          if use_ddp else {}),
                        "launch": ("eager" if not graphed else "hipGraph replay" if ddp is None else
                                   "hipGraph replay (forward/backward, optimiser) + eager RCCL collectives"),
                        **({"launch_probe": launch_probe} if launch_probe else {}),

@@ -219,8 +219,11 @@ __global__ __launch_bounds__(512) void linear_dgrad_sgd_kernel(const float* __re
       const int row = row0 + 4 * j + lg;
       const bool ok = live && row < c0 + clen && col < K;
       const long off = ok ? (long)row * K + col : 0L;
+      // straight-line loads from an always-valid address, then a select (as in linear_stream_kernel): out-of-range lanes hold
+      // zeros — gx accumulates gy * ring, and 0 * w[0] is only zero while w[0] is finite
       ring[p][j] = icl_nt_load4(w + off);
       mring[p][j] = first ? make_float4(0.f, 0.f, 0.f, 0.f) : icl_nt_load4(mom + off);
+      if (!ok) ring[p][j] = mring[p][j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (++l_t == tpu) { l_t = 0; ++l_unit; }
   };

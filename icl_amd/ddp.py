@@ -163,6 +163,7 @@ class GradientReducer:
             p._icl_factors = [(G, X)]
             shard = (self.world > 1 and self.shard_min_rows > 0 and G.shape[0] >= self.shard_min_rows and p.shape[0] % self.world == 0
                      and p.is_contiguous())
+            # consumed (and cleared) by FusedSGD._step_factored together with these factors: the decision never outlives its step
             p._icl_shard = (dist.get_rank(), self.world) if shard else None
             if shard:
                 self._sharded.append(p)

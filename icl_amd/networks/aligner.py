@@ -206,8 +206,8 @@ class InherentConsistent(nn.Module):
 
     def _tokens(self, i, feat):
         """``norm_layers[i](proj_layers[i](feat).flatten(2).transpose(1, 2))`` (:212): a 1x1x1 convolution followed by the token
-        transpose is one GEMM on the channel axis, ``feat^T W^T + b`` -> [B, N, C] — a plain library GEMM (rocBLAS), no
-        transpose copy."""
+        transpose is one GEMM on the channel axis, ``feat^T W^T + b`` -> [B, N, C] — one batched product of the tiled fp32-MFMA kernel
+        (csrc/kernels/gemm.h) that reads the channel-major map in place (k-strided A operand), no transpose copy."""
         if self.tokenized_input:
             return feat
         p = self.proj_layers[i]

@@ -392,7 +392,8 @@ SMALL_CONV_MIN_WEIGHTS = 128 * 128 * 27
 
 def _conv3d_tiny_volume(x, weight, bias):
     """3^3 convolution on <= 6^3 voxels with >= 128x128 channels: a skinny GEMM that streams the weights once
-    (csrc/kernels/misc.h im2col3 / col2im3 + the library GEMM; dW through the tall/skinny paths of ``linear``)."""
+    (csrc/kernels/misc.h im2col3 / col2im3 + the weight-streaming / tiled products of csrc/kernels/gemm.h through ``linear``;
+    dW through its tall/skinny paths)."""
     n, cin, d, h, w = x.shape
     cout = weight.shape[0]
     y = linear(_Im2Col3.apply(x), weight.flatten(1), bias)            # [n*S, cout]
@@ -1098,8 +1099,6 @@ class _LinearFactored(torch.autograd.Function):
         ctx.owner = owner
         ctx.has_bias = bias is not None
         ctx.x_shape = x.shape
-        if FactoredGrads.uses is not None:
-            FactoredGrads.uses[id(owner.weight)] = FactoredGrads.uses.get(id(owner.weight), 0) + 1
         return linear_forward_raw(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
@@ -1125,6 +1124,11 @@ class _LinearFactored(torch.autograd.Function):
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], owner=None) -> torch.Tensor:
     """F.linear.  ``owner``: the module whose ``.weight`` this is — lets the gradient stay factored (see FactoredGrads)."""
+    if FactoredGrads.uses is not None:
+        # every use of a weight in this step, whichever autograd path it takes below: the update-inside-backward of
+        # _LinearFactored is only legal for a weight that is read exactly once per step
+        key = id(owner.weight) if owner is not None and getattr(owner, "weight", None) is not None else id(weight)
+        FactoredGrads.uses[key] = FactoredGrads.uses.get(key, 0) + 1
     if (owner is not None and FactoredGrads.enabled and weight.requires_grad and weight.numel() >= FactoredGrads.min_elems
             and x.numel() // x.shape[-1] <= FactoredGrads.max_rows
             and (x.numel() // x.shape[-1]) * FactoredGrads.world <= FactoredGrads.max_rows_gathered

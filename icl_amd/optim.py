@@ -26,6 +26,7 @@ class FusedSGD(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.lr_dev = None   # optional device scalar read by the kernels instead of group['lr'] (hipGraph replay)
         self._groups = None  # id(parameter) -> its group (update_in_backward)
+        self._updated_in_backward = set()   # ids of the parameters whose update of this step already ran inside backward
 
     def zero_grad(self, set_to_none: bool = True):
         for group in self.param_groups:
@@ -44,15 +45,21 @@ class FusedSGD(torch.optim.Optimizer):
         if not p.is_cuda and not _lib.host_pointers_ok():
             raise RuntimeError("FusedSGD needs device tensors (no CPU fallback)")
         st = self.state[p]
+        shard = getattr(p, "_icl_shard", None)
+        p._icl_shard = None      # the decision belongs to THIS step's factors (ddp.GradientReducer.rebind sets it per step)
         first = 0
         if "momentum_buffer" not in st:
-            st["momentum_buffer"] = torch.empty_like(p)
+            # row-sharded: the other ranks' rows are never written here, so they must be zeros, not uninitialised memory
+            st["momentum_buffer"] = torch.zeros_like(p) if shard is not None else torch.empty_like(p)
             first = 1
+        elif st.get("momentum_shard") != shard and st.get("momentum_shard") is not None:
+            self._gather_momentum(p)      # the shard decision flipped: make every row of the buffer valid first
         m = st["momentum_buffer"]
+        if shard is not None:
+            st["momentum_shard"] = tuple(shard)      # only rows [r N/W, (r+1) N/W) of the buffer are this parameter's momentum
         stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream) if p.is_cuda else None
         lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
         pv, mv = p, m
-        shard = getattr(p, "_icl_shard", None)
         if shard is not None:
             # data-parallel crossover (ddp.GradientReducer): this rank updates only its block of rows from the gathered factors —
             # 1/W of the MFMA-bound rank-(M W) product — and the ranks all-gather the updated rows afterwards (post_update)
@@ -73,6 +80,37 @@ class FusedSGD(torch.optim.Optimizer):
             else:
                 _lib.check(L.icl_sgd_step_factored(pv.data_ptr(), mv.data_ptr(), g.data_ptr(), x.data_ptr(), rows, n, k, lr, mom, wd,
                                                    first, lrp, stream), "sgd_step_factored")
+
+    def _gather_momentum(self, p):
+        """Row-sharded data-parallel updates (ddp.GradientReducer, `_icl_shard`) keep only this rank's rows of the momentum buffer
+        current.  Before the buffer is used whole again — the shard decision flips, or the state is saved — the ranks exchange
+        their rows in place (a collective: every rank of the group gets here in the same step, the decision is a function of
+        shapes and world size only)."""
+        import torch.distributed as dist
+        st = self.state[p]
+        rank, world = st.pop("momentum_shard")
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() != world:
+            raise RuntimeError("FusedSGD: a row-sharded momentum buffer can only be completed by the process group that sharded it "
+                               f"(world size {world}); call optimizer.state_dict() / consolidate_momentum() before leaving the group")
+        m = st["momentum_buffer"]
+        rows = m.shape[0] // world
+        mine = m[rank * rows:(rank + 1) * rows]
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(m.view(-1), mine.reshape(-1))
+        else:
+            dist.all_gather([m[i * rows:(i + 1) * rows] for i in range(world)], mine.clone())
+
+    def consolidate_momentum(self):
+        """Collective: completes every row-sharded momentum buffer (all ranks call it together)."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if self.state.get(p, {}).get("momentum_shard") is not None:
+                    self._gather_momentum(p)
+
+    def state_dict(self):
+        """Collective when a data-parallel step has row-sharded a momentum buffer: the saved buffers are complete on every rank."""
+        self.consolidate_momentum()
+        return super().state_dict()
 
     def can_update_in_backward(self, p, rows: int) -> bool:
         n, k = p.shape
@@ -110,6 +148,11 @@ class FusedSGD(torch.optim.Optimizer):
         with ops._timed("linear_dgrad_sgd_kernel", 4.0 * rows * n * k, 16.0 * n * k, p):
             _lib.check(L.icl_linear_dgrad_sgd(g.data_ptr(), x.data_ptr(), p.data_ptr(), m.data_ptr(), gx.data_ptr(), ws.data_ptr(), rows, k, n,
                                               lr, mom, wd, first, lrp, stream), "linear_dgrad_sgd")
+        # the kernel wrote the weight through its raw pointer: tell autograd, so that any other node of this graph that saved the
+        # weight (a second use that the use count missed: F.linear, a tied weight, a hook) raises instead of differentiating
+        # through the already-updated matrix
+        torch.autograd.graph.increment_version(p)
+        self._updated_in_backward.add(id(p))
         return gx
 
     @torch.no_grad()
@@ -125,9 +168,19 @@ class FusedSGD(torch.optim.Optimizer):
             for p in group["params"]:
                 g = p.grad
                 fac = getattr(p, "_icl_factors", None)
+                if id(p) in self._updated_in_backward and (g is not None or fac):
+                    raise RuntimeError("FusedSGD: a parameter that was updated inside its backward pass (update_in_backward) also "
+                                       "received a gradient from another use in the same step; this step's update would be applied "
+                                       "twice.  Turn ICLConfig.update_in_backward off for models that reuse such a weight")
+                if fac and g is not None:
+                    # a weight with a factored use AND a dense one in the same step (ops.linear with few rows and with many): the
+                    # factors are multiplied out into the dense gradient (csrc/kernels/gemm.h) and the ordinary update runs
+                    from . import ops
+                    for gf, xf in fac:
+                        g = g + ops._tall_atb(gf, xf, False)[0]
+                    p.grad = g
+                    p._icl_factors = fac = None
                 if fac:
-                    if g is not None:
-                        raise RuntimeError("FusedSGD: parameter has both a dense and a factored gradient")
                     self._step_factored(L, p, fac, lr, mom, wd)
                     p._icl_factors = None
                     continue
@@ -163,4 +216,5 @@ class FusedSGD(torch.optim.Optimizer):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(p0.device).cuda_stream) if p0.is_cuda else None
                 lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
                 _lib.check(L.icl_sgd_step_multi(P_, G_, M_, N_, n, lr, mom, wd, first, lrp, stream), "sgd_step_multi")
+        self._updated_in_backward.clear()
         return loss

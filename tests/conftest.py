@@ -47,7 +47,8 @@ def pytest_collection_modifyitems(config, items):
         out = []
         for w in range(workers):
             out += long[w::workers] + rest[w * (block - 1):(w + 1) * (block - 1)]
-        out += [it for it in rest if it not in set(out)]
+        seen = set(map(id, out))
+        out += [it for it in rest if id(it) not in seen]
         items[:] = out
     # GPU tests are skipped (not failed) when selected on a host without a GPU.
     if torch.cuda.is_available():

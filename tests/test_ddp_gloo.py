@@ -121,6 +121,41 @@ def _worker_factored(rank, world, port, tmp):
             ref_opt.step()
             assert torch.allclose(lin.weight.detach(), rw.detach(), rtol=1e-5, atol=1e-6), (shard_rows, step)
             assert torch.allclose(lin.bias.detach(), rb.detach(), rtol=1e-5, atol=1e-6)
+            assert lin.weight._icl_shard is None      # consumed by the step: the decision never outlives its factors
+    # the shard decision flips between steps (sharded, sharded, whole, sharded, whole): the momentum rows the other ranks own are
+    # exchanged before the buffer is used whole again, and a saved state holds the complete buffer on every rank
+    torch.manual_seed(3)
+    lin = Linear(64, 48)
+    red = GradientReducer(lin, world, shard_min_rows=1)
+    red.broadcast_parameters()
+    rw, rb = torch.nn.Parameter(lin.weight.detach().clone()), torch.nn.Parameter(lin.bias.detach().clone())
+    ref_opt = torch.optim.SGD([rw, rb], lr=0.1, momentum=0.9, weight_decay=1e-2)
+    opt = FusedSGD(lin.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+    torch.manual_seed(12)
+    data = torch.randn(world, 6, 64)
+    for step, sharded in enumerate((1, 1, 0, 1, 0)):
+        red.shard_min_rows = 1 if sharded else 0
+        opt.zero_grad()
+        with ops.FactoredGrads(True):
+            lin(data[rank] + step).pow(2).mean().backward()
+        red.reduce_gradients()
+        assert (lin.weight._icl_shard is not None) == bool(sharded)
+        opt.step()
+        red.post_update()
+        gw, gb = torch.zeros_like(rw), torch.zeros_like(rb)
+        for r in range(world):
+            rw.grad = rb.grad = None
+            torch.nn.functional.linear(data[r] + step, rw, rb).pow(2).mean().backward()
+            gw += rw.grad / world
+            gb += rb.grad / world
+        rw.grad, rb.grad = gw, gb
+        ref_opt.step()
+        assert torch.allclose(lin.weight.detach(), rw.detach(), rtol=1e-5, atol=1e-6), step
+        if step == 3:     # saved right after a sharded step: state_dict() completes the buffer (collective)
+            sd = opt.state_dict()
+            m = sd["state"][0]["momentum_buffer"]
+            assert torch.allclose(m, ref_opt.state[rw]["momentum_buffer"], rtol=1e-5, atol=1e-6)
+            assert "momentum_shard" not in sd["state"][0]
     dist.destroy_process_group()
 
 

@@ -171,6 +171,44 @@ def test_fused_update_matches_optimizer_step_through_autograd():
         assert rel_err(a[1], b[1]) < 1e-6 and rel_err(a[2], b[2]) < 2e-5 and rel_err(a[3], b[3]) < 1e-6
 
 
+def test_update_inside_backward_refuses_a_weight_with_another_use():
+    """A second use of the weight outside _LinearFactored.  (1) through ops.linear's dense path (more rows than FactoredGrads
+    takes): counted, so nothing is fused and the step equals the unfused one.  (2) through torch's own F.linear, which ops.linear
+    cannot count: the fused kernel bumps the weight's version counter, so autograd raises when F.linear's backward unpacks the
+    weight it saved instead of differentiating through the already-updated matrix."""
+    from icl_amd.optim import FusedSGD
+
+    def run(fuse, second):
+        lin = torch.nn.Linear(1536, 1408)
+        with torch.no_grad():
+            lin.weight.copy_(_rand((1408, 1536), 41) * 0.05)
+            lin.bias.copy_(_rand((1408,), 42))
+        opt = FusedSGD(lin.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+        opt.can_update_in_backward = lambda p, rows: p.dim() == 2
+        x = _rand((6, 1536), 43).requires_grad_()
+        xt = _rand((600, 1536), 44)          # 600 rows > FactoredGrads.max_rows: ops.linear takes the dense _Linear path
+        ops.FactoredGrads.fused_optimizer = opt if fuse else None
+        ops.FactoredGrads.uses = {} if fuse else None
+        try:
+            with ops.FactoredGrads(True):
+                y = ops.linear(x, lin.weight, lin.bias, lin).sum()
+                if second == "dense":
+                    y = y + ops.linear(xt, lin.weight, lin.bias, lin).sum() * 0.01
+                elif second == "torch":
+                    y = y + F.linear(xt[:4], lin.weight, lin.bias).sum() * 0.01
+                y.backward()
+        finally:
+            ops.FactoredGrads.fused_optimizer = None
+            ops.FactoredGrads.uses = None
+        opt.step()
+        return x.grad.clone(), lin.weight.detach().clone()
+
+    a, b = run(True, "dense"), run(False, "dense")
+    assert rel_err(a[0], b[0]) < 2e-5 and rel_err(a[1], b[1]) < 1e-6
+    with pytest.raises(RuntimeError, match="modified by an inplace operation|updated inside its backward"):
+        run(True, "torch")
+
+
 @pytest.mark.parametrize("rows,i,o,act", [(16400, 48, 144, 0), (16390, 48, 192, 1), (16385, 192, 48, 0), (16384, 96, 96, 1)])
 def test_tall_skinny_linear_with_weights_in_registers(rows, i, o, act):
     """linear_rows_kernel (>= 16,384 rows, the token layers of SwinUNETR stage 0): forward with bias / GELU and the input gradient

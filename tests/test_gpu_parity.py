@@ -666,9 +666,10 @@ def test_graph_replay_equals_eager_steps(dev):
         torch.cuda.empty_cache()
     (w0, b0, l0), (w1, b1, l1) = finals
     # Measured (tests/diag/replay_band.py, parity mode): step 3 is bit-identical across two eager runs and a replayed run, step 4
-    # differs by 3.6e-6 (eager vs eager) / 7e-6 (eager vs replay) in the loss and 1e-7 in the parameters.  The only run-to-run
-    # noise left in the step are the fp32 atomics of the LayerNorm gamma / beta gradients (csrc/kernels/token.h); convolutions
-    # (Cin-split and weight-gradient slabs) and the loss statistics are summed in a fixed order.  Band = 10x the measurement.
+    # differed by 3.6e-6 (eager vs eager) / 7e-6 (eager vs replay) in the loss and 1e-7 in the parameters — measured in round 1, when
+    # the LayerNorm gamma / beta gradients were summed with fp32 atomics.  Since round 2 every cross-workgroup sum of the step has a
+    # fixed order (test_unet_icl_steps_are_bit_reproducible) and what remains between an eager and a replayed run is the dropout
+    # mask stream (seeded per step from device memory under replay).  The band stays at 10x the round-1 measurement.
     assert rel_err(w1.cpu(), w0.cpu()) < 1e-5 and rel_err(b1.cpu(), b0.cpu()) < 1e-5
     assert np.allclose(l0, l1, rtol=1e-4), (l0, l1)
     # dropout under replay: the device-resident step counter changes the mask between replays
@@ -685,8 +686,8 @@ def test_graph_replay_equals_eager_steps(dev):
 
 def test_aligner_side_stream_equals_single_stream(dev):
     """ops.SideStream (aligner heads forked onto a second HIP stream, forward and backward) changes the schedule, not the result:
-    losses, every dense gradient and the factored mlp2 gradients of one step equal those of the single-stream run up to the
-    run-to-run noise of the library GEMMs (a race between the streams would show as garbage, not as 1e-6)."""
+    losses, every dense gradient and the factored mlp2 gradients of one step equal those of the single-stream run (every kernel
+    of the step sums in a fixed order; a race between the streams would show as garbage, not as 1e-6)."""
     from icl_amd import ops
     from icl_amd.networks.unet_3D_icl import unet_3D_icl
     from icl_amd.trainer import ICLConfig, ICLTrainer

@@ -93,3 +93,25 @@ def test_checkpoint_filter_and_lr_schedule():
     assert abs(O.poly_lr(0.01, 0, 30000) - 0.01) < 1e-15 and O.poly_lr(0.01, 30000, 30000) == 0.0
     cfg = ICLConfig()
     assert cfg.base_lr * (1.0 - 100 / cfg.max_iterations) ** 0.9 == O.poly_lr(cfg.base_lr, 100, cfg.max_iterations)
+
+
+def test_bench_self_launches_its_ranks_and_relays_rank0_json():
+    """`python bench.py --gpus 2` (no launcher around it, the driver's N > 1 spelling without torch.distributed.run) starts its
+    ranks as a child torch.distributed.run, rendezvous on 127.0.0.1; rank 0's JSON line is the last line of stdout and the return
+    code is the launcher's.  The selftest mode runs the same launcher path and timing protocol on gloo with a sleep as the step."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["steps"] == 4
+    assert line["ms_per_step"] >= 3.9        # MAX over ranks: the last rank sleeps 4 ms per step, rank 0 only 2 ms
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+    # without enough devices the real mode refuses before anything is launched, naming the device count
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and f"{torch.cuda.device_count()} HIP device(s)" in r.stderr and r.stdout.strip() == ""

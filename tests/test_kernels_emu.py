@@ -576,7 +576,7 @@ def test_2d_ops_through_3d_kernels():
 
 @pytest.mark.parametrize("n,cin,cout,d,h,w", [(2, 128, 128, 3, 3, 3), (1, 130, 128, 2, 3, 4)])
 def test_conv3d_tiny_volume_gemm_path(n, cin, cout, d, h, w):
-    """<= 6^3 voxels with >= 128x128 channels: im2col3 / col2im3 + library GEMM instead of the tile kernels."""
+    """<= 6^3 voxels with >= 128x128 channels: im2col3 / col2im3 + the dense products of csrc/kernels/gemm.h instead of the tile kernels."""
     assert cin * cout * 27 >= ops.SMALL_CONV_MIN_WEIGHTS
     _conv_check(n, cin, cout, d, h, w, 3)
 
