@@ -26,6 +26,14 @@ __device__ __forceinline__ f32x4 icl_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(icl_bf16x8, a), __builtin_bit_cast(icl_bf16x8, b), c, 0, 0, 0);
 }
 
+// v_cvt_pk_bf16_f32: two fp32 -> two bf16, round to nearest even (NaN stays NaN), packed {hi, lo} into one dword
+typedef __bf16 icl_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float icl_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned icl_pack_bf16_rn(float lo, float hi) {
+  const icl_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, icl_bf16x2));
+}
+
 // v_alignbit_b32: bits [sh, sh + 32) of the 64-bit value {hi, lo}
 __device__ __forceinline__ unsigned icl_alignbit(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
@@ -34,6 +42,9 @@ __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 
 // hide an integer from constant folding: keeps LDS offsets small enough for ds_read2_b32 pairing (8-bit dword offsets)
 #define ICL_OPAQUE_INT(x) asm volatile("" : "+v"(x))
+// the four dwords of a uint4 are computed (and live in VGPRs) at this point of the program: stops the compiler from sinking a
+// computation whose result is only stored much later
+#define ICL_PIN4(u) asm volatile("" : "+v"((u).x), "+v"((u).y), "+v"((u).z), "+v"((u).w))
 // nothing may be scheduled across this point (keeps software-prefetched LDS reads ahead of the MFMAs they overlap)
 #define ICL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 

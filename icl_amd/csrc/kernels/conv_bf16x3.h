@@ -1,10 +1,15 @@
 // conv_bf16x3.h — 3x3x3 convolution (forward / input gradient) with fp32 operands split into three bf16 terms.
 //
 // The fp32 matrix pipe of gfx950 peaks at 157 TFLOP/s and the 3x3x3 convolutions of the U-Net are bound by it (profiles/r2_pmc_conv.md:
-// 81-85 % busy).  The bf16 pipe is 16x faster.  Every fp32 number is EXACTLY the sum of three bf16 numbers (8 + 8 + 8 mantissa bits,
-// truncation split: x = x1 + x2 + x3), so a product x*w is the sum of nine bf16 products; the six with the largest magnitude
-//     x1 w1 + (x1 w2 + x2 w1) + (x1 w3 + x2 w2 + x3 w1)
-// reproduce it to 2^-24 relative (the three dropped terms are below 2^-24 |x w|), which is the rounding error of an fp32 product.
+// 81-85 % busy).  The bf16 pipe is 16x faster.  Every fp32 number is EXACTLY the sum of three bf16 numbers (8 + 8 + 8 significand
+// bits, round-to-nearest split x = x1 + x2 + x3, bf3_split2 below), so a product x*w is the sum of nine bf16 products, each exact
+// in fp32; the kernel accumulates the six largest,
+//     x1 w1 + (x1 w2 + x2 w1) + (x1 w3 + x2 w2 + x3 w1),
+// and drops x2 w3 + x3 w2 + x3 w3, bounded by 2^-23 |x w| (|x2| <= 2^-8 |x|, |x3| <= 2^-16 |x|).  Measured on 4 M random pairs
+// (tools/split_error.py): error of the six-term product relative to |x w|, in units of 2^-24 (an fp32 multiply: mean 0.36, max
+// 1.0): round-to-nearest splits mean 0.06, max 0.9, mean SIGNED error 0.000 — the same on N(0,1), on all-positive and on
+// log-uniform 1e-15..1e15 operands; the truncation splits of round 2 measured mean 0.69, max 7.1 with every error on the sign of
+// -x w (a bias that adds up coherently over post-ReLU activations times same-sign weights).
 // Accumulation is fp32 inside v_mfma_f32_16x16x32_bf16, as in the fp32 kernels.  Six bf16 MFMAs of 16 cycles replace eight fp32 MFMAs
 // of 32 cycles for the same 16 x 16 x 32 block of multiply-adds: 2.67x the matrix rate at fp32 accuracy.
 //
@@ -46,21 +51,26 @@ struct Bf3T : Bf3Base {
 };
 typedef Bf3Base Bf3;
 
-// fp32 -> three bf16 by truncation: v = s1 + s2 + s3 exactly (24 mantissa bits = 3 x 8).  Packs 8 values per split.
+// Two fp32 -> their three bf16 terms, packed pairwise (low half = a).  Round-to-nearest splits: s1 = rn(v), s2 = rn(v - s1),
+// s3 = v - s1 - s2.  Both subtractions are exact (v - s1 has at most 16 significant bits, v - s1 - s2 at most 8), so
+// v = s1 + s2 + s3 EXACTLY for every finite v below the bf16 overflow threshold, with |s2| <= 2^-8 |v|, |s3| <= 2^-16 |v| and
+// residual signs that vary from element to element (a truncation split keeps all three terms on the sign of v: the dropped
+// product terms then add up coherently over a sum of same-sign products).  11 VALU per pair (3 v_cvt_pk_bf16_f32, 4 unpack, 4 sub).
+// Non-finite v (and |v| > 3.39e38, which rounds to a bf16 infinity): s2 and s3 are NaN — the result is non-finite wherever the
+// fp32 kernels give a non-finite result, as NaN where they may give an infinity.
+__device__ __forceinline__ void bf3_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = icl_pack_bf16_rn(a, b);
+  const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+  p2 = icl_pack_bf16_rn(ra, rb);
+  const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xffff0000u);
+  p3 = icl_pack_bf16_rn(sa, sb);
+}
+// 8 values -> 8 packed bf16 per split
 __device__ __forceinline__ void bf3_split8(const float* v, uint4& o1, uint4& o2, uint4& o3) {
-  unsigned h1[8], h2[8], h3[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const unsigned u = __float_as_uint(v[c]);
-    h1[c] = u & 0xffff0000u;
-    const float r = v[c] - __uint_as_float(h1[c]);
-    h2[c] = __float_as_uint(r) & 0xffff0000u;
-    const float r2 = r - __uint_as_float(h2[c]);
-    h3[c] = __float_as_uint(r2) & 0xffff0000u;
-  }
-  o1 = make_uint4((h1[0] >> 16) | h1[1], (h1[2] >> 16) | h1[3], (h1[4] >> 16) | h1[5], (h1[6] >> 16) | h1[7]);
-  o2 = make_uint4((h2[0] >> 16) | h2[1], (h2[2] >> 16) | h2[3], (h2[4] >> 16) | h2[5], (h2[6] >> 16) | h2[7]);
-  o3 = make_uint4((h3[0] >> 16) | h3[1], (h3[2] >> 16) | h3[3], (h3[4] >> 16) | h3[5], (h3[6] >> 16) | h3[7]);
+  bf3_split2(v[0], v[1], o1.x, o2.x, o3.x);
+  bf3_split2(v[2], v[3], o1.y, o2.y, o3.y);
+  bf3_split2(v[4], v[5], o1.z, o2.z, o3.z);
+  bf3_split2(v[6], v[7], o1.w, o2.w, o3.w);
 }
 
 // Split weights, ready for LDS: ws[chunk][stage 3][split * 2 + half][slot 10][CoutP] of 8 packed bf16, from the fp32 pack
@@ -92,10 +102,19 @@ __global__ __launch_bounds__(256) void conv_bf16x3_split_weights_kernel(const fl
   }
 }
 
-template <int NBT, int TY>
+// V = 0: the round-2 schedule (halo values kept as fp32 until the store phase, which splits them between two barriers: VALU, LDS
+//        and matrix phases of the eight waves add up).
+// V = 1: the halo loads are straight-line (clamped address + select: V = 0 emits a branch per predicated load), and each staging
+//        round is split into its three packed bf16 planes INSIDE the multiply phase, one round per tap pair of the dz = 1 / 2
+//        stages, so that the split VALU of one wave issues in the shadow of the MFMAs (its own and its SIMD partner's); the store
+//        phase between the barriers is then 15 ds_write_b128 per thread and nothing else.
+template <int NBT, int TY, int V = 1>
 __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {
   typedef Bf3T<TY> TC;
+  // three cout blocks: 48 accumulators + 36 weight-fragment + 24 weight-prefetch registers leave no room for the split planes
+  // (432 B of scratch when tried): those instantiations take the straight-line loads of V = 1 and keep the split in the store phase
+  constexpr bool EARLY = V != 0 && NBT < 3;
   constexpr int NB = 16 * NBT, PX = TC::PX, PY = TC::PY, NPOSP = TC::NPOSP, ROUNDS = TC::ROUNDS, NT = TC::NT;
   constexpr int WITEMS = 6 * Bf3::SLOTS * NB, WU = (WITEMS + NT - 1) / NT;      // 16-byte weight slots per dz plane
   ICL_DYN_LDS(uint4, lds);
@@ -132,23 +151,47 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       const int gz = z0 - 1 + (s_zyx[r] >> 16), gy = y0 - 1 + ((s_zyx[r] >> 8) & 255), gx = x0 - 1 + (s_zyx[r] & 255);
-      const bool ok = s_zyx[r] >= 0 && gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+      // (bitwise &: the short-circuit form compiles to a chain of exec-mask branches)
+      const bool ok = (s_zyx[r] >= 0) & ((unsigned)gz < (unsigned)g.D) & ((unsigned)gy < (unsigned)g.H) & ((unsigned)gx < (unsigned)g.W);
       // 32-bit lane offset against a wave-uniform channel base (16 channels x D*H*W < 2^31 elements, checked by the launcher)
       const int off = ok ? s_ch[r] * (int)DHW + gz * (int)HW + gy * g.W + gx : 0;
+      if (V == 0) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) xv[r][c] = ok ? (xb + c * DHW)[off] : 0.f;
+        for (int c = 0; c < 8; ++c) xv[r][c] = ok ? (xb + c * DHW)[off] : 0.f;
+      } else {
+        // unconditional loads from an always-valid address (offset 0 of the channel plane), then a select: no branch per load
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float v = (xb + c * DHW)[off];
+          xv[r][c] = ok ? v : 0.f;
+        }
+      }
     }
+  };
+  uint4 xsp[EARLY ? ROUNDS : 1][3];          // V = 1: the split planes of a staging round, produced during the multiply phase
+  auto split_round = [&](int r) {
+    bf3_split8(xv[r], xsp[EARLY ? r : 0][0], xsp[EARLY ? r : 0][1], xsp[EARLY ? r : 0][2]);
+    // pin the planes to this point of the program: left alone the compiler sinks the whole split to the end of the loop body
+    // (behind the last MFMA, in front of the barrier), which is the round-2 schedule again
+#pragma unroll
+    for (int s = 0; s < 3; ++s) ICL_PIN4(xsp[EARLY ? r : 0][s]);
   };
   auto store_x = [&]() {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       if (s_zyx[r] < 0) continue;
-      uint4 o1, o2, o3;
-      bf3_split8(xv[r], o1, o2, o3);
       uint4* d = Xs + s_dst[r];
-      d[0] = o1;
-      d[2 * NPOSP] = o2;
-      d[4 * NPOSP] = o3;
+      if (!EARLY) {
+        uint4 o1, o2, o3;
+        bf3_split8(xv[r], o1, o2, o3);
+        d[0] = o1;
+        d[2 * NPOSP] = o2;
+        d[4 * NPOSP] = o3;
+      } else {
+        d[0] = xsp[r][0];
+        d[2 * NPOSP] = xsp[r][1];
+        d[4 * NPOSP] = xsp[r][2];
+      }
     }
   };
   // weights: already split (conv_bf16x3_split_weights_kernel): one dz plane = 60 NB slots of 16 bytes, copied through registers
@@ -193,6 +236,10 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   if (tile < g.ntiles) {
     load_w(0, 0);
     load_x(tile, 0);
+    if (EARLY) {
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) split_round(r);
+    }
   }
   while (tile < g.ntiles) {
     int ntile = tile, nchunk = chunk + 1;
@@ -218,33 +265,47 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
         const int tA = 10 * dz + 2 * pair, tB = tA + 1 < 27 ? tA + 1 : 26;      // the zero slot multiplies any valid position
         const int offA = (tA / 9) * PY * PX + ((tA / 3) % 3) * PX + tA % 3, offB = (tB / 9) * PY * PX + ((tB / 3) % 3) * PX + tB % 3;
         const uint4* xp = xa + (tp ? offB : offA);
-        // all operand fragments of the pair first, then its 24 NBT MFMAs: the other wave of the SIMD multiplies while this one waits
-        uint4 b[3][NBT], a[4][3];
+        // the operand fragments of MB row blocks first (V = 0: all four; V = 1 with two or three cout blocks: two at a time, which
+        // frees 24 registers for the split planes), then their 6 MB NBT MFMAs: the other wave of the SIMD multiplies while this one waits
+        constexpr int MB = (!EARLY || NBT == 1) ? 4 : 2;
+        uint4 b[3][NBT];
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
           for (int j = 0; j < NBT; ++j) b[s][j] = wb[(s * 2 * Bf3::SLOTS + pair * 2) * NB + j * 16];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m0 = 0; m0 < 4; m0 += MB) {
+          uint4 a[MB][3];
 #pragma unroll
-          for (int s = 0; s < 3; ++s) a[m][s] = xp[2 * s * NPOSP + m * PX];
-        ICL_SCHED_BARRIER();
+          for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-          // (a split, b split) of the six products, smallest terms first; consecutive MFMAs go to different accumulators
-          constexpr int sa[6] = {2, 1, 0, 1, 0, 0}, sb[6] = {0, 1, 2, 0, 1, 0};
+            for (int s = 0; s < 3; ++s) a[m][s] = xp[2 * s * NPOSP + (m0 + m) * PX];
+          ICL_SCHED_BARRIER();
+          if (EARLY && m0 == 0) {
+            // staging round q of the NEXT work item (its loads were issued at dz = 0) becomes three packed planes here, in the same
+            // scheduling region as the pair's MFMAs: slots are the pairs 2..4 of dz = 1 and 0..3 of dz = 2
+            // (unconditional — a branch would cut the scheduling region; without a next work item the values are never stored)
+            static_assert(ROUNDS <= 7, "one staging round per slot");
+            const int q = dz == 1 ? pair - 2 : dz == 2 ? 3 + pair : -1;
+            if (q >= 0 && q < ROUNDS) split_round(q);
+          }
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+          for (int t = 0; t < 6; ++t) {
+            // (a split, b split) of the six products, smallest terms first; consecutive MFMAs go to different accumulators
+            constexpr int sa[6] = {2, 1, 0, 1, 0, 0}, sb[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-            for (int j = 0; j < NBT; ++j) {
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+              for (int j = 0; j < NBT; ++j) {
 #if defined(BF3_DEBUG) && (BF3_DEBUG & 1)
-              acc[m][j][0] += __uint_as_float(a[m][sa[t]].x ^ b[sb[t]][j].y);
+                acc[m0 + m][j][0] += __uint_as_float(a[m][sa[t]].x ^ b[sb[t]][j].y);
 #else
-              acc[m][j] = icl_mfma_16x16x32_bf16(a[m][sa[t]], b[sb[t]][j], acc[m][j]);
+                acc[m0 + m][j] = icl_mfma_16x16x32_bf16(a[m][sa[t]], b[sb[t]][j], acc[m0 + m][j]);
 #endif
-            }
+              }
+          }
+          ICL_SCHED_BARRIER();
         }
-        ICL_SCHED_BARRIER();
       }
     }
     if (chunk == g.nchunks - 1) {
@@ -308,12 +369,9 @@ struct Bf3WT {
 };
 typedef Bf3WT<1, 4> Bf3W;
 
-// one fp32 -> its three bf16 terms as the high halves of three dwords
+// one fp32 -> its three bf16 terms as the high halves of three dwords (same round-to-nearest split as bf3_split2)
 __device__ __forceinline__ void bf3_split1(float v, unsigned& h1, unsigned& h2, unsigned& h3) {
-  h1 = __float_as_uint(v) & 0xffff0000u;
-  const float r = v - __uint_as_float(h1);
-  h2 = __float_as_uint(r) & 0xffff0000u;
-  h3 = __float_as_uint(r - __uint_as_float(h2)) & 0xffff0000u;
+  bf3_split2(0.f, v, h1, h2, h3);
 }
 
 template <int NCB, int TZ>

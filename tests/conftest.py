@@ -32,7 +32,7 @@ def pytest_cmdline_main(config):
 
 
 # the tests that run for a minute or more on CPU, longest first (every xdist worker starts with one of them)
-LONG_TESTS = ("test_full_model_step_matches_reference", "test_2d_unet_icl_step_matches_reference",
+LONG_TESTS = ("test_three_trainer_steps_match_reference", "test_full_model_step_matches_reference", "test_2d_unet_icl_step_matches_reference",
               "test_icl_trainer_with_gradient_reducer_world2", "test_swin_stage_matches_oracle")
 
 

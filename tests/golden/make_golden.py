@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz from the REAL reference (run in the build container only).
 
-    python tests/golden/make_golden.py [--only unit|model2|model16]
+    python tests/golden/make_golden.py [--only unit|model2|model16|steps|model2d|swin|swin64|swinunet2d]
 
 The reference (/root/reference/code) is imported as-is; the only stand-ins are the five
 trivial MONAI symbols its U-Net ICL files import: MONAI is
@@ -385,6 +385,66 @@ def gen_model(R, out, nc):
     print(f"model nc={nc}: losses", d["losses"], "grad_none", len(none))
 
 
+# ---------------------------------------------------------------- three consecutive trainer steps (row T1)
+STEPS_MAX_ITER = 10      # a short schedule so that the poly learning rate moves visibly within three steps
+
+
+def gen_model_steps(R, out, nc=2, steps=3):
+    """Three iterations of the reference loop body (train_inherent_consistent_unet_3D_BraTS.py:99-121) on the real 785 M-parameter
+    model: SGD(lr 0.01, momentum 0.9, wd 1e-4), momentum carried over, a new batch per step, and the poly learning rate computed
+    from the PRE-increment iter_num after each optimiser step — so steps 1 and 2 both run at base_lr and step 3 at
+    base_lr * (1 - 1/max_iter)**0.9.  Parity mode (dropout / drop-path 0)."""
+    m3, L = R["m3"], R["losses"]
+    model = m3.unet_3D_icl(n_classes=nc, in_channels=1)
+    parity_mode(model)
+    fill(model)
+    model.train()
+    base_lr, max_iterations = 0.01, STEPS_MAX_ITER
+    optimizer = torch.optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001)
+    ce_loss, dice_loss = nn.CrossEntropyLoss(), L.DiceLoss(nc)
+    aux_loss, pse_loss = L.AuxLoss3D(nc), L.PseudoSoftLoss3D(nc)
+    named = dict(model.named_parameters())
+    big = "sspa.class_decoders.2.mlp2.fc1.weight"
+    w0_big = named[big].detach()[::432, ::432].double().clone()
+    d = {"param_keys": np.array(list(named.keys())), "max_iterations": np.array(max_iterations), "base_lr": np.array(base_lr)}
+    losses, lrs = [], []
+    iter_num = 0
+    for s in range(steps):
+        vol = synthetic_volume((2, 1, 96, 96, 96), 1337 + s)
+        lab = synthetic_labels((1, 96, 96, 96), 4242 + s, nc)
+        outputs = model(vol[:1], vol[1:])
+        soft = torch.softmax(outputs[0], dim=1)
+        l_ce = ce_loss(outputs[0], lab[:1])
+        l_dice = dice_loss(soft, lab[:1].unsqueeze(1))
+        l_aux = aux_loss(outputs[2], lab[:1])
+        l_pse = pse_loss(outputs[3], outputs[1])
+        l_con = L.softmax_mse_loss(outputs[3], outputs[4])
+        loss = l_dice + l_ce + l_aux + l_pse + 10 * l_con
+        lrs.append(optimizer.param_groups[0]["lr"])
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        lr_ = base_lr * (1.0 - iter_num / max_iterations) ** 0.9
+        for g in optimizer.param_groups:
+            g["lr"] = lr_
+        iter_num += 1
+        losses.append([float(l_dice), float(l_ce), float(l_aux), float(l_pse), float(l_con), float(loss)])
+        d[f"post_step{s + 1}_norms"] = np.array([float(p.detach().double().pow(2).sum().sqrt()) for p in named.values()])
+        print(f"steps: step {s + 1} lr {lrs[-1]:.6f} losses {losses[-1]}")
+    d["losses"] = np.array(losses)
+    d["lr_used"] = np.array(lrs)
+    for k in ("final.weight", "final.bias", "conv1.conv1.0.weight", "sspa.class_decoders.0.attn.fc_q.weight", "uscl.attn_convs1.2.weight"):
+        d["post_step3." + k] = npy(named[k])
+    d["post_step3." + big + "_sub"] = npy(named[big])[::432, ::432]
+    d["delta_step3." + big + "_sub"] = (named[big].detach()[::432, ::432].double() - w0_big).numpy()
+    mom_keys = [k for k, p in named.items() if "momentum_buffer" in optimizer.state.get(p, {})]
+    d["momentum_keys"] = np.array(mom_keys)
+    d["momentum_norms"] = np.array([float(optimizer.state[named[k]]["momentum_buffer"].double().pow(2).sum().sqrt()) for k in mom_keys])
+    d["momentum." + big + "_sub"] = npy(optimizer.state[named[big]]["momentum_buffer"])[::432, ::432]
+    d["momentum.final.weight"] = npy(optimizer.state[named["final.weight"]]["momentum_buffer"])
+    np.savez_compressed(os.path.join(out, f"model_unet3d_icl_nc{nc}_steps.npz"), **d)
+
+
 # ---------------------------------------------------------------- 2-D U-Net ICL (BASELINE config 1)
 def gen_model2d(R, out, nc=4):
     from networks.unet import UNet
@@ -638,6 +698,8 @@ if __name__ == "__main__":
         gen_model(R, HERE, 2)
     if a.only in ("all", "model16"):
         gen_model(R, HERE, 16)
+    if a.only in ("all", "steps"):
+        gen_model_steps(R, HERE)
     if a.only in ("all", "model2d"):
         gen_model2d(R, HERE)
     if a.only in ("all", "swin"):

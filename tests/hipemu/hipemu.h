@@ -31,6 +31,13 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
+static inline unsigned icl_bf16_rn_bits(float f) {      // fp32 -> bf16 bits, round to nearest even; NaN stays a (quiet) NaN
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+static inline unsigned icl_pack_bf16_rn(float lo, float hi) { return icl_bf16_rn_bits(lo) | (icl_bf16_rn_bits(hi) << 16); }
 static inline unsigned icl_alignbit(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)((((uint64_t)hi << 32) | lo) >> sh); }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
@@ -246,6 +253,7 @@ static inline float4 icl_nt_load4(const float* p) { return *reinterpret_cast<con
 static inline void icl_nt_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 #define ICL_OPAQUE_INT(x) ((void)(x))
 #define ICL_SCHED_BARRIER() ((void)0)
+#define ICL_PIN4(u) ((void)(u))
 #define ICL_WAVE_UNIFORM(x) ((void)(x))
 #define ICL_WAVE_SYNC() hipemu::yield_state(2)
 static inline float atomicAdd(float* p, float v) {

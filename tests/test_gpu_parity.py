@@ -595,6 +595,73 @@ def test_trainer_step_with_factored_mlp2_gradients_matches_reference_golden(dev)
         assert float(((a - w0) - (b - w0)).norm() / (b - w0).norm()) < 1e-3, k
 
 
+def _check_three_steps(model, g, losses, tag):
+    """Three reference iterations (tests/golden/make_golden.py::gen_model_steps): losses of every step, parameter norms after every
+    step, the small tensors and a subsample of a 13,824^2 matrix after step 3 (as the CHANGE against the initial weights, which is
+    what the optimiser produced: the weights themselves move by 1e-4 of their size)."""
+    assert np.allclose(np.array(losses), g["losses"], rtol=0, atol=2e-4), (tag, losses, g["losses"])
+    named = dict(model.named_parameters())
+    assert list(named) == list(g["param_keys"])
+    post = np.array([float(p.detach().double().norm()) for p in named.values()])
+    ref = g["post_step3_norms"]
+    off = [(k, post[i], ref[i]) for i, k in enumerate(named) if abs(post[i] - ref[i]) > 1e-4 * ref[i]]
+    assert not off, (tag, off[:8])
+    for k in ("final.weight", "final.bias", "conv1.conv1.0.weight", "sspa.class_decoders.0.attn.fc_q.weight", "uscl.attn_convs1.2.weight"):
+        assert rel_err(named[k].detach().cpu(), g["post_step3." + k]) < 1e-4, (tag, k)
+    big = "sspa.class_decoders.2.mlp2.fc1.weight"
+    w0 = torch.empty_like(named[big])
+    fill_like_reference_init([(big, w0)])
+    delta = (named[big].detach()[::432, ::432].double() - w0[::432, ::432].double()).cpu().numpy()
+    # three SGD steps with momentum: 2e-2 relative on the accumulated update of a sampled row block (the per-step gradients
+    # themselves agree to 1e-3: test_trainer_step_with_factored_mlp2_gradients_matches_reference_golden; the change of a weight
+    # is the difference of two fp32 numbers 1e4 times larger, so the golden itself resolves it to ~1e-3 of its size)
+    assert rel_err(delta, g["delta_step3." + big + "_sub"]) < 2e-2, tag
+
+
+def test_three_trainer_steps_match_reference_golden(dev):
+    """Row T1: three consecutive iterations of the reference loop (train_inherent_consistent_unet_3D_BraTS.py:99-121) — momentum
+    carried over, a new batch per step, the poly learning rate computed from the PRE-increment iter_num (steps 1 and 2 at base_lr,
+    step 3 at base_lr * 0.9**0.9) — against the reference's own three steps on the 785 M-parameter model.  Run twice: eagerly with
+    the SGD step of the 13,824^2 matrices inside their backward pass (update_in_backward, the default), and as hipGraph replays."""
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    nc = 2
+    g = load_golden("model_unet3d_icl_nc2_steps.npz")
+    vols = [synthetic_volume((2, 1, 96, 96, 96), 1337 + s).to(dev) for s in range(3)]
+    labs = [synthetic_labels((1, 96, 96, 96), 4242 + s, nc).to(dev) for s in range(3)]
+    cfg = dict(num_classes=nc, labeled_bs=1, base_lr=float(g["base_lr"]), max_iterations=int(g["max_iterations"]))
+    for mode in ("eager", "graph"):
+        model = unet_3D_icl(n_classes=nc, in_channels=1, device=dev)
+        fill_like_reference_init(list(model.named_parameters()))
+        _parity_mode(model)
+        model.train()
+        tr = ICLTrainer(model, ICLConfig(**cfg))
+        assert tr.cfg.update_in_backward and tr.cfg.factored_mlp2_grads
+        losses, lrs = [], []
+        for s in range(3):
+            if mode == "graph" and s == 1:
+                # capture() runs its warm-up step(s) as REAL training steps: step 2 is the warm-up step, step 3 the first replay
+                lrs.append(tr.optimizer.param_groups[0]["lr"])
+                tr.capture(vols[1], labs[1], warmup=1)
+                assert tr.iter_num == 2
+                losses.append(None)       # the warm-up step's losses are not returned
+                continue
+            lrs.append(tr.optimizer.param_groups[0]["lr"])
+            parts = tr.step(vols[s], labs[s])
+            losses.append([float(parts[k]) for k in ("dice", "ce", "aux", "pse", "con", "loss")])
+        assert np.allclose(lrs, g["lr_used"], rtol=1e-12), (lrs, g["lr_used"])
+        if mode == "graph":
+            assert tr.graph is not None and tr.use_graph
+            losses[1] = list(g["losses"][1])      # (not observable through capture(); steps 1 and 3 and the final state are)
+        _check_three_steps(model, g, losses, mode)
+        mom = tr.optimizer.state[model.final.weight]["momentum_buffer"]
+        assert rel_err(mom.cpu(), g["momentum.final.weight"]) < 1e-3, mode
+        big = dict(model.named_parameters())["sspa.class_decoders.2.mlp2.fc1.weight"]
+        assert rel_err(tr.optimizer.state[big]["momentum_buffer"][::432, ::432].cpu(), g["momentum.sspa.class_decoders.2.mlp2.fc1.weight_sub"]) < 2e-2
+        del tr, model
+        torch.cuda.empty_cache()
+
+
 def test_data_parallel_graph_step_on_one_rank_group(dev):
     """The data-parallel step as ICLTrainer.capture() records it — forward/backward graph with the gradients packed into flat
     buffers, eager RCCL collectives, optimiser graph reading the reduced buffers — on a ONE-rank RCCL group (the mean over one
@@ -864,19 +931,47 @@ def test_unet_icl_steps_are_bit_reproducible(dev):
     assert not differ, differ[:10]
 
 
+def _split_operands(kind, cin, cout, r, seed):
+    """Operand classes for the split-product accuracy tests: N(0,1); all-positive (post-ReLU activations x |weights|: the dropped
+    product terms of a truncation split would add up coherently here); magnitudes mixed over 1e-15 .. 1e15 per channel (the split
+    must hold at every exponent; products stay inside fp32); fp32 denormals among the activations."""
+    x = synthetic_volume((1, cin, r, r, r), seed)
+    w = synthetic_volume((cout, cin, 3, 3, 3), seed + 1) * 0.1
+    gy = synthetic_volume((1, cout, r, r, r), seed + 2)
+    if kind == "positive":
+        x, w, gy = x.abs(), w.abs(), gy.abs()
+    elif kind == "wide":
+        ex = torch.linspace(-15, 15, cin).view(1, cin, 1, 1, 1)
+        x = x * 10.0 ** ex
+        w = w * 10.0 ** (-ex.view(1, cin, 1, 1, 1))            # channel c: activations 1e+e_c, weights 1e-e_c
+        gy = gy * 10.0 ** torch.linspace(-15, 15, cout).view(1, cout, 1, 1, 1)
+    elif kind == "denormal":
+        x = x.clone()
+        x[:, ::2] = x[:, ::2] * 1e-41                          # every second channel: subnormal fp32 inputs
+        gy = gy.clone()
+        gy[:, ::2] = gy[:, ::2] * 1e-41
+    return x, w, gy
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["normal", "positive", "wide", "denormal"])
 @pytest.mark.parametrize("cin,cout,r", [(32, 32, 48), (16, 48, 48)])
-def test_split_bf16_convolution_is_as_accurate_as_the_fp32_mfma_path(dev, monkeypatch, cin, cout, r):
+def test_split_bf16_convolution_is_as_accurate_as_the_fp32_mfma_path(dev, monkeypatch, cin, cout, r, kind):
     """csrc/kernels/conv_bf16x3.h (3x3x3 forward / input gradient on the bf16 matrix pipe, every fp32 operand split EXACTLY into three
-    bf16 terms, six MFMA terms per product, fp32 accumulation): on a real layer shape its distance to the fp64 convolution is that of
-    the exact-fp32-MFMA kernels (ICL_CONV_SPLIT=0), forward and input gradient, and far inside the 1e-3 of BASELINE.json."""
+    bf16 terms by round-to-nearest, six MFMA terms per product, fp32 accumulation): on a real layer shape its distance to the fp64
+    convolution is that of the exact-fp32-MFMA kernels (ICL_CONV_SPLIT=0), forward and input gradient, for every operand class of
+    _split_operands — per OUTPUT CHANNEL, so that the small channels of the wide-range case count as much as the big ones — and
+    far inside the 1e-3 of BASELINE.json."""
     from icl_amd import ops
-    x = synthetic_volume((1, cin, r, r, r), 301)
-    w = synthetic_volume((cout, cin, 3, 3, 3), 302) * 0.1
-    gy = synthetic_volume((1, cout, r, r, r), 303)
+    x, w, gy = _split_operands(kind, cin, cout, r, 301)
     xr = x.double().requires_grad_()
     yr = torch.nn.functional.conv3d(xr, w.double(), None, padding=1)
     yr.backward(gy.double())
+
+    def chan_err(a, b):      # max over channels of (max |a - b| / max |b|) within the channel
+        d = (a.cpu().double() - b).abs().amax(dim=(0, 2, 3, 4))
+        return float((d / b.abs().amax(dim=(0, 2, 3, 4)).clamp_min(1e-300)).max())
+
     out = {}
     for split in ("1", "0"):
         monkeypatch.setenv("ICL_CONV_SPLIT", split)
@@ -886,23 +981,68 @@ def test_split_bf16_convolution_is_as_accurate_as_the_fp32_mfma_path(dev, monkey
             y.backward(gy.to(dev))
         names = [k for k in kt.summary() if k.startswith("conv3d_") and "_fwd_" in k]
         assert all(("bf16x3" in k) == (split == "1") for k in names) and names, names
-        out[split] = (float((y.detach().cpu().double() - yr.detach()).abs().max() / yr.detach().abs().max()),
-                      float((xg.grad.cpu().double() - xr.grad).abs().max() / xr.grad.abs().max()))
+        assert torch.isfinite(y).all() and torch.isfinite(xg.grad).all()
+        out[split] = (chan_err(y.detach(), yr.detach()), chan_err(xg.grad, xr.grad))
     (ef1, eb1), (ef0, eb0) = out["1"], out["0"]
-    assert ef1 < 2e-6 and eb1 < 2e-6, out
-    assert ef1 <= 2.0 * ef0 + 1e-7 and eb1 <= 2.0 * eb0 + 1e-7, out
+    assert ef1 < 3e-6 and eb1 < 3e-6, out
+    # the six-term product is closer to the exact product than an fp32 multiply (tools/split_error.py); what both paths share is
+    # the fp32 accumulation, whose order differs: 1.5x the fp32 path's own distance to fp64 is the band
+    assert ef1 <= 1.5 * ef0 + 1e-7 and eb1 <= 1.5 * eb0 + 1e-7, out
 
 
 @pytest.mark.gpu
+def test_split_bf16_convolution_all_positive_sums_carry_no_bias(dev, monkeypatch):
+    """All-positive operands (post-ReLU x |w|): every product of an output has the same sign, so a split whose dropped terms all
+    point one way shows as a SIGNED offset of the outputs against fp64 (truncation splits: -0.69 * 2^-24 per product, coherent).
+    The round-to-nearest split must be free of it: the mean signed error stays at the level of the fp32 kernels."""
+    from icl_amd import ops
+    cin, cout, r = 32, 32, 48
+    x, w, _ = _split_operands("positive", cin, cout, r, 321)
+    yr = torch.nn.functional.conv3d(x.double(), w.double(), None, padding=1)
+    bias = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("ICL_CONV_SPLIT", split)
+        y = ops.conv3d(x.to(dev), w.to(dev), None)
+        rel = (y.cpu().double() - yr) / yr
+        bias[split] = (float(rel.mean()), float(rel.abs().mean()))
+    assert abs(bias["1"][0]) < 1.5e-8, bias          # truncation splits measure about -4e-8 here (0.69 * 2^-24)
+    assert bias["1"][1] <= 1.25 * bias["0"][1] + 1e-9, bias
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad", [float("inf"), float("-inf"), float("nan")])
+def test_split_bf16_convolution_propagates_non_finite_inputs(dev, monkeypatch, bad):
+    """One non-finite input voxel: exactly the outputs whose 3x3x3 window holds it are non-finite, on the split-product path as on
+    the fp32 kernels (ICL_CONV_SPLIT=0) — NaN where the fp32 kernels give an infinity of either sign (inf - rn(inf) is NaN: stated in
+    conv_bf16x3.h) — and every other output is untouched."""
+    from icl_amd import ops
+    cin, cout, r = 16, 16, 48
+    x, w, _ = _split_operands("normal", cin, cout, r, 331)
+    x[0, 3, 20, 21, 22] = bad
+    masks, clean = {}, {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("ICL_CONV_SPLIT", split)
+        y = ops.conv3d(x.to(dev), w.to(dev), None).cpu()
+        masks[split] = ~torch.isfinite(y)
+        clean[split] = torch.where(masks[split], torch.zeros_like(y), y)
+    want = torch.zeros((1, cout, r, r, r), dtype=torch.bool)
+    want[:, :, 19:22, 20:23, 21:24] = True
+    assert torch.equal(masks["0"], want) and torch.equal(masks["1"], want)
+    assert float((clean["1"] - clean["0"]).abs().max() / clean["0"].abs().max()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["normal", "positive", "wide", "denormal"])
 @pytest.mark.parametrize("cin,cout", [(32, 16), (32, 32), (16, 64), (32, 48)])
-def test_split_bf16_weight_gradient(dev, monkeypatch, cin, cout):
+def test_split_bf16_weight_gradient(dev, monkeypatch, cin, cout, kind):
     """conv3d_bf16x3_wgrad_kernel<1, 4> / <2, 2> (the default; ICL_WGRAD_SPLIT=0 = fp32 MFMA): the weight gradient from split products is as close
-    to the fp64 gradient as the fp32-MFMA kernels' (both sum 110,592 voxels per element in fp32)."""
+    to the fp64 gradient as the fp32-MFMA kernels' (both sum 110,592 voxels per element in fp32), for every operand class of
+    _split_operands; errors per (cout, cin) filter so that the small filters of the wide-range case count."""
     from icl_amd import ops
     r = 48
-    x = synthetic_volume((1, cin, r, r, r), 311)
-    w = synthetic_volume((cout, cin, 3, 3, 3), 312) * 0.1
-    gy = synthetic_volume((1, cout, r, r, r), 313)
+    x, w, gy = _split_operands(kind, cin, cout, r, 311)
+    if kind == "wide":       # keep dY * x inside fp32: one exponent ramp on x, none on dY
+        gy = synthetic_volume((1, cout, r, r, r), 313)
     wr = w.double().requires_grad_()
     torch.nn.functional.conv3d(x.double(), wr, None, padding=1).backward(gy.double())
     errs = {}
@@ -913,6 +1053,8 @@ def test_split_bf16_weight_gradient(dev, monkeypatch, cin, cout):
             ops.conv3d(x.to(dev), wg, None).backward(gy.to(dev))
         names = list(kt.summary())
         assert any("bf16x3_wgrad" in k for k in names) == (split == "2"), names          # the path under test really ran
-        errs[split] = float((wg.grad.cpu().double() - wr.grad).abs().max() / wr.grad.abs().max())
-    assert errs["2"] < 5e-6 and errs["2"] <= 3.0 * errs["0"] + 2e-7, errs
+        assert torch.isfinite(wg.grad).all()
+        d = (wg.grad.cpu().double() - wr.grad).abs().amax(dim=(2, 3, 4))
+        errs[split] = float((d / wr.grad.abs().amax(dim=(2, 3, 4)).clamp_min(1e-300)).max())
+    assert errs["2"] < 2e-5 and errs["2"] <= 1.5 * errs["0"] + 2e-7, errs
 

@@ -71,9 +71,12 @@ def test_conv3d_wgrad_row_window_kernel(monkeypatch, mode, n, cin, cout, d, h, w
     (1, 20, 32, 3, 9, 24),      # weight gradient with two cout blocks per workgroup (2 x 8 x 16 tiles): ragged cin block, partial tiles
     (2, 16, 60, 2, 8, 16),      # ... two such workgroup columns, the last cout block ragged (60 -> 64), two samples
 ])
-def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w):
+@pytest.mark.parametrize("variant", ["1", "0"])
+def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w, variant):
     """conv_bf16x3.h: forward and input gradient with each fp32 operand split exactly into three bf16 terms (six bf16 MFMA terms per
-    product, fp32 accumulation) — same tolerance as the fp32-MFMA kernels, and the two paths agree to fp32 rounding."""
+    product, fp32 accumulation) — same tolerance as the fp32-MFMA kernels, and the two paths agree to fp32 rounding.  variant: the
+    schedule of the forward kernel (1 = split planes produced inside the multiply phase, the default; 0 = in the store phase)."""
+    monkeypatch.setenv("ICL_CONV_SPLIT_V", variant)
     monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
     monkeypatch.setenv("ICL_CONV_SPLIT", "1")
     monkeypatch.setenv("ICL_WGRAD_SPLIT", "2")      # split-product weight gradient for every Cout (the default)
@@ -86,7 +89,9 @@ def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w):
         y0 = ops.conv3d(x, wt, None)
     ref = F.conv3d(x.double(), wt.double(), None, padding=1)
     e1, e0 = float((y1.double() - ref).abs().max()), float((y0.double() - ref).abs().max())
-    assert e1 <= 4.0 * e0 + 2e-7 * float(ref.abs().max()), (e1, e0)     # about as close to the fp64 result as the fp32-MFMA path
+    # about as close to the fp64 result as the fp32-MFMA path (a max over a few thousand outputs of two different summation orders:
+    # the emulated bf16 MFMA rounds once per 32 products; the accuracy statement proper is the GPU test on real layer shapes)
+    assert e1 <= 3.0 * e0 + 2e-7 * float(ref.abs().max()), (e1, e0)
 
 
 def test_conv3d_forced_big_tile(monkeypatch):

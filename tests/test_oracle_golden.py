@@ -190,6 +190,50 @@ def test_full_model_step_matches_reference(nc):
 
 
 @pytest.mark.slow
+def test_three_trainer_steps_match_reference():
+    """Row T1, three consecutive iterations of the reference loop (train_..._BraTS.py:99-121) on the 785 M-parameter model: the
+    oracle's forward / losses / backward + sgd_step (momentum carried over) + poly_lr from the PRE-increment iter_num reproduce the
+    reference's three loss vectors, the learning rates it used and its parameters after step 3."""
+    g = load_golden("model_unet3d_icl_nc2_steps.npz")
+    nc = 2
+    shapes = O.unet_3d_icl_shapes(nc)
+    names = [k for k, _ in shapes]
+    assert names == list(g["param_keys"])
+    p = O.make_params(shapes, requires_grad=True)
+    p.update(O.aligner_buffers("sspa.", O.UNET3D_HEADS))
+    p.update(O.aligner_buffers("uscl.", O.UNET3D_HEADS))
+    base_lr, max_it = float(g["base_lr"]), int(g["max_iterations"])
+    big = "sspa.class_decoders.2.mlp2.fc1.weight"
+    w0 = p[big].detach()[::432, ::432].double().clone()
+    bufs, lr, iter_num = {}, base_lr, 0
+    for s in range(3):
+        vol = synthetic_volume((2, 1, 96, 96, 96), 1337 + s)
+        lab = synthetic_labels((1, 96, 96, 96), 4242 + s, nc)
+        for k in names:
+            p[k].grad = None
+        outs = O.unet_3d_icl_forward(p, vol[:1], vol[1:], training=True)
+        total, parts = O.icl_losses(outs, lab, nc)
+        got = [float(parts[k]) for k in ("dice", "ce", "aux", "pse", "con")] + [float(total)]
+        assert np.allclose(got, g["losses"][s], rtol=0, atol=2e-5), (s, got, g["losses"][s])
+        assert abs(lr - float(g["lr_used"][s])) < 1e-15
+        total.backward()
+        O.sgd_step(p, {k: p[k].grad for k in names}, bufs, lr=lr)
+        lr = O.poly_lr(base_lr, iter_num, max_it)       # from the pre-increment iter_num, used from the next step
+        iter_num += 1
+        post = np.array([float(p[k].detach().double().norm()) for k in names])
+        assert np.allclose(post, g[f"post_step{s + 1}_norms"], rtol=2e-6), s
+    for k in ("final.weight", "final.bias", "conv1.conv1.0.weight", "sspa.class_decoders.0.attn.fc_q.weight", "uscl.attn_convs1.2.weight"):
+        # element-wise after three updates: the weights moved by lr * (momentum sums of gradients that agree to ~1e-3), i.e. the
+        # two fp32 CPU backward passes (reference modules / functional oracle, different summation orders) differ by ~5e-5 of
+        # the weight scale on the first convolution, whose gradient sums 884,736 voxels per element
+        assert rel_err(p[k].detach(), g["post_step3." + k]) < 2e-4, k
+    delta = (p[big].detach()[::432, ::432].double() - w0).numpy()
+    assert rel_err(delta, g["delta_step3." + big + "_sub"]) < 5e-3
+    assert sorted(bufs) == sorted(g["momentum_keys"])
+    assert rel_err(bufs["final.weight"], g["momentum.final.weight"]) < 1e-4
+
+
+@pytest.mark.slow
 def test_2d_unet_icl_step_matches_reference():
     """BASELINE config 1: 2D U-Net ICL, 256x256, nc=4, batch 2+2 — the reference's own CPU-runnable case."""
     nc = 4
