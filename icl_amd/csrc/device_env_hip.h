@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,6 +33,15 @@ typedef float icl_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned icl_pack_bf16_rn(float lo, float hi) {
   const icl_f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, icl_bf16x2));
+}
+
+// ds_read_b64_tr_b16: transposing LDS read of 16-bit elements.  Within each group of 16 consecutive lanes, lane 4q + p supplies the
+// address of row q, columns 4p .. 4p + 3 (8 bytes) of a 4-row x 16-column block; lane i receives column i of the four rows, row q in
+// element q (cdna_hip_programming.md T10).  EXEC must be all ones.  Returns the four 16-bit elements as two dwords.
+typedef short icl_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 icl_lds_read_tr16_b64(const void* lds_ptr) {
+  typedef __attribute__((address_space(3))) icl_s16x4 lds_s16x4;
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lds_ptr));
 }
 
 // v_alignbit_b32: bits [sh, sh + 32) of the 64-bit value {hi, lo}

@@ -102,19 +102,22 @@ __global__ __launch_bounds__(256) void conv_bf16x3_split_weights_kernel(const fl
   }
 }
 
-// V = 0: the round-2 schedule (halo values kept as fp32 until the store phase, which splits them between two barriers: VALU, LDS
-//        and matrix phases of the eight waves add up).
-// V = 1: the halo loads are straight-line (clamped address + select: V = 0 emits a branch per predicated load), and each staging
-//        round is split into its three packed bf16 planes INSIDE the multiply phase, one round per tap pair of the dz = 1 / 2
-//        stages, so that the split VALU of one wave issues in the shadow of the MFMAs (its own and its SIMD partner's); the store
-//        phase between the barriers is then 15 ds_write_b128 per thread and nothing else.
-template <int NBT, int TY, int V = 1>
+// Schedule variants (ICL_CONV_SPLIT_V, A/B tool tools/conv_ab.py):
+// V = 0: the round-2 schedule: halo values stay fp32 until the store phase, which splits them between two barriers.
+// V & 1: straight-line halo loads (clamped address + select; V = 0 emits exec-mask branches around the predicated loads).
+// V & 2: each staging round is split into its three packed bf16 planes INSIDE the multiply phase (one round per tap pair of the
+//        dz = 1 / 2 stages, pinned there), so that the store phase is 15 ds_write_b128 per thread and nothing else.  MEASURED
+//        SLOWER (round 3, batch 2: 16->16 @96^3 171 vs 161 us, 48->16 473 vs 438, 32->32 @48^3 71.8 vs 67.8): the two waves of a
+//        SIMD run the multiply phase together, the matrix pipe is already saturated there, and the extra VALU lengthens each
+//        wave's in-order stream instead of hiding in the other wave's MFMAs.  Kept as a measurement variant, not the default.
+template <int NBT, int TY, int V = 0>
 __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {
   typedef Bf3T<TY> TC;
   // three cout blocks: 48 accumulators + 36 weight-fragment + 24 weight-prefetch registers leave no room for the split planes
   // (432 B of scratch when tried): those instantiations take the straight-line loads of V = 1 and keep the split in the store phase
-  constexpr bool EARLY = V != 0 && NBT < 3;
+  constexpr bool EARLY = (V & 2) != 0 && NBT < 3;
+  constexpr bool STRAIGHT = (V & 1) != 0;
   constexpr int NB = 16 * NBT, PX = TC::PX, PY = TC::PY, NPOSP = TC::NPOSP, ROUNDS = TC::ROUNDS, NT = TC::NT;
   constexpr int WITEMS = 6 * Bf3::SLOTS * NB, WU = (WITEMS + NT - 1) / NT;      // 16-byte weight slots per dz plane
   ICL_DYN_LDS(uint4, lds);
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       const bool ok = (s_zyx[r] >= 0) & ((unsigned)gz < (unsigned)g.D) & ((unsigned)gy < (unsigned)g.H) & ((unsigned)gx < (unsigned)g.W);
       // 32-bit lane offset against a wave-uniform channel base (16 channels x D*H*W < 2^31 elements, checked by the launcher)
       const int off = ok ? s_ch[r] * (int)DHW + gz * (int)HW + gy * g.W + gx : 0;
-      if (V == 0) {
+      if (!STRAIGHT) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) xv[r][c] = ok ? (xb + c * DHW)[off] : 0.f;
       } else {

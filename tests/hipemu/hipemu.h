@@ -20,6 +20,7 @@
 #include <cstring>
 #include <functional>
 #include <thread>
+#include <type_traits>
 #include <ucontext.h>
 #include <vector>
 
@@ -30,6 +31,8 @@ struct dim3 {
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
 static inline unsigned icl_bf16_rn_bits(float f) {      // fp32 -> bf16 bits, round to nearest even; NaN stays a (quiet) NaN
   uint32_t u;
@@ -248,6 +251,22 @@ template <typename T> static inline T __shfl(T v, int src, int width = 64) {
   return hipemu_shfl_from(v, (l & ~(width - 1)) | (src & (width - 1)));
 }
 
+// ds_read_b64_tr_b16 (device_env_hip.h): lane i of a 16-lane group receives, for q = 0..3, the 16-bit element i & 3 of the 8 bytes
+// addressed by lane 4q + (i >> 2) of its group
+static inline uint2 icl_lds_read_tr16_b64(const void* lds_ptr) {
+  uint64_t a = (uint64_t)(uintptr_t)lds_ptr;
+  uint32_t pub[2] = {(uint32_t)a, (uint32_t)(a >> 32)};
+  hipemu::wave_publish(pub, 2);
+  const int l = hipemu_lane(), g0 = l & ~15, i = l & 15;
+  uint16_t e[4];
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t* pa = hipemu::wave_peer(g0 + 4 * q + (i >> 2));
+    const uint16_t* src = reinterpret_cast<const uint16_t*>((uintptr_t)(((uint64_t)pa[1] << 32) | pa[0]));
+    e[q] = src[i & 3];
+  }
+  hipemu::wave_done();
+  return make_uint2((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16));
+}
 static inline float icl_fast_exp(float x) { return expf(x); }
 static inline float4 icl_nt_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static inline void icl_nt_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
