@@ -356,6 +356,8 @@ struct Bf3WGeom {
   int ntz, nty, ntx, ntiles;      // tiles per sample; ntiles = batch * ntz * nty * ntx
   int tiles_per_wg;               // contiguous run of tiles per workgroup (blockIdx.x)
   long x_bstride, gy_bstride;
+  int dbg;                        // timing ablations of conv_wgrad_tr.h (ICL_WGRAD_TR_DBG; results are wrong when set): 1 no global
+                                  // loads, 2 no split / LDS stores, 4 no multiply
 };
 
 // NCB cout blocks of 16 per workgroup (every staged x value then feeds NCB x 27 x 6 MFMA terms) on a TZ x 8 x 16 voxel tile:

@@ -84,13 +84,14 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
       s_nch[r] = live ? g.Cout - co0 - ob * 8 : 0;
     }
   }
-  float raw[C::ROUNDS][8];
+  float raw[C::ROUNDS][8] = {};
   auto tile_origin = [&](int tile, int& b, int& x0, int& y0, int& z0) {
     b = tile / tiles_per;
     const int bt = tile % tiles_per;
     x0 = (bt % g.ntx) * C::TX; y0 = ((bt / g.ntx) % g.nty) * C::TY; z0 = (bt / (g.ntx * g.nty)) * C::TZ;
   };
   auto load_tile = [&](int tile) {
+    if (g.dbg & 1) return;
     int b, x0, y0, z0;
     tile_origin(tile, b, x0, y0, z0);
     const float* xb = x + (long)b * g.x_bstride + (long)c0 * DHW;
@@ -100,21 +101,23 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
     for (int r = 0; r < C::ROUNDS; ++r) {
       const int gz = z0 - 1 + (s_zyx[r] >> 16), gyy = y0 - 1 + ((s_zyx[r] >> 8) & 255), gx = x0 - 1 + (s_zyx[r] & 255);
       const bool ok = (s_zyx[r] >= 0) & ((unsigned)gz < (unsigned)g.D) & ((unsigned)gyy < (unsigned)g.H) & ((unsigned)gx < (unsigned)g.W);
-      const int off = ok ? org + s_rel[r] : 0;           // 32-bit lane offset against a wave-uniform plane base (launcher: < 2^31)
+      // 32-bit lane offset against a wave-uniform block base (launcher: 32 planes < 2^31 elements).  Lanes of an octet without a
+      // single existing channel (ragged Cin / Cout) and out-of-volume positions read offset 0 of the block.
+      const bool ok0 = ok & (s_nch[r] > 0);
       const float* base = s_isx[r] ? xb : gb;
-      const int last = (s_isx[r] ? g.Cin - c0 : g.Cout - co0) - 1;      // last existing channel plane of the block (wave-uniform)
-      // unconditional loads from always-valid addresses, then a select: the lane offset walks the channel planes that exist
-      // (dead lanes walk them from offset 0), so every load is base (scalar) + 32-bit lane offset and the code is straight-line
-      int idx = off;
+      // unconditional loads from always-valid addresses, then a select: the lane offset walks the channel planes of its octet that
+      // exist and stays on the last one, so the code is straight-line and never reads outside the tensor
+      int idx = ok0 ? org + s_rel[r] : 0;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const float v = base[idx];
-        raw[r][c] = (ok & (c < s_nch[r])) ? v : 0.f;
-        idx += c < last ? (int)DHW : 0;
+        raw[r][c] = (ok0 & (c < s_nch[r])) ? v : 0.f;
+        idx += (ok0 & (c + 1 < s_nch[r])) ? (int)DHW : 0;
       }
     }
   };
   auto store_tile = [&](uint4* buf) {
+    if (g.dbg & 2) return;
 #pragma unroll
     for (int r = 0; r < C::ROUNDS; ++r) {
       if (s_zyx[r] < 0) continue;
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
   };
   // TH = the wave's tap half as a compile-time constant (the two halves are two code paths: every tap offset is an immediate)
   auto multiply = [&](const uint4* buf, auto TH) {
+    if (g.dbg & 4) return;
     constexpr int tap0 = C::NTAPH * decltype(TH)::value, ntap = decltype(TH)::value ? 27 - C::NTAPH : C::NTAPH;
     const unsigned char* base = reinterpret_cast<const unsigned char*>(buf);
     uint4 a[NCB][3];
