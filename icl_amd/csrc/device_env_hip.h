@@ -44,6 +44,17 @@ __device__ __forceinline__ uint2 icl_lds_read_tr16_b64(const void* lds_ptr) {
   return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lds_ptr));
 }
 
+// buffer_load_dword through a 128-bit resource descriptor (base pointer + byte extent held in scalar registers): 32-bit lane
+// offset, and the hardware returns 0 for any offset outside the extent — a lane that must read nothing is handed an offset of
+// 2^31 instead of a clamped address plus a select.  Build the descriptor from wave-uniform values only (kernel arguments, blockIdx).
+typedef __amdgpu_buffer_rsrc_t icl_rsrc_t;
+__device__ __forceinline__ icl_rsrc_t icl_make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float icl_buffer_load_f32(icl_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
 // v_alignbit_b32: bits [sh, sh + 32) of the 64-bit value {hi, lo}
 __device__ __forceinline__ unsigned icl_alignbit(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 

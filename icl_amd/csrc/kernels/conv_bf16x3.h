@@ -47,7 +47,7 @@ struct Bf3T : Bf3Base {
   static constexpr int NW = TZ * TY / 4, NT = 64 * NW, ITEMS = 2 * NPOS, ROUNDS = (ITEMS + NT - 1) / NT;
   static constexpr int XS_U4 = 6 * NPOSP;                        // uint4 (8 bf16) units
   static constexpr int ws_u4(int nb) { return 6 * SLOTS * nb; }
-  static constexpr size_t lds_bytes(int nbt) { return (size_t)(XS_U4 + ws_u4(16 * nbt)) * 16; }
+  static constexpr size_t lds_bytes(int nbt, int planes = 1) { return (size_t)(XS_U4 + planes * ws_u4(16 * nbt)) * 16; }
 };
 typedef Bf3Base Bf3;
 
@@ -105,6 +105,11 @@ __global__ __launch_bounds__(256) void conv_bf16x3_split_weights_kernel(const fl
 // Schedule variants (ICL_CONV_SPLIT_V, A/B tool tools/conv_ab.py):
 // V = 0: the round-2 schedule: halo values stay fp32 until the store phase, which splits them between two barriers.
 // V & 1: straight-line halo loads (clamped address + select; V = 0 emits exec-mask branches around the predicated loads).
+// V & 4: halo loads as buffer loads (32-bit lane offset against a descriptor of the 16-channel chunk; out-of-volume and idle lanes
+//        are handed offset 2^31 and the hardware returns 0): no branches, no address clamps, no selects.
+// V & 8: (one cout block) all three weight planes of the channel chunk stay in LDS (43 KB beside the 104 KB halo tile) instead of
+//        one plane per dz stage: two barriers per work item instead of six, and a single-chunk layer (16 -> 16) loads its weights
+//        once per workgroup instead of once per tile.
 // V & 2: each staging round is split into its three packed bf16 planes INSIDE the multiply phase (one round per tap pair of the
 //        dz = 1 / 2 stages, pinned there), so that the store phase is 15 ds_write_b128 per thread and nothing else.  MEASURED
 //        SLOWER (round 3, batch 2: 16->16 @96^3 171 vs 161 us, 48->16 473 vs 438, 32->32 @48^3 71.8 vs 67.8): the two waves of a
@@ -117,9 +122,10 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   // three cout blocks: 48 accumulators + 36 weight-fragment + 24 weight-prefetch registers leave no room for the split planes
   // (432 B of scratch when tried): those instantiations take the straight-line loads of V = 1 and keep the split in the store phase
   constexpr bool EARLY = (V & 2) != 0 && NBT < 3;
-  constexpr bool STRAIGHT = (V & 1) != 0;
+  constexpr bool STRAIGHT = (V & 1) != 0, BUFFER = (V & 4) != 0, WHOLE = (V & 8) != 0 && NBT == 1;
+  constexpr int WPL = WHOLE ? 3 : 1;                    // weight planes staged together
   constexpr int NB = 16 * NBT, PX = TC::PX, PY = TC::PY, NPOSP = TC::NPOSP, ROUNDS = TC::ROUNDS, NT = TC::NT;
-  constexpr int WITEMS = 6 * Bf3::SLOTS * NB, WU = (WITEMS + NT - 1) / NT;      // 16-byte weight slots per dz plane
+  constexpr int WITEMS = WPL * 6 * Bf3::SLOTS * NB, WU = (WITEMS + NT - 1) / NT;      // 16-byte weight slots per staging step
   ICL_DYN_LDS(uint4, lds);
   uint4* Xs = lds;
   uint4* Ws = lds + TC::XS_U4;
@@ -158,7 +164,15 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       const bool ok = (s_zyx[r] >= 0) & ((unsigned)gz < (unsigned)g.D) & ((unsigned)gy < (unsigned)g.H) & ((unsigned)gx < (unsigned)g.W);
       // 32-bit lane offset against a wave-uniform channel base (16 channels x D*H*W < 2^31 elements, checked by the launcher)
       const int off = ok ? s_ch[r] * (int)DHW + gz * (int)HW + gy * g.W + gx : 0;
-      if (!STRAIGHT) {
+      if (BUFFER) {
+        const icl_rsrc_t xr = icl_make_rsrc(xb, (unsigned)(16 * DHW * 4));
+        unsigned boff = ok ? (unsigned)off * 4u : 0x80000000u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          xv[r][c] = icl_buffer_load_f32(xr, boff);
+          boff += (unsigned)DHW * 4u;
+        }
+      } else if (!STRAIGHT) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) xv[r][c] = ok ? (xb + c * DHW)[off] : 0.f;
       } else {
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   };
   // weights: already split (conv_bf16x3_split_weights_kernel): one dz plane = 60 NB slots of 16 bytes, copied through registers
   uint4 wv[WU];
-  auto load_w = [&](int chunk, int dz) {
+  auto load_w = [&](int chunk, int dz) {      // WHOLE: dz = 0 and all three planes (they are contiguous in the workspace)
     const uint4* src = wsplit + (long)(chunk * 3 + dz) * 6 * Bf3::SLOTS * g.CoutP + n0;
 #pragma unroll
     for (int i = 0; i < WU; ++i) {
@@ -244,6 +258,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       for (int r = 0; r < ROUNDS; ++r) split_round(r);
     }
   }
+  bool first_item = true;
   while (tile < g.ntiles) {
     int ntile = tile, nchunk = chunk + 1;
     if (nchunk == g.nchunks) { nchunk = 0; ntile = next_tile(tile); }
@@ -251,15 +266,22 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #if !defined(BF3_DEBUG) || !(BF3_DEBUG & 2)
     store_x();
 #endif
+    if (WHOLE && (g.nchunks > 1 || first_item)) store_w();
+    first_item = false;
 #pragma unroll
     for (int dz = 0; dz < 3; ++dz) {
-      if (dz > 0) __syncthreads();         // the previous plane's weights are no longer read
-      store_w();
-      __syncthreads();
-      // global loads one phase ahead: the next weight plane first (older in the in-order vmcnt queue: waiting for it leaves the
-      // halo tile of the next work item in flight), then — once per work item — that halo tile
-      if (dz < 2) load_w(chunk, dz + 1);
-      else if (ntile < g.ntiles) load_w(nchunk, 0);
+      if (!WHOLE) {
+        if (dz > 0) __syncthreads();         // the previous plane's weights are no longer read
+        store_w();
+        __syncthreads();
+        // global loads one phase ahead: the next weight plane first (older in the in-order vmcnt queue: waiting for it leaves the
+        // halo tile of the next work item in flight), then — once per work item — that halo tile
+        if (dz < 2) load_w(chunk, dz + 1);
+        else if (ntile < g.ntiles) load_w(nchunk, 0);
+      } else if (dz == 0) {
+        __syncthreads();
+        if (g.nchunks > 1 && ntile < g.ntiles) load_w(nchunk, 0);
+      }
       if (dz == 0 && ntile < g.ntiles) load_x(ntile, nchunk);
       // stage dz holds the tap slots 10 dz .. 10 dz + 9 (27 taps + one zero slot = 14 pairs in stages of 5 / 5 / 4: a pair may
       // straddle two dz planes); lane group tp takes the first or the second tap of the pair: its halo offset is a select
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-          for (int j = 0; j < NBT; ++j) b[s][j] = wb[(s * 2 * Bf3::SLOTS + pair * 2) * NB + j * 16];
+          for (int j = 0; j < NBT; ++j) b[s][j] = wb[((WHOLE ? dz * 6 : 0) * Bf3::SLOTS + s * 2 * Bf3::SLOTS + pair * 2) * NB + j * 16];
 #pragma unroll
         for (int m0 = 0; m0 < 4; m0 += MB) {
           uint4 a[MB][3];

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
   const int tiles_per = g.ntz * g.nty * g.ntx;
 
   // ---- staging tables (tile-invariant).  Item it = tid + r * NT: kind (halo x / tile dY) is uniform per (wave, round).
-  int s_zyx[C::ROUNDS], s_dst[C::ROUNDS], s_rel[C::ROUNDS], s_nch[C::ROUNDS];
+  int s_zyx[C::ROUNDS], s_dst[C::ROUNDS], s_rel[C::ROUNDS];
   bool s_isx[C::ROUNDS];
 #pragma unroll
   for (int r = 0; r < C::ROUNDS; ++r) {
@@ -73,7 +73,6 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
       s_zyx[r] = live ? (pz << 16) | (py << 8) | px : -1;
       s_dst[r] = o * 3 * C::NPOSP + pos;
       s_rel[r] = o * 8 * (int)DHW + pz * (int)HW + py * g.W + px;          // + tile origin - (1, 1, 1)
-      s_nch[r] = live ? g.Cin - c0 - o * 8 : 0;                            // valid channels of the octet (<= 0: none)
     } else {
       const int ig = it - C::XPAD, ob = ig / C::TPOS, pos = ig % C::TPOS;
       const int tx = pos % C::TX, ty = (pos / C::TX) % C::TY, tz = pos / (C::TX * C::TY);
@@ -81,48 +80,47 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
       s_zyx[r] = live ? ((tz + 1) << 16) | ((ty + 1) << 8) | (tx + 1) : -1;  // same origin convention as the halo items
       s_dst[r] = C::XS_U4 + ob * 3 * C::TPOSP + pos;
       s_rel[r] = ob * 8 * (int)DHW + (tz + 1) * (int)HW + (ty + 1) * g.W + tx + 1;
-      s_nch[r] = live ? g.Cout - co0 - ob * 8 : 0;
     }
   }
-  float raw[C::ROUNDS][8] = {};
+  // the loads of a tile travel TWO phases ahead of the phase that splits them (a phase lasts 2-3 us, about one load latency under
+  // load: one phase ahead left the latency half exposed — ablation: loads alone 126 us of a 206 us launch, 16->16 @96^3):
+  // raw[j & 1] holds tile j; the tile loop is unrolled by two so that every index is a constant
+  float raw[2][C::ROUNDS][8] = {};
   auto tile_origin = [&](int tile, int& b, int& x0, int& y0, int& z0) {
     b = tile / tiles_per;
     const int bt = tile % tiles_per;
     x0 = (bt % g.ntx) * C::TX; y0 = ((bt / g.ntx) % g.nty) * C::TY; z0 = (bt / (g.ntx * g.nty)) * C::TZ;
   };
-  auto load_tile = [&](int tile) {
+  auto load_tile = [&](int tile, auto SLOT) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOT)::value;
     if (g.dbg & 1) return;
     int b, x0, y0, z0;
     tile_origin(tile, b, x0, y0, z0);
-    const float* xb = x + (long)b * g.x_bstride + (long)c0 * DHW;
-    const float* gb = gy + (long)b * g.gy_bstride + (long)co0 * DHW;
+    // buffer loads: the descriptor spans the channel planes of this block that exist in sample b, so an offset beyond them — a
+    // ragged octet, or the 2^31 handed to out-of-volume and idle lanes — reads 0 in hardware: no address clamps, no selects
+    const icl_rsrc_t xr = icl_make_rsrc(x + (long)b * g.x_bstride + (long)c0 * DHW, (unsigned)((long)(g.Cin - c0) * DHW * 4));
+    const icl_rsrc_t gr = icl_make_rsrc(gy + (long)b * g.gy_bstride + (long)co0 * DHW, (unsigned)((long)(g.Cout - co0) * DHW * 4));
     const int org = (z0 - 1) * (int)HW + (y0 - 1) * g.W + x0 - 1;
 #pragma unroll
     for (int r = 0; r < C::ROUNDS; ++r) {
       const int gz = z0 - 1 + (s_zyx[r] >> 16), gyy = y0 - 1 + ((s_zyx[r] >> 8) & 255), gx = x0 - 1 + (s_zyx[r] & 255);
       const bool ok = (s_zyx[r] >= 0) & ((unsigned)gz < (unsigned)g.D) & ((unsigned)gyy < (unsigned)g.H) & ((unsigned)gx < (unsigned)g.W);
-      // 32-bit lane offset against a wave-uniform block base (launcher: 32 planes < 2^31 elements).  Lanes of an octet without a
-      // single existing channel (ragged Cin / Cout) and out-of-volume positions read offset 0 of the block.
-      const bool ok0 = ok & (s_nch[r] > 0);
-      const float* base = s_isx[r] ? xb : gb;
-      // unconditional loads from always-valid addresses, then a select: the lane offset walks the channel planes of its octet that
-      // exist and stays on the last one, so the code is straight-line and never reads outside the tensor
-      int idx = ok0 ? org + s_rel[r] : 0;
+      unsigned off = ok ? (unsigned)(org + s_rel[r]) * 4u : 0x80000000u;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const float v = base[idx];
-        raw[r][c] = (ok0 & (c < s_nch[r])) ? v : 0.f;
-        idx += (ok0 & (c + 1 < s_nch[r])) ? (int)DHW : 0;
+        raw[slot][r][c] = icl_buffer_load_f32(s_isx[r] ? xr : gr, off);
+        off += (unsigned)DHW * 4u;
       }
     }
   };
-  auto store_tile = [&](uint4* buf) {
+  auto store_tile = [&](uint4* buf, auto SLOT) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOT)::value;
     if (g.dbg & 2) return;
 #pragma unroll
     for (int r = 0; r < C::ROUNDS; ++r) {
       if (s_zyx[r] < 0) continue;
       uint4 o1, o2, o3;
-      bf3_split8(raw[r], o1, o2, o3);
+      bf3_split8(raw[slot][r], o1, o2, o3);
       uint4* d = buf + s_dst[r];
       const int pitch = s_isx[r] ? C::NPOSP : C::TPOSP;
       d[0] = o1;
@@ -144,12 +142,12 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
 #pragma unroll
     for (int t = 0; t < C::NTAPH; ++t) acc[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto frag = [&](const unsigned char* p) {      // two transposing reads: k = 0..3 and 4..7 of the lane group (64 bytes apart)
+  auto frag = [&](const unsigned char* p) __attribute__((always_inline)) {      // two transposing reads: k = 0..3 and 4..7 of the lane group (64 bytes apart)
     const uint2 lo = icl_lds_read_tr16_b64(p), hi = icl_lds_read_tr16_b64(p + 64);
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
   };
   // TH = the wave's tap half as a compile-time constant (the two halves are two code paths: every tap offset is an immediate)
-  auto multiply = [&](const uint4* buf, auto TH) {
+  auto multiply = [&](const uint4* buf, auto TH) __attribute__((always_inline)) {
     if (g.dbg & 4) return;
     constexpr int tap0 = C::NTAPH * decltype(TH)::value, ntap = decltype(TH)::value ? 27 - C::NTAPH : C::NTAPH;
     const unsigned char* base = reinterpret_cast<const unsigned char*>(buf);
@@ -159,7 +157,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
 #pragma unroll
       for (int s = 0; s < 3; ++s) a[cb][s] = frag(base + a_off + (cb * 6 + s) * C::TPOSP * 16);
     uint4 b[2][3];
-    auto read_b = [&](int buf_i, int t) {
+    auto read_b = [&](int buf_i, int t) __attribute__((always_inline)) {
       const int tap = tap0 + t;
       const unsigned char* p = base + b_off + (((tap / 9) * C::PY + (tap / 3) % 3) * C::PX + tap % 3) * 16;
 #pragma unroll
@@ -182,31 +180,42 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
 
   const int t_begin = blockIdx.x * g.tiles_per_wg;
   const int t_end = t_begin + g.tiles_per_wg < g.ntiles ? t_begin + g.tiles_per_wg : g.ntiles;
-  // prologue: tile 0 into buffer 0, the loads of tile 1 in flight
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  // prologue: tile 0 into buffer 0; the loads of tiles 1 and 2 in flight
   if (t_begin < t_end) {
-    load_tile(t_begin);
-    store_tile(lds);
-    if (t_begin + 1 < t_end) load_tile(t_begin + 1);
+    load_tile(t_begin, I0());
+    store_tile(lds, I0());
+    if (t_begin + 1 < t_end) load_tile(t_begin + 1, I1());
+    if (t_begin + 2 < t_end) load_tile(t_begin + 2, I0());
   }
   __syncthreads();
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    uint4* cur = lds + ((tile - t_begin) & 1) * C::BUF_U4;
-    uint4* nxt = lds + (((tile - t_begin) & 1) ^ 1) * C::BUF_U4;
-    const bool more = tile + 1 < t_end;                  // raw[] holds tile + 1
+  // one phase: multiply tile `tile` (relative parity PAR: buffer PAR), split + store tile + 1 (raw slot PAR ^ 1) into the other
+  // buffer, issue the loads of tile + 3 into the slot that the store has just freed
+  auto phase = [&](int tile, auto PAR) __attribute__((always_inline)) {
+    constexpr int par = decltype(PAR)::value;
+    typedef std::integral_constant<int, par ^ 1> OTHER;
+    uint4* cur = lds + par * C::BUF_U4;
+    uint4* nxt = lds + (par ^ 1) * C::BUF_U4;
+    const bool more = tile + 1 < t_end;
     if (th == 0) {
       if (more) {
-        store_tile(nxt);
-        if (tile + 2 < t_end) load_tile(tile + 2);
+        store_tile(nxt, OTHER());
+        if (tile + 3 < t_end) load_tile(tile + 3, OTHER());
       }
-      multiply(cur, std::integral_constant<int, 0>());
+      multiply(cur, I0());
     } else {
-      multiply(cur, std::integral_constant<int, 1>());
+      multiply(cur, I1());
       if (more) {
-        store_tile(nxt);
-        if (tile + 2 < t_end) load_tile(tile + 2);
+        store_tile(nxt, OTHER());
+        if (tile + 3 < t_end) load_tile(tile + 3, OTHER());
       }
     }
     __syncthreads();                                      // nxt is complete, cur has been read by everyone
+  };
+  for (int tile = t_begin; tile < t_end; tile += 2) {
+    phase(tile, I0());
+    if (tile + 1 < t_end) phase(tile + 1, I1());
   }
 
   // ---- sum over the four k-groups (per tap half) through LDS: kg 2, 3 -> kg 0, 1; then kg 1 -> kg 0

@@ -267,6 +267,14 @@ static inline uint2 icl_lds_read_tr16_b64(const void* lds_ptr) {
   hipemu::wave_done();
   return make_uint2((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16));
 }
+struct icl_rsrc_t { const unsigned char* p; unsigned bytes; };
+static inline icl_rsrc_t icl_make_rsrc(const void* p, unsigned bytes) { return icl_rsrc_t{(const unsigned char*)p, bytes}; }
+static inline float icl_buffer_load_f32(icl_rsrc_t r, unsigned byte_off) {
+  if ((uint64_t)byte_off + 4 > r.bytes) return 0.f;
+  float f;
+  memcpy(&f, r.p + byte_off, 4);
+  return f;
+}
 static inline float icl_fast_exp(float x) { return expf(x); }
 static inline float4 icl_nt_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static inline void icl_nt_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
