@@ -109,13 +109,14 @@ __global__ __launch_bounds__(256) void conv_bf16x3_split_weights_kernel(const fl
 //        are handed offset 2^31 and the hardware returns 0): no branches, no address clamps, no selects.
 // V & 8: (one cout block) all three weight planes of the channel chunk stay in LDS (43 KB beside the 104 KB halo tile) instead of
 //        one plane per dz stage: two barriers per work item instead of six, and a single-chunk layer (16 -> 16) loads its weights
-//        once per workgroup instead of once per tile.
+//        once per workgroup instead of once per tile.  DEFAULT (round 3, batch 2: 16->16 @96^3 137 vs 152 us, 48->16 406 vs 423).
+//        V & 4 measured neutral on top of it (139 / 419) and alone (152 / 430).
 // V & 2: each staging round is split into its three packed bf16 planes INSIDE the multiply phase (one round per tap pair of the
 //        dz = 1 / 2 stages, pinned there), so that the store phase is 15 ds_write_b128 per thread and nothing else.  MEASURED
 //        SLOWER (round 3, batch 2: 16->16 @96^3 171 vs 161 us, 48->16 473 vs 438, 32->32 @48^3 71.8 vs 67.8): the two waves of a
 //        SIMD run the multiply phase together, the matrix pipe is already saturated there, and the extra VALU lengthens each
 //        wave's in-order stream instead of hiding in the other wave's MFMAs.  Kept as a measurement variant, not the default.
-template <int NBT, int TY, int V = 0>
+template <int NBT, int TY, int V = 8>
 __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {
   typedef Bf3T<TY> TC;

@@ -98,7 +98,13 @@ def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root):
         ("final.weight", full, 1e-3), ("final.bias", full, 1e-3), ("conv1.conv1.0.weight", full, 2e-2), ("sspa.guided_Q", full, 5e-3),
         ("sspa.class_decoders.0.attn.fc_q.weight", full, 5e-3), ("uscl.attn_convs1.2.weight", full, 5e-3),
         ("sspa.attn_convs0.2.block.depthwise.weight", full, 5e-3), ("sspa.query_convs.0.weight", full, 5e-3),
-        ("sspa.class_decoders.2.mlp2.fc1.weight", lambda t: t[::432, ::432], 5e-3),      # dense 13,824^2 gradient of stock SGD
+        # dense 13,824^2 gradient of stock SGD, 1,024 sampled elements of size 1e-6.  Measured (tests/diag/mlp2_grad_sensitivity.py,
+        # round 3): exact-fp32 convolutions 1.2e-3 from the golden; the same kernels with the input volume scaled by (1 + 1e-7)
+        # move the sample by 1.5e-3 (rounding-sized perturbations flip ReLU / max-pool decisions); the split-product
+        # convolutions 1.6e-2 — their products are closer to exact than an fp32 multiply, but v_mfma_f32_16x16x32_bf16 does not round
+        # its 32-product sums to nearest (-0.36 * 2^-24 coherent offset, test_split_bf16_convolution_all_positive_sums_carry_no_bias),
+        # and this cancellation-heavy gradient sees it.  Losses, maps, gradient norms and the other tensors are unchanged.
+        ("sspa.class_decoders.2.mlp2.fc1.weight", lambda t: t[::432, ::432], 3e-2),
         ("center.conv2.0.weight", lambda t: t[::16, ::16], 2e-2),
     ]
     # conv biases in front of an InstanceNorm and attn_convs1 biases in front of the class softmax: the true gradient is exactly 0

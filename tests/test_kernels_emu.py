@@ -71,11 +71,12 @@ def test_conv3d_wgrad_row_window_kernel(monkeypatch, mode, n, cin, cout, d, h, w
     (1, 20, 32, 3, 9, 24),      # weight gradient with two cout blocks per workgroup (2 x 8 x 16 tiles): ragged cin block, partial tiles
     (2, 16, 60, 2, 8, 16),      # ... two such workgroup columns, the last cout block ragged (60 -> 64), two samples
 ])
-@pytest.mark.parametrize("variant", ["1", "0"])
+@pytest.mark.parametrize("variant", ["8", "0", "4"])
 def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w, variant):
     """conv_bf16x3.h: forward and input gradient with each fp32 operand split exactly into three bf16 terms (six bf16 MFMA terms per
     product, fp32 accumulation) — same tolerance as the fp32-MFMA kernels, and the two paths agree to fp32 rounding.  variant: the
-    schedule of the forward kernel (1 = split planes produced inside the multiply phase, the default; 0 = in the store phase)."""
+    schedule of the forward kernel (8 = all weight planes of a chunk in LDS for one cout block, the default; 0 = one plane per dz
+    stage; 4 = buffer loads); the weight gradient runs on conv_wgrad_tr.h (transposing LDS reads)."""
     monkeypatch.setenv("ICL_CONV_SPLIT_V", variant)
     monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
     monkeypatch.setenv("ICL_CONV_SPLIT", "1")
