@@ -172,6 +172,10 @@ def main():
                     help="one rank: auto = after capture, time 3 replayed and 3 eager steps and run the timed region in the faster mode "
                          "(with the aligner heads on their own stream an eager step beats the replay when the host keeps up); "
                          "graph = always replay.  N > 1 always replays.")
+    ap.add_argument("--feed", action="store_true",
+                    help="after the headline region, time the same K steps with every batch built on the device by the data feed "
+                         "(TwoStreamBatchSampler indices -> OnDeviceAugment.batch: rot/flip/crop of 240x240x155 volumes resident in "
+                         "HBM) and the feed alone; reported as `feed` (the headline `value` keeps its HBM-resident input)")
     ap.add_argument("--force-ddp", action="store_true", help="with --gpus 1: run the data-parallel step on a one-rank RCCL group")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="exercise ONLY the multi-rank plumbing (self-launch, rendezvous, barrier-bracketed timing, MAX over ranks, "
@@ -281,6 +285,51 @@ def main():
         dt = float(t.item())
     volumes = 2 * world * args.steps
     value = volumes / dt
+
+    feed = None
+    if args.feed and rank == 0:
+        # the loader of the reference trainers (dataloaders/brats2019.py: h5 volume -> RandomRotFlip -> RandomCrop(96^3) -> ToTensor ->
+        # collate, four worker processes) as the build runs it: volumes resident in HBM, one fused gather kernel per batch, the
+        # random draws on the host in the reference's numpy order.  Synthetic volumes at the real BraTS2019 extent.
+        import numpy as np
+        from icl_amd.dataloaders.brats2019 import DeviceVolumeStore, OnDeviceAugment, TwoStreamBatchSampler
+        nvol, shape = 8, (240, 240, 155)
+        store = DeviceVolumeStore([(synthetic_volume(shape, 500 + i).numpy(), synthetic_labels(shape, 600 + i, nc).numpy().astype(np.uint8))
+                                   for i in range(nvol)], dev)
+        aug = OnDeviceAugment(store, (96, 96, 96))
+        np.random.seed(1337)
+        sampler = TwoStreamBatchSampler(list(range(2)), list(range(2, nvol)), 2, 1)
+
+        def batches():
+            while True:
+                for idx in sampler:
+                    yield list(idx)
+        it = batches()
+        for _ in range(3):
+            b = aug.batch(next(it))
+        torch.cuda.synchronize()
+        n_feed = 200
+        t1 = time.perf_counter()
+        for _ in range(n_feed):
+            b = aug.batch(next(it))
+        torch.cuda.synchronize()
+        feed_alone = (time.perf_counter() - t1) / n_feed
+        for _ in range(2):
+            b = aug.batch(next(it))
+            trainer.step(b["image"], b["label"][:1])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            b = aug.batch(next(it))
+            trainer.step(b["image"], b["label"][:1])
+        torch.cuda.synchronize()
+        dt_feed = (time.perf_counter() - t1) / args.steps
+        feed = {"batches_per_s_feed_alone": round(1.0 / feed_alone, 1), "ms_per_batch_feed_alone": round(feed_alone * 1e3, 4),
+                "ms_per_step_with_feed": round(dt_feed * 1e3, 3), "ms_per_step_resident_input": round(dt / args.steps * 1e3, 3),
+                "volumes_per_s_with_feed": round(2.0 / dt_feed, 3),
+                "source": f"{nvol} synthetic volumes {shape[0]}x{shape[1]}x{shape[2]} fp32 + uint8 labels resident in HBM, "
+                          "TwoStreamBatchSampler(2 labeled, 6 unlabeled, batch 2) -> OnDeviceAugment.batch (crop_rotflip_kernel)"}
+        del store, aug
 
     exact = None
     if rank == 0 and world == 1 and not args.no_exact_compare and os.environ.get("ICL_CONV_SPLIT", "1") != "0":
@@ -406,7 +455,8 @@ def main():
                        # (tests/test_gpu_parity.py::test_split_bf16_convolution_is_as_accurate_as_the_fp32_mfma_path)
                        "conv_products": ("exact 3-way bf16 splits of fp32 operands, 6 MFMA terms, fp32 accumulate (ICL_CONV_SPLIT=1)"
                                          if os.environ.get("ICL_CONV_SPLIT", "1") != "0" else "v_mfma_f32_16x16x4_f32"),
-                       **({"exact_fp32_mfma_convolutions": exact} if exact else {})},
+                       **({"exact_fp32_mfma_convolutions": exact} if exact else {}),
+                       **({"feed": feed} if feed else {})},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

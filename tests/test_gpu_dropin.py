@@ -135,6 +135,50 @@ def test_reference_loop_body_swinunetr_icl_through_compat_root(compat_root):
     _check_step(model, g, got, grads, elementwise, skip)
 
 
+def test_amos_validation_with_the_hip_model(compat_root):
+    """`val_3D.test_all_case_amos` (/root/reference/code/val_3D.py:120-137) with a HIP `unet_3D_icl` of the AMOS class count on a
+    volume that needs a 2 x 2 x 2 window grid with shifted-back last windows: the batched on-device sliding window (four windows per
+    forward, constant-weight averaging of the LOGITS, arg-max, `cal_metric` per class) equals a window-by-window evaluation written
+    out here (one forward per window, float64 accumulation on the host), and one window's logits equal the CPU oracle's."""
+    from networks.net_factory_3d import net_factory_3d
+    from oracle import icl_oracle as O
+    from val_3D import _scan_starts, cal_metric, test_all_case_amos
+    nc = 16
+    model = net_factory_3d(net_type="unet_3D_icl", in_chns=1, class_num=nc)
+    fill_like_reference_init(list(model.named_parameters()))
+    dev = next(model.parameters()).device
+    shape = (112, 100, 104)
+    vol = synthetic_volume((1, 1) + shape, 77)
+    lab = synthetic_labels((1, 1) + shape, 78, nc)
+    metrics = test_all_case_amos(model, "unet_3D_icl", [{"image": vol, "label": lab}], num_classes=nc)
+    assert not model.training and len(metrics) == nc - 1 and all(len(m) == 1 for m in metrics)
+    # the same evaluation, one window at a time
+    grids = [_scan_starts(s, 96, 0.25) for s in shape]
+    assert grids == [[0, 16], [0, 4], [0, 8]]
+    acc = np.zeros((nc,) + shape, np.float64)
+    cnt = np.zeros(shape, np.float64)
+    first = None
+    with torch.no_grad():
+        for z in grids[0]:
+            for y in grids[1]:
+                for x in grids[2]:
+                    win = vol[:, :, z:z + 96, y:y + 96, x:x + 96].contiguous()
+                    out = model(win.to(dev), inference=True)[0].double().cpu().numpy()
+                    first = (win, out) if first is None else first
+                    acc[:, z:z + 96, y:y + 96, x:x + 96] += out
+                    cnt[z:z + 96, y:y + 96, x:x + 96] += 1
+    pred = np.argmax(acc / cnt, axis=0)
+    want = [cal_metric(lab[0, 0].numpy() == i, pred == i) for i in range(1, nc)]
+    assert [m[0] for m in metrics] == want
+    # parity of the window forward itself with the CPU oracle (1e-3 on logits, BASELINE.json)
+    p = O.make_params(O.unet_3d_icl_shapes(nc))
+    p.update(O.aligner_buffers("sspa.", O.UNET3D_HEADS))
+    p.update(O.aligner_buffers("uscl.", O.UNET3D_HEADS))
+    with torch.no_grad():
+        ref = O.unet_3d_icl_forward(p, first[0], inference=True)
+    assert rel_err(first[1][None], ref.numpy()) < 1e-3
+
+
 def test_dice_loss_on_probabilities_equals_dice_loss_on_logits():
     """`DiceLoss(nc)(softmax(logits), y.unsqueeze(1))` (the trainer's call, :105-108) and `DiceLoss(nc)(logits, ..., softmax=True)`
     (AuxLoss3D's call, losses.py:269) are the same number, and so are their gradients with respect to the logits."""
@@ -152,5 +196,7 @@ def test_dice_loss_on_probabilities_equals_dice_loss_on_logits():
 
 def test_on_device_data_feed_equals_the_reference_transforms():
     sys.path.insert(0, HERE)
-    from test_datafeed import check_augment_cases
+    from test_datafeed import check_augment_cases, check_big_cases, device_big_batch
     check_augment_cases(torch.device("cuda", 0))
+    # the real BraTS2019 extent: 240 x 240 x 155 volumes resident in HBM -> 96^3 patches, bit-exact (CRC) against the reference
+    check_big_cases(device_big_batch(torch.device("cuda", 0)))

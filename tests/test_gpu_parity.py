@@ -599,23 +599,33 @@ def _check_three_steps(model, g, losses, tag):
     """Three reference iterations (tests/golden/make_golden.py::gen_model_steps): losses of every step, parameter norms after every
     step, the small tensors and a subsample of a 13,824^2 matrix after step 3 (as the CHANGE against the initial weights, which is
     what the optimiser produced: the weights themselves move by 1e-4 of their size)."""
-    assert np.allclose(np.array(losses), g["losses"], rtol=0, atol=2e-4), (tag, losses, g["losses"])
+    # Tolerances from a measurement, not from taste (tests/diag/three_steps.py, round 3): the exact-fp32 kernels with every input
+    # volume scaled by (1 + 1e-7) leave their own unperturbed run by 5e-7 / 1e-4 / 1.4e-3 in the total loss of steps 1 / 2 / 3 and
+    # by 2e-4 (aux), 1e-4 (consistency) in the terms of step 3: rounding-sized noise in the gradients of steps 1-2 is amplified by
+    # the updates (lr 0.01, consistency weight 10).  The distance to the golden is of exactly that size for both convolution paths
+    # (step 3: aux 1-2e-4, consistency 1.7-1.9e-4, total 1.9-2.1e-3); the CPU oracle reproduces the golden to 2e-5 because it
+    # runs the reference's own torch-CPU kernels in the same order.  Bands: 5x the measured noise.
+    losses, ref_l = np.array(losses), g["losses"]
+    for s_, (term_tol, total_tol) in enumerate(((2e-5, 2e-5), (2e-4, 6e-4), (1e-3, 1e-2))):
+        assert np.allclose(losses[s_, :5], ref_l[s_, :5], rtol=0, atol=term_tol), (tag, s_, losses[s_], ref_l[s_])
+        assert abs(losses[s_, 5] - ref_l[s_, 5]) < total_tol, (tag, s_, losses[s_], ref_l[s_])
     named = dict(model.named_parameters())
     assert list(named) == list(g["param_keys"])
     post = np.array([float(p.detach().double().norm()) for p in named.values()])
     ref = g["post_step3_norms"]
-    off = [(k, post[i], ref[i]) for i, k in enumerate(named) if abs(post[i] - ref[i]) > 1e-4 * ref[i]]
+    off = [(k, post[i], ref[i]) for i, k in enumerate(named) if abs(post[i] - ref[i]) > 5e-4 * ref[i]]      # measured: 1.3e-4 at most
     assert not off, (tag, off[:8])
     for k in ("final.weight", "final.bias", "conv1.conv1.0.weight", "sspa.class_decoders.0.attn.fc_q.weight", "uscl.attn_convs1.2.weight"):
-        assert rel_err(named[k].detach().cpu(), g["post_step3." + k]) < 1e-4, (tag, k)
+        assert rel_err(named[k].detach().cpu(), g["post_step3." + k]) < 5e-4, (tag, k)
     big = "sspa.class_decoders.2.mlp2.fc1.weight"
     w0 = torch.empty_like(named[big])
     fill_like_reference_init([(big, w0)])
     delta = (named[big].detach()[::432, ::432].double() - w0[::432, ::432].double()).cpu().numpy()
-    # three SGD steps with momentum: 2e-2 relative on the accumulated update of a sampled row block (the per-step gradients
-    # themselves agree to 1e-3: test_trainer_step_with_factored_mlp2_gradients_matches_reference_golden; the change of a weight
-    # is the difference of two fp32 numbers 1e4 times larger, so the golden itself resolves it to ~1e-3 of its size)
-    assert rel_err(delta, g["delta_step3." + big + "_sub"]) < 2e-2, tag
+    # three SGD steps with momentum: the accumulated update of a sampled row block (1,024 elements of a cancellation-heavy
+    # gradient whose step-1 sample is reproducible to 1.5e-3 under rounding-sized input noise)
+    # (measured 2.4e-2 with the exact-fp32 convolutions, 2.1-2.6e-2 with the split products, and the same 2.4e-2 under the
+    # (1 + 1e-7) input perturbation: tests/diag/three_steps.py)
+    assert rel_err(delta, g["delta_step3." + big + "_sub"]) < 6e-2, tag
 
 
 def test_three_trainer_steps_match_reference_golden(dev):
@@ -657,7 +667,7 @@ def test_three_trainer_steps_match_reference_golden(dev):
         mom = tr.optimizer.state[model.final.weight]["momentum_buffer"]
         assert rel_err(mom.cpu(), g["momentum.final.weight"]) < 1e-3, mode
         big = dict(model.named_parameters())["sspa.class_decoders.2.mlp2.fc1.weight"]
-        assert rel_err(tr.optimizer.state[big]["momentum_buffer"][::432, ::432].cpu(), g["momentum.sspa.class_decoders.2.mlp2.fc1.weight_sub"]) < 2e-2
+        assert rel_err(tr.optimizer.state[big]["momentum_buffer"][::432, ::432].cpu(), g["momentum.sspa.class_decoders.2.mlp2.fc1.weight_sub"]) < 6e-2
         del tr, model
         torch.cuda.empty_cache()
 
