@@ -44,9 +44,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md dense bf16 matrix peak
 # csrc/kernels/conv_bf16x3.h multiplies fp32 operands as exact three-way bf16 splits: SIX bf16 MFMA terms per fp32 product.  Its
 # speed of light in ALGORITHMIC (fp32) FLOP/s is therefore the bf16 peak / 6.
 SPLIT_TERMS = 6
-# matrix-pipe busy fraction of the kernel's cycles, PMC (profiles/r2_pmc_conv.md), static
-PIPE_BUSY = {"conv3d_mfma_fwd_static_kernel": 0.81, "conv3d_bf16x3_fwd_kernel<1, 8>": 0.46, "conv3d_bf16x3_fwd_kernel<2, 8>": 0.52,
-             "conv3d_bf16x3_fwd_kernel<3, 8>": 0.62}
+# matrix-pipe busy fraction of the kernel's cycles, PMC (profiles/r3_pmc_conv.md; <2, 8> / <3, 8>: profiles/r2_pmc_conv.md), static
+PIPE_BUSY = {"conv3d_mfma_fwd_static_kernel": 0.81, "conv3d_bf16x3_fwd_kernel<1, 8, 8>": 0.50, "conv3d_bf16x3_fwd_kernel<2, 8, 8>": 0.52,
+             "conv3d_bf16x3_fwd_kernel<3, 8, 8>": 0.62, "conv3d_wgrad_tr_kernel<1, 0>": 0.44, "conv3d_wgrad_tr_kernel<2, 0>": 0.49}
 
 
 def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
@@ -87,7 +87,7 @@ def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
             "sample": f"{steps} full ICL step(s) of the same workload (2 volumes 96^3 each, nc={num_classes}) after a 32^3 conv warm-up: {t:.2f} s"}
 
 
-HBM_TRAFFIC_FILE = "profiles/r2_hbm_traffic.json"
+HBM_TRAFFIC_FILE = "profiles/r3_hbm_traffic.json"
 
 
 def hbm_traffic(kernel: str):
@@ -395,7 +395,7 @@ def main():
                     **({"launch_note": "a timed launch = conv_bf16x3_split_weights_kernel (2-5 us) + the convolution kernel; rocprofv3 "
                                        "lists them separately (profiles/r2_bench_kernel_stats.csv)"} if split else {}),
                     "traffic": traffic["hbm_bytes"] if traffic else None, "traffic_detail": traffic,
-                    # PMC (profiles/r2_pmc_conv.md, static): fraction of the kernel's cycles with the matrix pipe busy; the rest of
+                    # PMC (profiles/r3_pmc_conv.md, static): fraction of the kernel's cycles with the matrix pipe busy; the rest of
                     # the gap to the 2.4 GHz peak is the clock the chip holds under matrix load (1.8-2.1 GHz)
                     "matrix_pipe_busy_static_profile": busy,
                     "launches_per_step": n // 3, "avg_launch_us": round(ms * 1e3 / n, 2),

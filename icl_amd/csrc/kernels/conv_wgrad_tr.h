@@ -44,7 +44,10 @@ struct WgTrT {
   static_assert((size_t)2 * 2 * ACC * 4 * 64 * 4 <= LDS_BYTES, "the cross-wave sum (two writers per tap half) must fit in the tile buffers");
 };
 
-template <int NCB>
+// MERGE = 1: the split + store of tile i + 1 is spread over the tap loop of the multiply phase of tile i (one staging round every
+// four taps, the loads of tile i + 3 behind the last one) instead of running as a block in front of / behind it: a wave's phase is
+// then one merged instruction stream instead of the chain S + M.
+template <int NCB, int MERGE = 0>
 __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                               float* __restrict__ gwp, Bf3WGeom g) {
   typedef WgTrT<NCB> C;
@@ -71,14 +74,14 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
       const int px = pos % C::PX, row = pos / C::PX, py = row % C::PY, pz = row / C::PY;
       const bool live = it < C::XITEMS;
       s_zyx[r] = live ? (pz << 16) | (py << 8) | px : -1;
-      s_dst[r] = o * 3 * C::NPOSP + pos;
+      s_dst[r] = live ? o * 3 * C::NPOSP + pos : C::NPOS;                  // idle lanes: a pad slot (never read)
       s_rel[r] = o * 8 * (int)DHW + pz * (int)HW + py * g.W + px;          // + tile origin - (1, 1, 1)
     } else {
       const int ig = it - C::XPAD, ob = ig / C::TPOS, pos = ig % C::TPOS;
       const int tx = pos % C::TX, ty = (pos / C::TX) % C::TY, tz = pos / (C::TX * C::TY);
       const bool live = ig < 2 * NCB * C::TPOS;
       s_zyx[r] = live ? ((tz + 1) << 16) | ((ty + 1) << 8) | (tx + 1) : -1;  // same origin convention as the halo items
-      s_dst[r] = C::XS_U4 + ob * 3 * C::TPOSP + pos;
+      s_dst[r] = live ? C::XS_U4 + ob * 3 * C::TPOSP + pos : C::XS_U4 + C::TPOS;
       s_rel[r] = ob * 8 * (int)DHW + (tz + 1) * (int)HW + (ty + 1) * g.W + tx + 1;
     }
   }
@@ -113,20 +116,22 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
       }
     }
   };
-  auto store_tile = [&](uint4* buf, auto SLOT) __attribute__((always_inline)) {
+  // one staging round: split the eight channel values of the lane's item into three packed planes, three 16-byte stores (idle
+  // lanes store into a pad slot: no control flow)
+  auto store_round = [&](uint4* buf, auto SLOT, int r) __attribute__((always_inline)) {
     constexpr int slot = decltype(SLOT)::value;
+    uint4 o1, o2, o3;
+    bf3_split8(raw[slot][r], o1, o2, o3);
+    uint4* d = buf + s_dst[r];
+    const int pitch = s_isx[r] ? C::NPOSP : C::TPOSP;
+    d[0] = o1;
+    d[pitch] = o2;
+    d[2 * pitch] = o3;
+  };
+  auto store_tile = [&](uint4* buf, auto SLOT) __attribute__((always_inline)) {
     if (g.dbg & 2) return;
 #pragma unroll
-    for (int r = 0; r < C::ROUNDS; ++r) {
-      if (s_zyx[r] < 0) continue;
-      uint4 o1, o2, o3;
-      bf3_split8(raw[slot][r], o1, o2, o3);
-      uint4* d = buf + s_dst[r];
-      const int pitch = s_isx[r] ? C::NPOSP : C::TPOSP;
-      d[0] = o1;
-      d[pitch] = o2;
-      d[2 * pitch] = o3;
-    }
+    for (int r = 0; r < C::ROUNDS; ++r) store_round(buf, SLOT, r);
   };
 
   // ---- operand addressing (bytes from the buffer base).  Lane 4q + p of a 16-lane group addresses position q of the group's four,
@@ -147,7 +152,8 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
   };
   // TH = the wave's tap half as a compile-time constant (the two halves are two code paths: every tap offset is an immediate)
-  auto multiply = [&](const uint4* buf, auto TH) __attribute__((always_inline)) {
+  // (MERGE: nxt / SLOT / next_load = where the staging rounds of the next tile go, and the tile whose loads to issue afterwards)
+  auto multiply = [&](const uint4* buf, auto TH, uint4* nxt, auto SLOT, int next_load) __attribute__((always_inline)) {
     if (g.dbg & 4) return;
     constexpr int tap0 = C::NTAPH * decltype(TH)::value, ntap = decltype(TH)::value ? 27 - C::NTAPH : C::NTAPH;
     const unsigned char* base = reinterpret_cast<const unsigned char*>(buf);
@@ -175,6 +181,13 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) acc[cb][t] = icl_mfma_16x16x32_bf16(a[cb][sa[k]], b[cur][sb[k]], acc[cb][t]);
       }
+      if (MERGE) {
+        // staging round r of the next tile behind tap 1 + 4 r; the loads two tiles further behind the last round (the index is
+        // clamped by the caller, so the tail reloads a tile instead of branching)
+        static_assert(!MERGE || 1 + 4 * (C::ROUNDS - 1) + 1 < 27 - C::NTAPH, "staging rounds must fit in the shorter tap half");
+        if (t >= 1 && (t - 1) % 4 == 0 && (t - 1) / 4 < C::ROUNDS) store_round(nxt, SLOT, (t - 1) / 4);
+        if (t == 1 + 4 * (C::ROUNDS - 1) + 1) load_tile(next_load, SLOT);
+      }
     }
   };
 
@@ -198,14 +211,18 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
     uint4* cur = lds + par * C::BUF_U4;
     uint4* nxt = lds + (par ^ 1) * C::BUF_U4;
     const bool more = tile + 1 < t_end;
-    if (th == 0) {
+    if (MERGE) {
+      const int nl = tile + 3 < t_end ? tile + 3 : t_end - 1;
+      if (th == 0) multiply(cur, I0(), nxt, OTHER(), nl);
+      else multiply(cur, I1(), nxt, OTHER(), nl);
+    } else if (th == 0) {
       if (more) {
         store_tile(nxt, OTHER());
         if (tile + 3 < t_end) load_tile(tile + 3, OTHER());
       }
-      multiply(cur, I0());
+      multiply(cur, I0(), nxt, OTHER(), 0);
     } else {
-      multiply(cur, I1());
+      multiply(cur, I1(), nxt, OTHER(), 0);
       if (more) {
         store_tile(nxt, OTHER());
         if (tile + 3 < t_end) load_tile(tile + 3, OTHER());

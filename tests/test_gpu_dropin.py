@@ -142,7 +142,8 @@ def test_amos_validation_with_the_hip_model(compat_root):
     out here (one forward per window, float64 accumulation on the host), and one window's logits equal the CPU oracle's."""
     from networks.net_factory_3d import net_factory_3d
     from oracle import icl_oracle as O
-    from val_3D import _scan_starts, cal_metric, test_all_case_amos
+    from val_3D import cal_metric, test_all_case_amos          # the names the reference trainers import
+    from icl_amd.val_3D import _scan_starts
     nc = 16
     model = net_factory_3d(net_type="unet_3D_icl", in_chns=1, class_num=nc)
     fill_like_reference_init(list(model.named_parameters()))
