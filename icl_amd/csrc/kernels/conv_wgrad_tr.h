@@ -44,10 +44,11 @@ struct WgTrT {
   static_assert((size_t)2 * 2 * ACC * 4 * 64 * 4 <= LDS_BYTES, "the cross-wave sum (two writers per tap half) must fit in the tile buffers");
 };
 
-// MERGE = 1: the split + store of tile i + 1 is spread over the tap loop of the multiply phase of tile i (one staging round every
-// four taps, the loads of tile i + 3 behind the last one) instead of running as a block in front of / behind it: a wave's phase is
-// then one merged instruction stream instead of the chain S + M.
-template <int NCB, int MERGE = 0>
+// Measured and dropped (round 3): the split + store of tile i + 1 spread over the tap loop of the multiply phase (one staging round
+// every four taps — a wave's phase as ONE merged instruction stream instead of the chain S, M): 5-14 % slower on the one-cout-block
+// layers (16->16 @96^3 181 vs 167 us, 48->16 546 vs 479), 1-4 % slower with two cout blocks — as for the forward kernel, VALU that
+// the compiler interleaves with a wave's own MFMAs costs more than the same VALU run as a block beside the partner wave's MFMAs.
+template <int NCB>
 __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                               float* __restrict__ gwp, Bf3WGeom g) {
   typedef WgTrT<NCB> C;
@@ -152,8 +153,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
   };
   // TH = the wave's tap half as a compile-time constant (the two halves are two code paths: every tap offset is an immediate)
-  // (MERGE: nxt / SLOT / next_load = where the staging rounds of the next tile go, and the tile whose loads to issue afterwards)
-  auto multiply = [&](const uint4* buf, auto TH, uint4* nxt, auto SLOT, int next_load) __attribute__((always_inline)) {
+  auto multiply = [&](const uint4* buf, auto TH) __attribute__((always_inline)) {
     if (g.dbg & 4) return;
     constexpr int tap0 = C::NTAPH * decltype(TH)::value, ntap = decltype(TH)::value ? 27 - C::NTAPH : C::NTAPH;
     const unsigned char* base = reinterpret_cast<const unsigned char*>(buf);
@@ -181,13 +181,6 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) acc[cb][t] = icl_mfma_16x16x32_bf16(a[cb][sa[k]], b[cur][sb[k]], acc[cb][t]);
       }
-      if (MERGE) {
-        // staging round r of the next tile behind tap 1 + 4 r; the loads two tiles further behind the last round (the index is
-        // clamped by the caller, so the tail reloads a tile instead of branching)
-        static_assert(!MERGE || 1 + 4 * (C::ROUNDS - 1) + 1 < 27 - C::NTAPH, "staging rounds must fit in the shorter tap half");
-        if (t >= 1 && (t - 1) % 4 == 0 && (t - 1) / 4 < C::ROUNDS) store_round(nxt, SLOT, (t - 1) / 4);
-        if (t == 1 + 4 * (C::ROUNDS - 1) + 1) load_tile(next_load, SLOT);
-      }
     }
   };
 
@@ -211,18 +204,14 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
     uint4* cur = lds + par * C::BUF_U4;
     uint4* nxt = lds + (par ^ 1) * C::BUF_U4;
     const bool more = tile + 1 < t_end;
-    if (MERGE) {
-      const int nl = tile + 3 < t_end ? tile + 3 : t_end - 1;
-      if (th == 0) multiply(cur, I0(), nxt, OTHER(), nl);
-      else multiply(cur, I1(), nxt, OTHER(), nl);
-    } else if (th == 0) {
+    if (th == 0) {
       if (more) {
         store_tile(nxt, OTHER());
         if (tile + 3 < t_end) load_tile(tile + 3, OTHER());
       }
-      multiply(cur, I0(), nxt, OTHER(), 0);
+      multiply(cur, I0());
     } else {
-      multiply(cur, I1(), nxt, OTHER(), 0);
+      multiply(cur, I1());
       if (more) {
         store_tile(nxt, OTHER());
         if (tile + 3 < t_end) load_tile(tile + 3, OTHER());

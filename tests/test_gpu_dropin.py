@@ -170,7 +170,10 @@ def test_amos_validation_with_the_hip_model(compat_root):
                     cnt[z:z + 96, y:y + 96, x:x + 96] += 1
     pred = np.argmax(acc / cnt, axis=0)
     want = [cal_metric(lab[0, 0].numpy() == i, pred == i) for i in range(1, nc)]
-    assert [m[0] for m in metrics] == want
+    # the device path averages the logits in fp32, this loop in float64: of 1.16 M arg-max decisions over 16 random-weight classes a
+    # few near-ties fall the other way (measured: Dice equal to 4e-7)
+    for got, ref in zip((m[0] for m in metrics), want):
+        assert abs(got[0] - ref[0]) < 1e-4 and abs(got[1] - ref[1]) <= 1.0, (got, ref)
     # parity of the window forward itself with the CPU oracle (1e-3 on logits, BASELINE.json)
     p = O.make_params(O.unet_3d_icl_shapes(nc))
     p.update(O.aligner_buffers("sspa.", O.UNET3D_HEADS))
