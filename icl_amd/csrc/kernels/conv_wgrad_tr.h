@@ -39,9 +39,10 @@ struct WgTrT {
   // then 2 NCB TPOS tile positions x cout octets
   static constexpr int XITEMS = 2 * NPOS, XPAD = (XITEMS + 63) / 64 * 64, ITEMS = XPAD + 2 * NCB * TPOS;
   static constexpr int ROUNDS = (ITEMS + NT - 1) / NT;
+  static constexpr int PF = NCB_ < 3 ? 2 : 1;                              // tiles of loads in flight ahead of the split (registers)
   static constexpr int NTAPH = 14;                                        // taps per wave: half 0 owns 0..13, half 1 owns 14..26
   static constexpr int ACC = NTAPH * NCB;
-  static_assert((size_t)2 * 2 * ACC * 4 * 64 * 4 <= LDS_BYTES, "the cross-wave sum (two writers per tap half) must fit in the tile buffers");
+  static_assert((size_t)2 * 2 * NTAPH * 4 * 64 * 4 <= LDS_BYTES, "the cross-wave sum (two writers per tap half, one cout block) must fit in the tile buffers");
 };
 
 // Measured and dropped (round 3): the split + store of tile i + 1 spread over the tap loop of the multiply phase (one staging round
@@ -89,14 +90,16 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
   // the loads of a tile travel TWO phases ahead of the phase that splits them (a phase lasts 2-3 us, about one load latency under
   // load: one phase ahead left the latency half exposed — ablation: loads alone 126 us of a 206 us launch, 16->16 @96^3):
   // raw[j & 1] holds tile j; the tile loop is unrolled by two so that every index is a constant
-  float raw[2][C::ROUNDS][8] = {};
+  // (three cout blocks: 168 accumulator registers leave room for ONE tile of loads in flight, and the x fragments of a tap are not
+  // double-buffered)
+  float raw[C::PF][C::ROUNDS][8] = {};
   auto tile_origin = [&](int tile, int& b, int& x0, int& y0, int& z0) {
     b = tile / tiles_per;
     const int bt = tile % tiles_per;
     x0 = (bt % g.ntx) * C::TX; y0 = ((bt / g.ntx) % g.nty) * C::TY; z0 = (bt / (g.ntx * g.nty)) * C::TZ;
   };
   auto load_tile = [&](int tile, auto SLOT) __attribute__((always_inline)) {
-    constexpr int slot = decltype(SLOT)::value;
+    constexpr int slot = decltype(SLOT)::value % C::PF;
     if (g.dbg & 1) return;
     int b, x0, y0, z0;
     tile_origin(tile, b, x0, y0, z0);
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
   // one staging round: split the eight channel values of the lane's item into three packed planes, three 16-byte stores (idle
   // lanes store into a pad slot: no control flow)
   auto store_round = [&](uint4* buf, auto SLOT, int r) __attribute__((always_inline)) {
-    constexpr int slot = decltype(SLOT)::value;
+    constexpr int slot = decltype(SLOT)::value % C::PF;
     uint4 o1, o2, o3;
     bf3_split8(raw[slot][r], o1, o2, o3);
     uint4* d = buf + s_dst[r];
@@ -162,18 +165,20 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int s = 0; s < 3; ++s) a[cb][s] = frag(base + a_off + (cb * 6 + s) * C::TPOSP * 16);
-    uint4 b[2][3];
+    constexpr int NB = NCB < 3 ? 2 : 1;
+    uint4 b[NB][3];
     auto read_b = [&](int buf_i, int t) __attribute__((always_inline)) {
       const int tap = tap0 + t;
       const unsigned char* p = base + b_off + (((tap / 9) * C::PY + (tap / 3) % 3) * C::PX + tap % 3) * 16;
 #pragma unroll
       for (int s = 0; s < 3; ++s) b[buf_i][s] = frag(p + s * C::NPOSP * 16);
     };
-    read_b(0, 0);
+    if (NB == 2) read_b(0, 0);
 #pragma unroll
     for (int t = 0; t < ntap; ++t) {
-      const int cur = t & 1;
-      if (t + 1 < ntap) read_b(cur ^ 1, t + 1);          // next tap's fragments are in flight during this tap's MFMAs
+      const int cur = NB == 2 ? (t & 1) : 0;
+      if (NB == 1) read_b(0, t);
+      else if (t + 1 < ntap) read_b(cur ^ 1, t + 1);     // next tap's fragments are in flight during this tap's MFMAs
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         // (dY split, x split) of the six terms, smallest first
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
     load_tile(t_begin, I0());
     store_tile(lds, I0());
     if (t_begin + 1 < t_end) load_tile(t_begin + 1, I1());
-    if (t_begin + 2 < t_end) load_tile(t_begin + 2, I0());
+    if (C::PF == 2 && t_begin + 2 < t_end) load_tile(t_begin + 2, I0());
   }
   __syncthreads();
   // one phase: multiply tile `tile` (relative parity PAR: buffer PAR), split + store tile + 1 (raw slot PAR ^ 1) into the other
@@ -207,14 +212,14 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
     if (th == 0) {
       if (more) {
         store_tile(nxt, OTHER());
-        if (tile + 3 < t_end) load_tile(tile + 3, OTHER());
+        if (tile + 1 + C::PF < t_end) load_tile(tile + 1 + C::PF, OTHER());
       }
       multiply(cur, I0());
     } else {
       multiply(cur, I1());
       if (more) {
         store_tile(nxt, OTHER());
-        if (tile + 3 < t_end) load_tile(tile + 3, OTHER());
+        if (tile + 1 + C::PF < t_end) load_tile(tile + 1 + C::PF, OTHER());
       }
     }
     __syncthreads();                                      // nxt is complete, cur has been read by everyone
@@ -224,30 +229,29 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
     if (tile + 1 < t_end) phase(tile + 1, I1());
   }
 
-  // ---- sum over the four k-groups (per tap half) through LDS: kg 2, 3 -> kg 0, 1; then kg 1 -> kg 0
+  // ---- sum over the four k-groups (per tap half) through LDS, one cout block at a time: kg 2, 3 -> kg 0, 1; then kg 1 -> kg 0
   float* red = reinterpret_cast<float*>(lds);
 #pragma unroll
   for (int step = 2; step >= 1; step >>= 1) {
-    if (kg >= step && kg < 2 * step) {
-      float* d = red + (long)((kg - step) * 2 + th) * (C::ACC * 4 * 64) + lane;
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int t = 0; t < C::NTAPH; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) d[((cb * C::NTAPH + t) * 4 + r) * 64] = acc[cb][t][r];
-    }
-    __syncthreads();
-    if (kg < step) {
-      const float* d = red + (long)(kg * 2 + th) * (C::ACC * 4 * 64) + lane;
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
+    for (int cb = 0; cb < NCB; ++cb) {
+      if (kg >= step && kg < 2 * step) {
+        float* d = red + (long)((kg - step) * 2 + th) * (C::NTAPH * 4 * 64) + lane;
 #pragma unroll
         for (int t = 0; t < C::NTAPH; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[cb][t][r] += d[((cb * C::NTAPH + t) * 4 + r) * 64];
+          for (int r = 0; r < 4; ++r) d[(t * 4 + r) * 64] = acc[cb][t][r];
+      }
+      __syncthreads();
+      if (kg < step) {
+        const float* d = red + (long)(kg * 2 + th) * (C::NTAPH * 4 * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < C::NTAPH; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[cb][t][r] += d[(t * 4 + r) * 64];
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   // D[row = cout 4 lg + r][col = cin li]: one float4 of four couts per (tap, cin)
   if (kg == 0 && c0 + li < g.CinP) {
