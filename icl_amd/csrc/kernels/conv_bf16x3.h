@@ -116,6 +116,41 @@ __global__ __launch_bounds__(256) void conv_bf16x3_split_weights_kernel(const fl
 //        SLOWER (round 3, batch 2: 16->16 @96^3 171 vs 161 us, 48->16 473 vs 438, 32->32 @48^3 71.8 vs 67.8): the two waves of a
 //        SIMD run the multiply phase together, the matrix pipe is already saturated there, and the extra VALU lengthens each
 //        wave's in-order stream instead of hiding in the other wave's MFMAs.  Kept as a measurement variant, not the default.
+// The same for up to kSplitMulti packed weights in ONE launch (grid.y = weight): a training step splits every convolution weight
+// once, up front (they only change in the optimiser), instead of one small launch in front of every convolution call.
+constexpr int kSplitMulti = 32;
+struct SplitMulti {
+  const float* wp[kSplitMulti];
+  uint4* ws[kSplitMulti];
+  int cinP[kSplitMulti], coutP[kSplitMulti], nchunks[kSplitMulti];
+};
+__global__ __launch_bounds__(256) void conv_bf16x3_split_weights_multi_kernel(SplitMulti m) {
+  const int e = blockIdx.y;
+  const float* __restrict__ wp = m.wp[e];
+  uint4* __restrict__ ws = m.ws[e];
+  const int cinP = m.cinP[e], coutP = m.coutP[e];
+  const long total = (long)m.nchunks[e] * 3 * 2 * Bf3::SLOTS * coutP;
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(it % coutP);
+    long r = it / coutP;
+    const int slot = (int)(r % Bf3::SLOTS);
+    r /= Bf3::SLOTS;
+    const int hf = (int)(r % 2);
+    r /= 2;
+    const int dz = (int)(r % 3), chunk = (int)(r / 3);
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = 10 * dz + slot < 27 ? wp[((long)(10 * dz + slot) * cinP + chunk * 16 + hf * 8 + c) * coutP + co] : 0.f;
+    uint4 o1, o2, o3;
+    bf3_split8(v, o1, o2, o3);
+    const long plane = (long)Bf3::SLOTS * coutP;
+    uint4* d = ws + ((long)(chunk * 3 + dz) * 6 + hf) * plane + (long)slot * coutP + co;
+    d[0] = o1;
+    d[2 * plane] = o2;
+    d[4 * plane] = o3;
+  }
+}
+
 template <int NBT, int TY, int V = 8>
 __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {

@@ -189,7 +189,7 @@ class PackedWeights:
     current: Optional["PackedWeights"] = None
 
     def __init__(self):
-        self.entries = {}     # id(parameter) -> [parameter, wp, wpt, valid]
+        self.entries = {}     # id(parameter) -> [parameter, wp, wpt, valid, wsplit_fwd, wsplit_dgrad, planes valid, wants planes]
 
     def begin_step(self):
         PackedWeights.current = self
@@ -206,10 +206,43 @@ class PackedWeights:
                                                    _stream(live[0][0])), "pack_weights_multi")
         for e in live:
             e[3] = True
+        # the three bf16 planes of every pack that can run on the split-product kernels (csrc/kernels/conv_bf16x3.h), again in one
+        # launch: a convolution call then starts its kernel directly instead of a small split launch in front of it
+        jobs = []
+        for e in live:
+            cout, cin = e[0].shape[0], e[0].shape[1]
+            if e[0].shape[2] != 3 or not e[7]:      # only weights that have met a volume the split-product kernels take
+                continue
+            if e[4] is None and e[5] is None:
+                for slot, (ci, co) in ((4, (cin, cout)), (5, (cout, cin))):
+                    nb = L.icl_conv3d_split_ws_bytes(ci, co)
+                    if nb:
+                        e[slot] = torch.empty(nb // 4, dtype=torch.float32, device=e[0].device)
+            if e[4] is not None:
+                jobs.append((e[1], e[4], cin, cout))
+            if e[5] is not None:
+                jobs.append((e[2], e[5], cout, cin))
+        if jobs:
+            m = len(jobs)
+            arr, iarr = ctypes.c_void_p * m, ctypes.c_int32 * m
+            _lib.check(L.icl_conv3d_split_weights_multi(arr(*[j[0].data_ptr() for j in jobs]), arr(*[j[1].data_ptr() for j in jobs]),
+                                                        iarr(*[j[2] for j in jobs]), iarr(*[j[3] for j in jobs]), m, _stream(live[0][0])),
+                       "split_weights_multi")
+        for e in live:
+            e[6] = True
+
+    @staticmethod
+    def split_of(weight):
+        """(fwd planes, dgrad planes) of a weight whose packs were split by this step's ``begin_step()``; (None, None) otherwise."""
+        cache = PackedWeights.current if isinstance(weight, torch.nn.Parameter) else None
+        e = cache.entries.get(id(weight)) if cache is not None else None
+        if e is None or e[0] is not weight or not e[3] or not e[6]:
+            return None, None
+        return e[4], e[5]
 
     def end_step(self):
         for e in self.entries.values():
-            e[3] = False
+            e[3] = e[6] = False
         if PackedWeights.current is self:
             PackedWeights.current = None
 
@@ -231,11 +264,24 @@ class PackedWeights:
             wpt = torch.empty(L.icl_conv3d_packed_elems(cout, cin, ks, 1), dtype=torch.float32, device=weight.device)
         _lib.check(L.icl_conv3d_pack_weights_both(_ptr(weight), _ptr(wp), _ptr(wpt), cout, cin, ks, _stream(weight)), "pack_weights_both")
         if cache is not None:
-            cache.entries[id(weight)] = [weight, wp, wpt, True]
+            if e is not None:
+                e[1], e[2], e[3], e[6] = wp, wpt, True, False       # packed by this call: the split planes are stale
+            else:
+                cache.entries[id(weight)] = [weight, wp, wpt, True, None, None, False, False]
         return wp, wpt
 
+    @staticmethod
+    def note_volume(weight, voxels: int):
+        """Called by the convolution with the size of the volume it runs on: weights that meet a volume of the split-product
+        kernels (>= 48^3 voxels unless ICL_CONV_SPLIT_MIN says otherwise) get their bf16 planes from the next begin_step() on."""
+        cache = PackedWeights.current if isinstance(weight, torch.nn.Parameter) else None
+        e = cache.entries.get(id(weight)) if cache is not None else None
+        if e is not None and e[0] is weight and voxels >= int(os.environ.get("ICL_CONV_SPLIT_MIN", 48 ** 3)):
+            e[7] = True
 
-def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_bstride):
+
+def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_bstride, wsplit=None):
+    """``wsplit``: the pack's bf16 planes when the step's PackedWeights.begin_step() has split them already."""
     L = _lib.lib()
     s = d * h * w
     # algorithmic work of this launch (SURVEY.md Appendix B): 2*taps*Cin*Cout FLOP per voxel; 4*(I+O+W) bytes
@@ -244,6 +290,11 @@ def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_b
     need = L.icl_conv3d_fwd_ws_bytes(n, cin, cout, d, h, w, ks)
     ws = _ws(need, x) if need else None
     with _timed("conv3d_mfma_fwd_kernel", flops, nbytes, x):
+        if wsplit is not None and ks == 3:
+            rc = L.icl_conv3d_fwd_presplit(_ptr(x), _ptr(wsplit), _ptr(bias), _ptr(y), n, cin, cout, d, h, w, x_bstride, y_bstride, _stream(x))
+            if rc != 1:         # 1: this shape does not run on the split-product kernel -> the fp32 pack below
+                _lib.check(rc, "conv3d_fwd_presplit")
+                return
         _lib.check(L.icl_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(ws), n, cin, cout, d, h, w, ks,
                                     x_bstride, y_bstride, _stream(x)), "conv3d_fwd")
 
@@ -296,12 +347,16 @@ class _Conv3d(torch.autograd.Function):
             _lib.check(_lib.lib().icl_conv1x1_small(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), n, cin, cout, s, cin, 1, _stream(x)),
                        "conv1x1_small")
             return y
+        wsf = ctx.wsd = None
         if ctx.needs_input_grad[0]:
             # the input gradient will need the flipped/transposed packing too: one launch for both, kept for backward
             wp, ctx.wpt = PackedWeights.get(weight)
+            wsf, ctx.wsd = PackedWeights.split_of(weight)
+            if ks == 3:
+                PackedWeights.note_volume(weight, s)
         else:
             wp = pack_weights(weight, 0)
-        conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, cin * s, y, cout * s)
+        conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, cin * s, y, cout * s, wsplit=wsf)
         return y
 
     @staticmethod
@@ -325,7 +380,7 @@ class _Conv3d(torch.autograd.Function):
             else:
                 gx = torch.empty_like(x)
                 wpt = ctx.wpt if ctx.wpt is not None else pack_weights(weight, 1)
-                conv3d_forward_raw(gy, wpt, None, n, cout, cin, d, h, w, ks, cout * s, gx, cin * s)
+                conv3d_forward_raw(gy, wpt, None, n, cout, cin, d, h, w, ks, cout * s, gx, cin * s, wsplit=getattr(ctx, "wsd", None))
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw = torch.empty_like(weight)
             gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None

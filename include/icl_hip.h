@@ -47,6 +47,16 @@ int icl_conv3d_pack_weights_multi(const void* const* w, void* const* wp_fwd, voi
  * ws (counted by icl_conv3d_fwd_ws_bytes; without ws the fp32 MFMA kernels run).  Environment: ICL_CONV_SPLIT=0 selects the fp32
  * MFMA kernels for every shape. */
 int64_t icl_conv3d_fwd_ws_bytes(int n, int cin, int cout, int d, int h, int w, int ks);
+/* Split-product convolution with the weight split hoisted out of the call (the weights only change in the optimiser step):
+ * icl_conv3d_split_weights_multi turns up to `count` packed weights wp[i] (icl_conv3d_pack_weights, mode 0 or 1; Cin % 16 == 0) into
+ * their three bf16 planes wsplit[i] (icl_conv3d_split_ws_bytes(cin, cout) bytes each, 16-byte aligned; 0 = not eligible) in ONE
+ * launch; icl_conv3d_fwd_presplit is icl_conv3d_fwd on such planes.  It returns 1 — nothing launched — when the shape does not run on
+ * the split-product kernel (volume below 48^3, W % 4 != 0, ICL_CONV_SPLIT=0): the caller then uses icl_conv3d_fwd with the fp32 pack. */
+int64_t icl_conv3d_split_ws_bytes(int cin, int cout);
+int icl_conv3d_split_weights_multi(const void* const* wp, void* const* wsplit, const int32_t* cin, const int32_t* cout, int count,
+                                   void* stream);
+int icl_conv3d_fwd_presplit(const float* x, const void* wsplit, const float* bias, float* y, int n, int cin, int cout, int d, int h, int w,
+                            int64_t x_bstride, int64_t y_bstride, void* stream);
 int icl_conv3d_fwd(const float* x, const float* wp, const float* bias, float* y, void* ws, int n, int cin, int cout, int d, int h,
                    int w, int ks, int64_t x_bstride, int64_t y_bstride, void* stream);
 /* gw[cout][cin][taps] = sum over batch and voxels; ws >= icl_conv3d_wgrad_ws_bytes(n,cin,cout,ks) bytes (one packed
