@@ -49,6 +49,10 @@ struct WgTrT {
 // every four taps — a wave's phase as ONE merged instruction stream instead of the chain S, M): 5-14 % slower on the one-cout-block
 // layers (16->16 @96^3 181 vs 167 us, 48->16 546 vs 479), 1-4 % slower with two cout blocks — as for the forward kernel, VALU that
 // the compiler interleaves with a wave's own MFMAs costs more than the same VALU run as a block beside the partner wave's MFMAs.
+// Also measured and dropped: dedicated producer / consumer waves for one cout block (waves 0-7 only multiply, 4 or 8 more waves
+// only stage; 126 registers, three / four waves per SIMD): 4 producers 11-12 % slower (the staging of a tile becomes the longer
+// side), 8 producers within 1 % of this kernel (16->16 @96^3 166 vs 168 us) — with one cout block the LDS is the co-bottleneck
+// (one transposing read per MFMA: ~55 % of its bandwidth, plus the staging writes), not the order of S and M inside a wave.
 template <int NCB>
 __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                               float* __restrict__ gwp, Bf3WGeom g) {
