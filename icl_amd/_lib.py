@@ -32,6 +32,7 @@ _SIGNATURES = {
     "icl_conv3d_pack_weights_multi": (c_int, [P, P, P, P, P, P, I, P]),
     "icl_conv3d_fwd_ws_bytes": (c_int64, [I, I, I, I, I, I, I]),
     "icl_conv3d_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, L, L, P]),
+    "icl_scalar_combine": (c_int, [P, P, I, I, P, P]),
     "icl_conv3d_split_ws_bytes": (c_int64, [I, I]),
     "icl_conv3d_split_weights_multi": (c_int, [P, P, P, P, I, P]),
     "icl_conv3d_fwd_presplit": (c_int, [P, P, P, P, I, I, I, I, I, I, L, L, P]),

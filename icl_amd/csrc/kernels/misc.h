@@ -162,6 +162,23 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const float* __rest
   }
 }
 
+// ---- out[j] = sum_i w[j][i] * *in[i] for up to 16 device scalars in and 16 out: every "+", "/ 3", "10 *" between the loss terms of
+// a step (utils/losses.py, trainer :105-112) in ONE launch — as 0-dim torch arithmetic they were ~20 one-element kernels forward and
+// ~10 backward.  The backward is the same kernel with the transposed weights (the inputs then are the elements of one gradient vector).
+constexpr int kScalarCombine = 16;
+struct ScalarCombine {
+  const float* in[kScalarCombine];
+  float w[kScalarCombine][kScalarCombine];      // [out][in]
+  int n_in, n_out;
+};
+__global__ __launch_bounds__(64) void scalar_combine_kernel(ScalarCombine s, float* __restrict__ out) {
+  const int j = threadIdx.x;
+  if (j >= s.n_out) return;
+  float acc = 0.f;
+  for (int i = 0; i < s.n_in; ++i) acc += s.w[j][i] * *s.in[i];      // fixed order
+  out[j] = acc;
+}
+
 // ---- column sums of up to kColsumMulti small row-major matrices in ONE launch (grid.y = matrix): out_i[c] = sum_r g_i[r][c].
 // The bias gradients of the aligner's Linear layers (a few to a few hundred rows each): the trainer collects them during backward
 // and reduces them together instead of one tiny reduction launch per layer (38 per U-Net step).

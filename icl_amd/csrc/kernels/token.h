@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
 // ---------------------------------------------------------------- prototype cross-attention
 // q    [B,h,nc,D]   (the reference's reshape-quirk layout of fc_q's output, unet_3D_icl.py:287)
 // kv   [B,N,2,h,D]  (fc_kv output: k | v, head, d)
-// logits[B,h,nc,N] = scale * q.k   — returned as the "attention" map (pre-softmax, :290,296)
+// logits[B,nc,h,N] = scale * q.k   — returned as the "attention" map (pre-softmax, :290,296), stored CLASS-major: the layout of the
+// reference's `attn1.permute(0, 2, 1, 3)`, so the caller's permute is a no-op and the token-axis LayerNorm / MLP that follow read
+// contiguous rows (as [B,h,nc,N] every consumer started with a transposing copy, forward and backward)
 // out  [B,h,nc,D]   = softmax_N(logits) @ v;  stats[B,h,nc,2] = (row max, sum of exp) for the backward.
 constexpr int kAttnMaxNc = 16;
 
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) s += qs[c * D + d] * k[d];
-    logits[((long)bh * nc + c) * N + n] = s * scale;
+    logits[(((long)b * nc + c) * H + h) * N + n] = s * scale;
   }
 }
 
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const float* __res
   const int row = blockIdx.x;  // (b*H + h)*nc + c
   const int bh = row / nc;
   const int b = bh / H, h = bh % H;
-  const float* l = logits + (long)row * N;
+  const float* l = logits + (((long)b * nc + row % nc) * H + h) * N;
   float m = -3.0e38f;
   for (int n = threadIdx.x; n < N; n += 256) m = fmaxf(m, l[n]);
   m = wave_max(m);
@@ -234,11 +236,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
 #pragma unroll
   for (int d = 0; d < D; ++d) { v[d] = kv[base + (long)H * D + d]; dk[d] = 0.f; dv[d] = 0.f; }
   for (int c = 0; c < nc; ++c) {
-    const float p = expf(logits[((long)bh * nc + c) * N + n] - ms[c * 2]) / ms[c * 2 + 1];
+    const long li = (((long)b * nc + c) * H + h) * N + n;
+    const float p = expf(logits[li] - ms[c * 2]) / ms[c * 2 + 1];
     float dp = 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) dp += gos[c * D + d] * v[d];
-    const float g = (glog ? glog[((long)bh * nc + c) * N + n] : 0.f) + p * (dp - dl[c]);
+    const float g = (glog ? glog[li] : 0.f) + p * (dp - dl[c]);
 #pragma unroll
     for (int d = 0; d < D; ++d) { dk[d] += scale * g * qs[c * D + d]; dv[d] += p * gos[c * D + d]; }
   }
@@ -267,16 +270,17 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   }
   __syncthreads();
   const float m = stats[(long)row * 2], tot = stats[(long)row * 2 + 1], delta = delta_s;
+  const long lrow = (((long)b * nc + row % nc) * H + h) * N;      // class-major logits / glog row
   float acc[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) acc[d] = 0.f;
   for (int n = threadIdx.x; n < N; n += 256) {
     const long base = ((long)b * N + n) * 2 * H * D + h * D;
-    const float p = expf(logits[(long)row * N + n] - m) / tot;
+    const float p = expf(logits[lrow + n] - m) / tot;
     float dp = 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) dp += go[d] * kv[base + (long)H * D + d];
-    const float g = (glog ? glog[(long)row * N + n] : 0.f) + p * (dp - delta);
+    const float g = (glog ? glog[lrow + n] : 0.f) + p * (dp - delta);
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] += g * kv[base + d];
   }

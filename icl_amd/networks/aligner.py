@@ -95,9 +95,9 @@ class Query_Attention(nn.Module):  # noqa: N801
         nc, h = q.shape[1], self.num_heads
         qh = self.fc_q(q).reshape(B, h, nc, C // h)          # reshape quirk (:287)
         kv = self.fc_kv(x)                                    # [B, N, 2C] = [B, N, (k|v), h, d]
-        out, logits = ops.prototype_attention(qh, kv, h, self.scale)   # out [B,h,nc,d], logits [B,h,nc,N]
+        out, logits = ops.prototype_attention(qh, kv, h, self.scale)   # out [B,h,nc,d], logits [B,nc,h,N] (= attn1.permute(0,2,1,3), :296)
         out = self.proj(out.reshape(B, nc, C))                # reshape quirk (:293)
-        return out, logits.permute(0, 2, 1, 3)
+        return out, logits
 
 
 class Class_Decoder(nn.Module):  # noqa: N801

@@ -1050,7 +1050,10 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, weight.shape[1]).contiguous()
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
-        ctx.bias_param = owner.bias if (owner is not None and bias is not None and getattr(owner, "bias", None) is bias) else None
+        # the Parameter behind the bias (for DeferredBiasGrads: all small bias gradients of a step reduced in one launch): the
+        # owner's, or the argument itself when the caller passed a Parameter without naming its module
+        ctx.bias_param = (owner.bias if (owner is not None and bias is not None and getattr(owner, "bias", None) is bias)
+                          else (bias if isinstance(bias, torch.nn.Parameter) else None))
         ctx.x_shape = x.shape
         return linear_forward_raw(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])
 
@@ -1489,7 +1492,7 @@ class _ProtoAttention(torch.autograd.Function):
         B, h, nc, d = qh.shape
         N = kv.shape[1]
         assert h == heads and kv.shape[2] == 2 * h * d
-        logits = torch.empty((B, h, nc, N), dtype=torch.float32, device=qh.device)
+        logits = torch.empty((B, nc, h, N), dtype=torch.float32, device=qh.device)       # class-major: the layout the reference returns
         out = torch.empty((B, h, nc, d), dtype=torch.float32, device=qh.device)
         stats = torch.empty((B, h, nc, 2), dtype=torch.float32, device=qh.device)
         _lib.check(L.icl_attn_fwd(_ptr(qh), _ptr(kv), _ptr(logits), _ptr(out), _ptr(stats), B, h, nc, N, d, scale, _stream(qh)), "attn_fwd")
@@ -1514,7 +1517,7 @@ class _ProtoAttention(torch.autograd.Function):
 
 def prototype_attention(qh: torch.Tensor, kv: torch.Tensor, heads: int, scale: float):
     """qh [B,h,nc,d]; kv [B,N,2*h*d] laid out (k|v, head, d).  Returns (softmax(QK^T*scale) V  [B,h,nc,d],
-    scaled pre-softmax logits [B,h,nc,N])."""
+    scaled pre-softmax logits [B,nc,h,N] — already in the layout of the reference's ``attn1.permute(0, 2, 1, 3)``)."""
     return _ProtoAttention.apply(qh, kv, heads, float(scale))
 
 
@@ -1564,6 +1567,42 @@ class _FusedLoss(torch.autograd.Function):
         _lib.check(L.icl_loss_bwd(_ptr(a), None if hard else _ptr(target), _ptr(target) if hard else None, _ptr(weight),
                                   _ptr(stats), _ptr(g0), _ptr(g1), _ptr(ga), B, nc, S, mode, aip, _stream(a)), "loss_bwd")
         return ga, None, None, None, None
+
+
+class _CombineScalars(torch.autograd.Function):
+    """out[j] = sum_i W[j][i] * terms[i] for 0-dim fp32 tensors ``terms``: one launch (icl_scalar_combine); backward one launch with
+    W^T.  The scalar arithmetic between loss terms (trainer :105-112, losses.py "(a + b + c) / 3") as torch ops is a chain of
+    one-element kernels, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, W, *terms):
+        n, m = len(terms), len(W)
+        ts = [t if (t.dtype == torch.float32 and t.dim() == 0) else t.float().reshape(()) for t in terms]
+        _require(*ts)
+        out = torch.empty(m, dtype=torch.float32, device=ts[0].device)
+        arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        flat = (ctypes.c_float * (m * n))(*[float(W[j][i]) for j in range(m) for i in range(n)])
+        _lib.check(_lib.lib().icl_scalar_combine(arr, flat, n, m, _ptr(out), _stream(out)), "scalar_combine")
+        ctx.W = W
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        W, n = ctx.W, ctx.n
+        m = len(W)
+        gout = gout.contiguous()
+        gin = torch.empty(n, dtype=torch.float32, device=gout.device)
+        arr = (ctypes.c_void_p * m)(*[gout.data_ptr() + 4 * j for j in range(m)])
+        flat = (ctypes.c_float * (n * m))(*[float(W[j][i]) for i in range(n) for j in range(m)])       # W^T, [n][m]
+        _lib.check(_lib.lib().icl_scalar_combine(arr, flat, m, n, _ptr(gin), _stream(gin)), "scalar_combine_bwd")
+        return (None,) + tuple(gin[i] for i in range(n))
+
+
+def combine_scalars(terms, W) -> torch.Tensor:
+    """[sum_i W[j][i] * terms[i] for j] as one fp32 vector; ``terms``: 0-dim tensors on one device, ``W``: nested Python floats
+    (at most 16 x 16)."""
+    return _CombineScalars.apply(tuple(tuple(float(v) for v in row) for row in W), *terms)
 
 
 def _weight_tensor(weight, like):

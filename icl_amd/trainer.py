@@ -65,11 +65,26 @@ class ICLTrainer:
         lab = label_batch[:cfg.labeled_bs]
         # CrossEntropyLoss()(out0, y) and DiceLoss(softmax(out0), y) (…BraTS.py:105-108) from one fused pass
         loss_ce, loss_dice = ops.cross_entropy_dice_parts(outputs[0], lab, cfg.num_classes)
-        loss_aux = self.aux_loss(outputs[2], lab)
-        loss_pse = self.pse_loss(outputs[3], outputs[1])
-        loss_con = L.softmax_mse_loss(outputs[3], outputs[4])
-        loss = loss_dice + loss_ce + loss_aux + cfg.w_pse * loss_pse + cfg.w_con * loss_con
-        return loss, dict(dice=loss_dice, ce=loss_ce, aux=loss_aux, pse=loss_pse, con=loss_con)
+        # every term of the five-part objective as a leaf scalar, the weighted sums (loss = dice + ce + aux + w_pse pse + w_con con,
+        # aux / pse / con = means over the scales) in ONE launch: out = [loss, aux, pse, con]
+        aux = self.aux_loss.leaves(outputs[2], lab)
+        pse = self.pse_loss.leaves(outputs[3], outputs[1])
+        con = L.softmax_mse_leaves(outputs[3], outputs[4])
+        leaves = [loss_dice, loss_ce] + aux + pse + con
+        if len(leaves) > 16:      # more scales than the combine kernel takes: the class-level means, then the sum
+            loss_aux = self.aux_loss(outputs[2], lab)
+            loss_pse = self.pse_loss(outputs[3], outputs[1])
+            loss_con = L.softmax_mse_loss(outputs[3], outputs[4])
+            loss = loss_dice + loss_ce + loss_aux + cfg.w_pse * loss_pse + cfg.w_con * loss_con
+            return loss, dict(dice=loss_dice, ce=loss_ce, aux=loss_aux, pse=loss_pse, con=loss_con)
+        na, npse, ncon = len(aux), len(pse), len(con)
+        nmaps = max(len(outputs[2]), 1)
+        wa, wp, wc = [1.0 / nmaps] * na, [1.0 / max(npse, 1)] * npse, [1.0 / max(ncon, 1)] * ncon
+        z = lambda k: [0.0] * k      # noqa: E731
+        W = [[1.0, 1.0] + wa + [cfg.w_pse * v for v in wp] + [cfg.w_con * v for v in wc],
+             z(2) + wa + z(npse) + z(ncon), z(2) + z(na) + wp + z(ncon), z(2) + z(na) + z(npse) + wc]
+        out = ops.combine_scalars(leaves, W)
+        return out[0], dict(dice=loss_dice, ce=loss_ce, aux=out[1], pse=out[2], con=out[3])
 
     def _forward_backward(self, volume_batch, label_batch):
         cfg = self.cfg

@@ -29,14 +29,23 @@ def softmax_dice_loss(input_logits, target_logits):
     return ops.soft_dice_loss(input_logits, target_logits)
 
 
+def _mean_of(leaves):
+    """Mean of a list of 0-dim loss terms in one launch (ops.combine_scalars) instead of a chain of one-element adds and a divide."""
+    if len(leaves) == 1:
+        return leaves[0]
+    return ops.combine_scalars(leaves, [[1.0 / len(leaves)] * len(leaves)])[0]
+
+
+def softmax_mse_leaves(input_logits, target_logits):
+    """The per-scale terms of softmax_mse_loss (each enters the loss with weight 1 / len)."""
+    return [ops.softmax_mse(a, b.detach()) for a, b in zip(input_logits, target_logits)]
+
+
 def softmax_mse_loss(input_logits, target_logits, sigmoid=False):
     """losses.py:68-90: lists of per-scale maps; targets detached; mean over scales."""
     if sigmoid:
         raise NotImplementedError("the ICL trainers never pass sigmoid=True")
-    loss = 0.0
-    for a, b in zip(input_logits, target_logits):
-        loss = loss + ops.softmax_mse(a, b.detach())
-    return loss / len(input_logits)
+    return _mean_of(softmax_mse_leaves(input_logits, target_logits))
 
 
 class DiceLoss(nn.Module):
@@ -71,11 +80,16 @@ class AuxLoss(nn.Module):
         self.dice_loss = DiceLoss(n_classes)
         self.resize = tuple(resize)
 
-    def forward(self, feat_maps, labels):
-        loss = 0.0
+    def leaves(self, feat_maps, labels):
+        """[ce_0, dice_0, ce_1, dice_1, ...]: the loss is their sum / len(feat_maps)."""
+        out = []
         for fm in feat_maps:
-            loss = loss + ops.cross_entropy_dice(_resize2d(fm, self.resize), labels.long(), self.n_classes)
-        return loss / len(feat_maps)
+            out += list(ops.cross_entropy_dice_parts(_resize2d(fm, self.resize), labels.long(), self.n_classes))
+        return out
+
+    def forward(self, feat_maps, labels):
+        lv = self.leaves(feat_maps, labels)
+        return ops.combine_scalars(lv, [[1.0 / len(feat_maps)] * len(lv)])[0]
 
 
 class PseudoSoftLoss(nn.Module):
@@ -85,12 +99,12 @@ class PseudoSoftLoss(nn.Module):
         super().__init__()
         self.resize = tuple(resize)
 
-    def forward(self, feat_maps, predicts):
+    def leaves(self, feat_maps, predicts):
         tgt = predicts.detach()
-        loss = 0.0
-        for fm in feat_maps:
-            loss = loss + softmax_dice_loss(_resize2d(fm, self.resize), tgt)
-        return loss / len(feat_maps)
+        return [softmax_dice_loss(_resize2d(fm, self.resize), tgt) for fm in feat_maps]
+
+    def forward(self, feat_maps, predicts):
+        return _mean_of(self.leaves(feat_maps, predicts))
 
 
 class AuxLoss3D(nn.Module):
@@ -103,12 +117,16 @@ class AuxLoss3D(nn.Module):
         self.dice_loss = DiceLoss(n_classes)
         self.resize = tuple(resize)
 
-    def forward(self, feat_maps, labels):
-        loss = 0.0
+    def leaves(self, feat_maps, labels):
+        """[ce_0, dice_0, ce_1, dice_1, ...] (CE + Dice(softmax=True) per map): the loss is their sum / len(feat_maps)."""
+        out = []
         for fm in feat_maps:
-            r = _resize(fm, self.resize)
-            loss = loss + ops.cross_entropy_dice(r, labels.long(), self.n_classes)  # CE + Dice(softmax=True)
-        return loss / len(feat_maps)
+            out += list(ops.cross_entropy_dice_parts(_resize(fm, self.resize), labels.long(), self.n_classes))
+        return out
+
+    def forward(self, feat_maps, labels):
+        lv = self.leaves(feat_maps, labels)
+        return ops.combine_scalars(lv, [[1.0 / len(feat_maps)] * len(lv)])[0]
 
 
 class PseudoSoftLoss3D(nn.Module):
@@ -118,9 +136,9 @@ class PseudoSoftLoss3D(nn.Module):
         super().__init__()
         self.resize = tuple(resize)
 
-    def forward(self, feat_maps, predicts):
+    def leaves(self, feat_maps, predicts):
         tgt = predicts.detach()
-        loss = 0.0
-        for fm in feat_maps:
-            loss = loss + softmax_dice_loss(_resize(fm, self.resize), tgt)
-        return loss / len(feat_maps)
+        return [softmax_dice_loss(_resize(fm, self.resize), tgt) for fm in feat_maps]
+
+    def forward(self, feat_maps, predicts):
+        return _mean_of(self.leaves(feat_maps, predicts))

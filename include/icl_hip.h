@@ -160,7 +160,7 @@ int icl_layernorm_bwd(const float* gy, const float* x, const float* gamma, const
 int icl_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int icl_gelu_bwd(const float* gy, const float* x, float* gx, int64_t n, void* stream);
 /* Prototype cross-attention of Query_Attention.forward (:283-297): q [B,h,nc,d] (reshape-quirk layout of fc_q's output),
- * kv [B,N,2,h,d] (fc_kv output).  logits [B,h,nc,N] = scale*q.k (the pre-softmax map the reference returns),
+ * kv [B,N,2,h,d] (fc_kv output).  logits [B,nc,h,N] = scale*q.k (the pre-softmax map, in the class-major layout the reference returns it in: `attn1.permute(0, 2, 1, 3)`, :296),
  * out [B,h,nc,d] = softmax_N(logits) @ v, stats [B,h,nc,2] = (row max, sum exp).  d in {8,16}, nc <= 16.
  * Backward: gout / glog (either may be NULL) are the upstream gradients of out / logits. */
 int icl_attn_fwd(const float* q, const float* kv, float* logits, float* out, float* stats, int b, int h, int nc, int n, int d,
@@ -171,6 +171,10 @@ int icl_attn_bwd(const float* q, const float* kv, const float* logits, const flo
 /* out_i[c] = sum_r g_i[r * cols_i + c] for `count` small row-major matrices, one launch per 48 of them: the bias gradients of the
  * aligner / Swin Linear layers (unet_3D_icl.py:244-315) collected over a backward pass. */
 int icl_colsum_multi(const void* const* g, void* const* out, const int32_t* rows, const int32_t* cols, int count, void* stream);
+/* out[j] = sum_i w[j * n_in + i] * *in[i]: n_in <= 16 device scalars (pointers in a HOST array), n_out <= 16 results, w a HOST array.
+ * The scalar arithmetic between the loss terms of an ICL step (weighted sums, means over three scales) in one launch; its backward is
+ * the same call with the transposed weights. */
+int icl_scalar_combine(const void* const* in, const float* w, int n_in, int n_out, float* out, void* stream);
 
 /* ---- token <-> window order of the Swin blocks (pad + roll + window_partition, window_reverse + roll + crop:
  * networks/swinunetr_icl.py:825-866, networks/swinunet_icl.py:256-283): out[b][m][0..c) = idx[m] >= 0 ? src[b][idx[m]][0..c) : 0,

@@ -171,14 +171,16 @@ def test_token_ops_and_losses_and_sgd(dev):
     for B, h, nc, d, N in [(2, 16, 2, 16, 216), (1, 8, 16, 16, 1728), (2, 4, 2, 16, 13824)]:
         C = h * d
         qh, kv = _rand((B, h, nc, d), 71), _rand((B, N, 2 * C), 72)
-        go, gl = _rand((B, h, nc, d), 73), _rand((B, h, nc, N), 74)
+        go, gl = _rand((B, h, nc, d), 73), _rand((B, nc, h, N), 74)      # logits come back class-major (attn1.permute(0, 2, 1, 3))
         qg, kg = qh.to(dev).requires_grad_(), kv.to(dev).requires_grad_()
         out, logits = ops.prototype_attention(qg, kg, h, d ** -0.5)
+        assert logits.shape == (B, nc, h, N) and logits.is_contiguous()
         ((out * go.to(dev)).sum() + (logits * gl.to(dev)).sum()).backward()
         qr, kr = qh.clone().requires_grad_(), kv.clone().requires_grad_()
         kvp = kr.reshape(B, N, 2, h, d).permute(2, 0, 3, 1, 4)
-        lr = (qr @ kvp[0].transpose(-2, -1)) * d ** -0.5
-        orf = lr.softmax(dim=-1) @ kvp[1]
+        lr4 = (qr @ kvp[0].transpose(-2, -1)) * d ** -0.5
+        orf = lr4.softmax(dim=-1) @ kvp[1]
+        lr = lr4.permute(0, 2, 1, 3)
         ((orf * go).sum() + (lr * gl).sum()).backward()
         assert rel_err(out.detach().cpu(), orf.detach()) < 1e-5 and rel_err(logits.detach().cpu(), lr.detach()) < 1e-5
         assert rel_err(qg.grad.cpu(), qr.grad) < 1e-4 and rel_err(kg.grad.cpu(), kr.grad) < 1e-4

@@ -527,14 +527,16 @@ def test_prototype_attention(B, h, nc, d, N):
     C = h * d
     qh = _rand((B, h, nc, d), 71, True)
     kv = _rand((B, N, 2 * C), 72, True)
-    go, gl = _rand((B, h, nc, d), 73), _rand((B, h, nc, N), 74)
+    go, gl = _rand((B, h, nc, d), 73), _rand((B, nc, h, N), 74)      # logits come back class-major (attn1.permute(0, 2, 1, 3))
     scale = d ** -0.5
     out, logits = ops.prototype_attention(qh, kv, h, scale)
+    assert logits.shape == (B, nc, h, N) and logits.is_contiguous()
     ((out * go).sum() + (logits * gl).sum()).backward()
     qr, kr = qh.detach().clone().requires_grad_(), kv.detach().clone().requires_grad_()
     kvp = kr.reshape(B, N, 2, h, d).permute(2, 0, 3, 1, 4)
-    lr = (qr @ kvp[0].transpose(-2, -1)) * scale
-    orf = lr.softmax(dim=-1) @ kvp[1]
+    lr4 = (qr @ kvp[0].transpose(-2, -1)) * scale
+    orf = lr4.softmax(dim=-1) @ kvp[1]
+    lr = lr4.permute(0, 2, 1, 3)
     ((orf * go).sum() + (lr * gl).sum()).backward()
     assert rel_err(out.detach(), orf.detach()) < 1e-5 and rel_err(logits.detach(), lr.detach()) < 1e-5
     assert rel_err(qh.grad, qr.grad) < 1e-4 and rel_err(kv.grad, kr.grad) < 1e-4
