@@ -252,7 +252,7 @@ def main():
             flag = torch.tensor([ok], device=dev, dtype=torch.int32)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
             if int(flag.item()) == 0:
-                trainer.graph = trainer.graph_update = None
+                trainer.graph = trainer.graph_forward = trainer.graph_update = None
                 ddp.static = False
                 graphed = False
         trainer.step(vol, lab)
@@ -363,7 +363,7 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_kernel_timer:
-        trainer.graph = trainer.graph_update = None   # per-kernel HIP-event timing needs eager launches ...
+        trainer.graph = trainer.graph_forward = trainer.graph_update = None   # per-kernel HIP-event timing needs eager launches ...
         trainer.ddp = None                              # ... of this rank's step alone: the other ranks are done
         ops.SideStream.enabled = False                  # ... on ONE stream: a kernel's duration is its own, not a share of the GPU
         with ops.KernelTimer() as kt:

@@ -7,6 +7,7 @@ logits returned as the "attention", ``q + drop_path(q)`` doubling, token-axis ``
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Sequence
 
@@ -114,13 +115,21 @@ class Class_Decoder(nn.Module):  # noqa: N801
         self.norm3 = LayerNorm(n_tokens, device)
         self.mlp2 = MLP(n_tokens, n_tokens, device)
 
-    def forward(self, query, feat):
+    def attend(self, query, feat):
+        """The query half (:258-264): attention, then the query's own residual MLP.  The returned logits feed ``refine``."""
         query, attn = self.attn(self.norm1_query(query), self.norm1(feat))
         query = self.drop_path.add(query, query)
         query = self.drop_path.add(query, self.mlp(self.norm2(query)))
-        attn = self.drop_path.add(attn, attn)
-        attn = self.drop_path.add(attn, self.mlp2(self.norm3(attn)))
         return query, attn
+
+    def refine(self, attn):
+        """The attention-map half (:265-267): residual token-axis MLP.  Needs nothing of the query half but the logits."""
+        attn = self.drop_path.add(attn, attn)
+        return self.drop_path.add(attn, self.mlp2(self.norm3(attn)))
+
+    def forward(self, query, feat):
+        query, attn = self.attend(query, feat)
+        return query, self.refine(attn)
 
 
 class _SepBlock(nn.Module):
@@ -222,39 +231,57 @@ class InherentConsistent(nn.Module):
         ``attn_convs0`` (batch statistics) and the per-call batch means ``updated_Qs`` are still evaluated per input, in
         the reference order (a, then b)."""
         bs = feats[0].shape[0]
-        maps_a, maps_b, qs_a, qs_b = [], [], [], []
+        maps_a, maps_b, qs_a, qs_b, branches = [], [], [], [], []
         nxt = getattr(self, self._qname).expand(bs, -1, -1)
         for i in range(len(self.depth)):
             tok = self._tokens(i, feats[i])
-            q_out, attn = self.class_decoders[i](nxt, tok)
-            b, nc, h, n = attn.shape
-            r = self.resolutions[i]
-            sp = (r,) * self.dims
-            a = attn.contiguous().view(b, nc, h, *sp)
-            for part, maps in zip(ops.split_batch(a, ba), (maps_a, maps_b)):
-                pb = part.shape[0]
-                m = self.attn_convs1[i](self.attn_convs0[i](part.reshape(pb * nc, h, *sp)))
-                maps.append(m.reshape(pb, nc, *sp))
+            q_out, attn = self.class_decoders[i].attend(nxt, tok)
+            # the map chain of this level (token-axis MLP + separable convolutions) does not feed the next level: its own lane
+            with ops.SideStream([attn], lane=(1 + i) if ops.SideStream.lane_mask & 1 else 99) as lane:
+                attn = self.class_decoders[i].refine(attn)
+                b, nc, h, n = attn.shape
+                r = self.resolutions[i]
+                sp = (r,) * self.dims
+                a = attn.contiguous().view(b, nc, h, *sp)
+                for part, maps in zip(ops.split_batch(a, ba), (maps_a, maps_b)):
+                    pb = part.shape[0]
+                    m = self.attn_convs1[i](self.attn_convs0[i](part.reshape(pb * nc, h, *sp)))
+                    maps.append(m.reshape(pb, nc, *sp))
+            branches.append((lane, [maps_a[-1], maps_b[-1]]))
             nxt = self.query_convs[i](q_out)
             qa, qb = ops.split_batch(q_out, ba)
             qs_a.append(_batch_mean(qa))
             qs_b.append(_batch_mean(qb))
+        for lane, outs in branches:
+            lane.join(outs)
         return (maps_a, qs_a), (maps_b, qs_b)
 
     def forward(self, feats, guided_Q=None, modal="labeled"):
         bs = feats[0].shape[0]
-        feat_maps, updated_qs = [], []
-        nxt = getattr(self, self._qname).expand(bs, -1, -1) if modal == "labeled" else None
+        feat_maps, updated_qs, branches = [], [], []
+        labeled = modal == "labeled"
+        nxt = getattr(self, self._qname).expand(bs, -1, -1) if labeled else None
         for i in range(len(self.depth)):
-            tok = self._tokens(i, feats[i])
-            q_in = nxt if modal == "labeled" else guided_Q[i].expand(bs, -1, -1)
-            q_out, attn = self.class_decoders[i](q_in, tok)
-            b, nc, h, n = attn.shape
-            r = self.resolutions[i]
-            sp = (r,) * self.dims
-            a = attn.contiguous().view(b * nc, h, *sp)
-            a = self.attn_convs1[i](self.attn_convs0[i](a))
-            feat_maps.append(a.reshape(b, nc, *sp))
-            nxt = self.query_convs[i](q_out)
-            updated_qs.append(_batch_mean(q_out))
+            # guided queries (unet_3D_icl.py:224-239; its unused next_guided_Q is not computed): the levels do not depend on each other at all — a whole level per lane; own queries:
+            # only the map chain leaves the current stream (see forward_labeled_pair)
+            whole = None if labeled else ops.SideStream([feats[i], guided_Q[i]], lane=(1 + i) if ops.SideStream.lane_mask & 2 else 99)
+            with (whole if whole is not None else contextlib.nullcontext()):
+                tok = self._tokens(i, feats[i])
+                q_in = nxt if labeled else guided_Q[i].expand(bs, -1, -1)
+                q_out, attn = self.class_decoders[i].attend(q_in, tok)
+                part = ops.SideStream([attn], lane=1 + i) if labeled else None
+                with (part if part is not None else contextlib.nullcontext()):
+                    attn = self.class_decoders[i].refine(attn)
+                    b, nc, h, n = attn.shape
+                    r = self.resolutions[i]
+                    sp = (r,) * self.dims
+                    a = attn.contiguous().view(b * nc, h, *sp)
+                    a = self.attn_convs1[i](self.attn_convs0[i](a))
+                    feat_maps.append(a.reshape(b, nc, *sp))
+                if labeled:
+                    nxt = self.query_convs[i](q_out)
+                updated_qs.append(_batch_mean(q_out))
+            branches.append((whole or part, [feat_maps[-1]] + ([updated_qs[-1]] if whole is not None else [])))
+        for lane, outs in branches:
+            lane.join(outs)
         return feat_maps, updated_qs

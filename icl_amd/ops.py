@@ -48,18 +48,35 @@ class SideStream:
     captured step (ICLTrainer.capture) the two streams become parallel branches of the hipGraph.  Tensors crossing streams are
     recorded with the caching allocator (``record_stream``).  ``ICL_ALIGNER_STREAM=0`` (or a CPU tensor) runs the body in line."""
     enabled = os.environ.get("ICL_ALIGNER_STREAM", "1") != "0"
+    lane_mask = int(os.environ.get("ICL_ALIGNER_LANE_MASK", "3"))
+    lanes = int(os.environ.get("ICL_ALIGNER_LANES", "3"))   # further streams for the per-level branches inside the aligners (0: none)
     _streams = {}
+    _outer = None
 
-    def __init__(self, inputs):
+    def __init__(self, inputs, lane: int = 0):
+        """``lane`` 0 is the aligner stream itself; lanes 1..``SideStream.lanes`` carry branches forked from it (the attention-map
+        chain of one resolution level: drop-path, LayerNorm, the token-axis ``mlp2``, the separable convolutions — independent of
+        the query chain that links the levels, unet_3D_icl.py:209-222), so that the many small launches of the 6^3 / 12^3 levels
+        and the HBM-bound 13,824^2 weight streams of the 24^3 level overlap instead of queueing behind each other.  A lane beyond
+        ``SideStream.lanes`` runs its body in line on the current stream."""
         self.stream = None
+        self.children, self.pending = [], []
         t0 = inputs[0]
-        if SideStream.enabled and t0.is_cuda and torch.is_grad_enabled():
+        if SideStream.enabled and t0.is_cuda and torch.is_grad_enabled() and lane <= SideStream.lanes:
             dev = t0.device
-            s = SideStream._streams.get(dev.index)
+            s = SideStream._streams.get((dev.index, lane))
             if s is None:
-                s = SideStream._streams[dev.index] = torch.cuda.Stream(device=dev)
+                s = SideStream._streams[(dev.index, lane)] = torch.cuda.Stream(device=dev)
             self.main = torch.cuda.current_stream(dev)
             s.wait_stream(self.main)
+            if lane == 0:
+                # the lanes fork from and join to the stream the aligner stream itself forks from (see join())
+                for k in range(1, SideStream.lanes + 1):
+                    sk = SideStream._streams.get((dev.index, k))
+                    if sk is None:
+                        sk = SideStream._streams[(dev.index, k)] = torch.cuda.Stream(device=dev)
+                    sk.wait_stream(self.main)
+                    self.children.append(sk)
             for t in inputs:
                 t.record_stream(s)
             self.stream = s
@@ -68,18 +85,33 @@ class SideStream:
     def __enter__(self):
         if self.stream is not None:
             self._guard.__enter__()
+            if self.children:
+                SideStream._outer = self
         return self
 
     def __exit__(self, *a):
         if self.stream is not None:
+            if SideStream._outer is self:
+                SideStream._outer = None
             self._guard.__exit__(*a)
 
     def join(self, outputs):
+        """Order the forking stream after this one.  A lane joined inside the aligner stream's block is NOT waited for there: the
+        aligner stream's own join (to the stream everything forked from) waits for every lane — the lanes' results are consumed by the
+        losses only, and a lane that the aligner stream waits on after it waited on the aligner stream is the two-way dependency
+        between forked streams that a stream capture on ROCm 7.2 does not survive (trainer.capture)."""
         if self.stream is None:
             return
+        outer = SideStream._outer
+        if outer is not None and outer is not self:
+            outer.pending.extend(outputs)
+            return
         self.main.wait_stream(self.stream)
-        for t in outputs:
+        for sk in self.children:
+            self.main.wait_stream(sk)
+        for t in list(outputs) + self.pending:
             t.record_stream(self.main)
+        self.pending = []
 
 
 class KernelTimer:

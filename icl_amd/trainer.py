@@ -56,6 +56,7 @@ class ICLTrainer:
         self.packed = ops.PackedWeights()
         BatchNormAct.share_counters(model)   # one vector for all BatchNorm step counters: one add per step
         self.graph = None
+        self.graph_forward = None
         self.graph_update = None
         self.use_graph = True     # False: launch eagerly although a captured graph exists (bench.py --launch auto compares the two)
         self.lr_dev = None
@@ -86,7 +87,8 @@ class ICLTrainer:
         out = ops.combine_scalars(leaves, W)
         return out[0], dict(dice=loss_dice, ce=loss_ce, aux=out[1], pse=out[2], con=out[3])
 
-    def _forward_backward(self, volume_batch, label_batch):
+    def _forward_backward(self, volume_batch, label_batch, boundary=None):
+        """``boundary()`` (capture only) is called between the loss and ``loss.backward()``."""
         cfg = self.cfg
         ops.StepRNG.begin_step()
         self.packed.begin_step()        # every convolution weight packed once, in one launch (ops.PackedWeights)
@@ -102,6 +104,8 @@ class ICLTrainer:
             with ops.FactoredGrads(cfg.factored_mlp2_grads):
                 outputs = self.model(volume_batch[:cfg.labeled_bs], volume_batch[cfg.labeled_bs:])
                 loss, parts = self.compute_loss(outputs, label_batch)
+                if boundary is not None:
+                    boundary()
                 loss.backward()
         finally:
             ops.FactoredGrads.fused_optimizer = None
@@ -117,8 +121,8 @@ class ICLTrainer:
         self.packed.end_step()
         ops.StepRNG.end_step()
 
-    def _step_body(self, volume_batch, label_batch):
-        parts = self._forward_backward(volume_batch, label_batch)
+    def _step_body(self, volume_batch, label_batch, boundary=None):
+        parts = self._forward_backward(volume_batch, label_batch, boundary)
         if self.ddp is not None:
             self.ddp.reduce_gradients()
         self._apply_update()
@@ -147,6 +151,8 @@ class ICLTrainer:
                 self.static_vol.copy_(volume_batch)
             if label_batch.data_ptr() != self.static_lab.data_ptr():
                 self.static_lab.copy_(label_batch)
+            if self.graph_forward is not None:
+                self.graph_forward.replay()
             self.graph.replay()
             if self.graph_update is not None:    # data-parallel: collectives between the two graphs
                 self.ddp.communicate()
@@ -195,19 +201,37 @@ class ICLTrainer:
         torch.cuda.synchronize(dev)
         # RCCL's watchdog thread polls its events from another thread: keep its calls out of the capture's error scope
         mode = dict(capture_error_mode="thread_local") if ddp is not None else {}
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, **mode):
+        # Forward (+ losses) and backward (+ optimiser) are captured as TWO graphs replayed back to back (one memory pool).  Reason:
+        # the branch streams inside the aligners (ops.SideStream lanes) wait on the aligner stream in the forward pass and the aligner
+        # stream waits on them in the backward pass; hipStreamEndCapture (ROCm 7.2) crashes on a capture in which two forked streams
+        # wait on each other in both directions (tools/capture_probe.py: "pingpong*", "nested*", "lanes_autograd").  Per graph every
+        # cross-stream edge between forked streams has one direction.
+        pool = torch.cuda.graph_pool_handle()
+        graph_f, graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        cap_f, cap_b = torch.cuda.graph(graph_f, pool=pool, **mode), torch.cuda.graph(graph, pool=pool, **mode)
+        active = [cap_f]
+
+        def boundary():
+            active.pop().__exit__(None, None, None)
+            cap_b.__enter__()
+            active.append(cap_b)
+
+        cap_f.__enter__()
+        try:
             if ddp is None:
-                self.static_out = self._step_body(self.static_vol, self.static_lab)
+                self.static_out = self._step_body(self.static_vol, self.static_lab, boundary)
             else:
-                self.static_out = self._forward_backward(self.static_vol, self.static_lab)
+                self.static_out = self._forward_backward(self.static_vol, self.static_lab, boundary)
                 ddp.pack()
+        finally:
+            active.pop().__exit__(None, None, None)
+        self.graph_forward = graph_f
         self.graph_update = None
         if ddp is not None:
             ddp.rebind()
             ddp._captured = True
             update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(update, pool=graph.pool(), **mode):
+            with torch.cuda.graph(update, pool=pool, **mode):
                 ddp.unpack()
                 self._apply_update()
             self.graph_update = update
