@@ -46,7 +46,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md dense bf16 matrix peak
 SPLIT_TERMS = 6
 # matrix-pipe busy fraction of the kernel's cycles, PMC (profiles/r3_pmc_conv.md; <2, 8> / <3, 8>: profiles/r2_pmc_conv.md), static
 PIPE_BUSY = {"conv3d_mfma_fwd_static_kernel": 0.81, "conv3d_bf16x3_fwd_kernel<1, 8, 8>": 0.50, "conv3d_bf16x3_fwd_kernel<2, 8, 8>": 0.52,
-             "conv3d_bf16x3_fwd_kernel<3, 8, 8>": 0.62, "conv3d_wgrad_tr_kernel<1>": 0.44, "conv3d_wgrad_tr_kernel<2>": 0.49}
+             "conv3d_bf16x3_fwd_kernel<3, 8, 8>": 0.62, "conv3d_wgrad_tr_kernel<1>": 0.44, "conv3d_wgrad_tr_kernel<2>": 0.49,
+             "conv3d_bf16x3_fwd_kernel<1, 8, 24>": 0.52}
 
 
 def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
@@ -96,7 +97,9 @@ def hbm_traffic(kernel: str):
     number is a STATIC one, measured by that run for the layer named in `shape`; the JSON line says so (`source`)."""
     try:
         with open(os.path.join(ROOT, HBM_TRAFFIC_FILE)) as f:
-            k = json.load(f)["kernels"].get(kernel)
+            ks = json.load(f)["kernels"]
+        # schedule variant 24 of the split-product forward kernel moves the same bytes as variant 8 (same tiles, same staging)
+        k = ks.get(kernel) or ks.get(kernel.replace(", 8, 24>", ", 8, 8>"))
         if not k:
             return None
         return {"source": f"static profile ({HBM_TRAFFIC_FILE}), not measured in this run",
@@ -392,8 +395,8 @@ def main():
                     "peak_basis": (f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} / {SPLIT_TERMS} terms per fp32 product"
                                    if split else "dense fp32 MFMA peak"),
                     "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                    **({"launch_note": "a timed launch = conv_bf16x3_split_weights_kernel (2-5 us) + the convolution kernel; rocprofv3 "
-                                       "lists them separately (profiles/r2_bench_kernel_stats.csv)"} if split else {}),
+                    **({"launch_note": "a timed launch = the convolution kernel alone: the weight planes of every layer are split "
+                                       "once per step (conv_bf16x3_split_weights_multi_kernel, one launch)"} if split else {}),
                     "traffic": traffic["hbm_bytes"] if traffic else None, "traffic_detail": traffic,
                     # PMC (profiles/r3_pmc_conv.md, static): fraction of the kernel's cycles with the matrix pipe busy; the rest of
                     # the gap to the 2.4 GHz peak is the clock the chip holds under matrix load (1.8-2.1 GHz)

@@ -159,6 +159,9 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   // (432 B of scratch when tried): those instantiations take the straight-line loads of V = 1 and keep the split in the store phase
   constexpr bool EARLY = (V & 2) != 0 && NBT < 3;
   constexpr bool STRAIGHT = (V & 1) != 0, BUFFER = (V & 4) != 0, WHOLE = (V & 8) != 0 && NBT == 1;
+  // V & 16: operand fragments fetched one half-step ahead (see the multiply loop).  B fragments are double-buffered up to two cout
+  // blocks; with three the second set does not fit the register budget (B of the next pair is then read behind the last MFMA)
+  constexpr bool PIPE = (V & 16) != 0 && !EARLY, PIPE_B2 = NBT < 3;
   constexpr int WPL = WHOLE ? 3 : 1;                    // weight planes staged together
   constexpr int NB = 16 * NBT, PX = TC::PX, PY = TC::PY, NPOSP = TC::NPOSP, ROUNDS = TC::ROUNDS, NT = TC::NT;
   constexpr int WITEMS = WPL * 6 * Bf3::SLOTS * NB, WU = (WITEMS + NT - 1) / NT;      // 16-byte weight slots per staging step
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   const uint4* wb = Ws + (half * Bf3::SLOTS + tp) * NB + lr;
 
   f32x4 acc[4][NBT];
+  uint4 pa1[PIPE ? 4 : 1], pa23[PIPE ? 4 : 1][2], pb[PIPE && PIPE_B2 ? 2 : 1][3][NBT];      // V & 16: fragments fetched ahead
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -321,6 +325,84 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       if (dz == 0 && ntile < g.ntiles) load_x(ntile, nchunk);
       // stage dz holds the tap slots 10 dz .. 10 dz + 9 (27 taps + one zero slot = 14 pairs in stages of 5 / 5 / 4: a pair may
       // straddle two dz planes); lane group tp takes the first or the second tap of the pair: its halo offset is a select
+      if constexpr (PIPE) {
+        // A pair's 24 NBT products in two halves of 12 NBT: X = the a1 terms (a1 b3, a1 b2, a1 b1: one operand plane of the four row
+        // blocks, 4 reads), Y = (a3 b1, a2 b2, a2 b1: two planes, 8 reads).  The reads of a half are issued in front of the MFMAs of the
+        // half before it — Y of this pair under X, X and the weight fragments of the NEXT pair under Y — so a wave waits for LDS
+        // only at the start of a barrier-free run of pairs; until round 3 every pair was "15 reads, wait, 24 MFMAs" and the matrix
+        // pipe idled whenever both waves of a SIMD were reading (multiply phase alone: 56 % busy, BF3_DEBUG = 6).
+        const int np = dz < 2 ? 5 : 4;
+        auto frag_ptr = [&](int sdz, int spair) {
+          const int tA = 10 * sdz + 2 * spair, tB = tA + 1 < 27 ? tA + 1 : 26;
+          const int offA = (tA / 9) * PY * PX + ((tA / 3) % 3) * PX + tA % 3, offB = (tB / 9) * PY * PX + ((tB / 3) % 3) * PX + tB % 3;
+          return xa + (tp ? offB : offA);
+        };
+        auto load_b = [&](int buf, int sdz, int spair) {
+#pragma unroll
+          for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int j = 0; j < NBT; ++j)
+#if defined(BF3_DEBUG) && (BF3_DEBUG & 8)
+              pb[buf][s][j] = make_uint4(sdz + s, spair, j, lane);
+#else
+              pb[buf][s][j] = wb[((WHOLE ? sdz * 6 : 0) * Bf3::SLOTS + s * 2 * Bf3::SLOTS + spair * 2) * NB + j * 16];
+#endif
+        };
+        auto load_x1 = [&](int sdz, int spair) {
+          const uint4* xp = frag_ptr(sdz, spair);
+#pragma unroll
+#if defined(BF3_DEBUG) && (BF3_DEBUG & 8)
+          for (int m = 0; m < 4; ++m) pa1[m] = make_uint4(m, lane, (unsigned)(size_t)xp, 1u);
+#else
+          for (int m = 0; m < 4; ++m) pa1[m] = xp[m * PX];
+#endif
+        };
+        auto load_x23 = [&](int sdz, int spair) {
+          const uint4* xp = frag_ptr(sdz, spair);
+#pragma unroll
+#if defined(BF3_DEBUG) && (BF3_DEBUG & 8)
+          for (int m = 0; m < 4; ++m) { pa23[m][1] = make_uint4(m, lane, (unsigned)(size_t)xp, 2u); pa23[m][0] = make_uint4(m, lane, (unsigned)(size_t)xp, 3u); }
+#else
+          for (int m = 0; m < 4; ++m) pa23[m][1] = xp[4 * NPOSP + m * PX];      // a3 first: its products lead the Y half
+#pragma unroll
+          for (int m = 0; m < 4; ++m) pa23[m][0] = xp[2 * NPOSP + m * PX];
+#endif
+        };
+        if (!WHOLE || dz == 0) {              // start of a barrier-free run: nothing was fetched ahead
+          load_b(PIPE_B2 ? (5 * dz) & 1 : 0, dz, 0);
+          load_x1(dz, 0);
+        }
+#pragma unroll
+        for (int pair = 0; pair < np; ++pair) {
+          const int cur = PIPE_B2 ? (5 * dz + pair) & 1 : 0;
+          load_x23(dz, pair);
+          ICL_SCHED_BARRIER();
+#pragma unroll
+          for (int sb = 2; sb >= 0; --sb)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+              for (int j = 0; j < NBT; ++j) acc[m][j] = icl_mfma_16x16x32_bf16(pa1[m], pb[cur][sb][j], acc[m][j]);
+          ICL_SCHED_BARRIER();
+          const bool more = pair + 1 < np || (WHOLE && dz < 2);
+          const int ndz = pair + 1 < np ? dz : dz + 1, npair = pair + 1 < np ? pair + 1 : 0;
+          if (more) {
+            if (PIPE_B2) load_b(cur ^ 1, ndz, npair);
+            load_x1(ndz, npair);
+          }
+          ICL_SCHED_BARRIER();
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            constexpr int sa[3] = {1, 0, 0}, sbb[3] = {0, 1, 0};      // a3 b1, a2 b2, a2 b1
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+              for (int j = 0; j < NBT; ++j) acc[m][j] = icl_mfma_16x16x32_bf16(pa23[m][sa[t]], pb[cur][sbb[t]][j], acc[m][j]);
+          }
+          ICL_SCHED_BARRIER();
+          if (more && !PIPE_B2) load_b(0, ndz, npair);
+        }
+      } else {
 #pragma unroll
       for (int pair = 0; pair < (dz < 2 ? 5 : 4); ++pair) {
         const int tA = 10 * dz + 2 * pair, tB = tA + 1 < 27 ? tA + 1 : 26;      // the zero slot multiplies any valid position
@@ -367,6 +449,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
           }
           ICL_SCHED_BARRIER();
         }
+      }
       }
     }
     if (chunk == g.nchunks - 1) {

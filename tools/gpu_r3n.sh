@@ -1,6 +1,6 @@
-cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
-rocprofv3 --kernel-trace -d $O/r3n_trace -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 6 > /dev/null 2>&1
-python3 $R/tools/timeline.py $O/r3n_trace/t_kernel_trace.csv 3 100 0 1.6 15 | grep '^   '
-python3 $R/tools/timeline.py $O/r3n_trace/t_kernel_trace.csv 3 100 12.3 16 15 | grep '^   '
-rm -f $O/r3n_trace/t_kernel_trace.csv
+cd $R
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_dropin.py -q -x > $O/r3n_tests.log 2>&1
+grep -n 'passed\|failed\|Error\|error' $O/r3n_tests.log | head -20
+for i in 1 2; do python3 bench.py --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 20 2>&1 | tail -1 | cut -c140-170; done
+ICL_CONV_SPLIT_V=8 python3 bench.py --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 20 2>&1 | tail -1 | cut -c140-170
