@@ -1,6 +1,8 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_dropin.py -q -x > $O/r3n_tests.log 2>&1
-grep -n 'passed\|failed\|Error\|error' $O/r3n_tests.log | head -20
-for i in 1 2; do python3 bench.py --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 20 2>&1 | tail -1 | cut -c140-170; done
-ICL_CONV_SPLIT_V=8 python3 bench.py --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 20 2>&1 | tail -1 | cut -c140-170
+B="python3 bench.py --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 20"
+run() { echo "$1"; env $1 $B 2>&1 | tail -1 | cut -c140-170; }
+run "ICL_LOSS_LANES=0"
+run "ICL_LOSS_LANES=1"
+run "ICL_LOSS_LANES=0"
+run "ICL_LOSS_LANES=1"
