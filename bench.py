@@ -47,7 +47,7 @@ SPLIT_TERMS = 6
 # matrix-pipe busy fraction of the kernel's cycles, PMC (profiles/r3_pmc_conv.md; <2, 8> / <3, 8>: profiles/r2_pmc_conv.md), static
 PIPE_BUSY = {"conv3d_mfma_fwd_static_kernel": 0.81, "conv3d_bf16x3_fwd_kernel<1, 8, 8>": 0.50, "conv3d_bf16x3_fwd_kernel<2, 8, 8>": 0.52,
              "conv3d_bf16x3_fwd_kernel<3, 8, 8>": 0.62, "conv3d_wgrad_tr_kernel<1>": 0.44, "conv3d_wgrad_tr_kernel<2>": 0.49,
-             "conv3d_bf16x3_fwd_kernel<1, 8, 24>": 0.52}
+             "conv3d_bf16x3_fwd_kernel<1, 8, 24>": 0.52, "conv3d_bf16x3_fwd_kernel<1, 8, 60>": 0.55}
 
 
 def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
@@ -98,8 +98,8 @@ def hbm_traffic(kernel: str):
     try:
         with open(os.path.join(ROOT, HBM_TRAFFIC_FILE)) as f:
             ks = json.load(f)["kernels"]
-        # schedule variant 24 of the split-product forward kernel moves the same bytes as variant 8 (same tiles, same staging)
-        k = ks.get(kernel) or ks.get(kernel.replace(", 8, 24>", ", 8, 8>"))
+        # schedule variants 24 / 60 of the split-product forward kernel move the same bytes as variant 8 (same tiles, same staging)
+        k = ks.get(kernel) or ks.get(kernel.replace(", 8, 24>", ", 8, 8>").replace(", 8, 60>", ", 8, 8>"))
         if not k:
             return None
         return {"source": f"static profile ({HBM_TRAFFIC_FILE}), not measured in this run",

@@ -54,6 +54,11 @@ __device__ __forceinline__ icl_rsrc_t icl_make_rsrc(const void* p, unsigned byte
 __device__ __forceinline__ float icl_buffer_load_f32(icl_rsrc_t r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
+// ... with a wave-uniform byte offset on top (the instruction's scalar offset operand: no VALU add per load).  An out-of-range
+// lane offset (>= the descriptor's extent) returns 0 whatever the scalar part is.
+__device__ __forceinline__ float icl_buffer_load_f32(icl_rsrc_t r, unsigned byte_off, unsigned uniform_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)uniform_off, 0));
+}
 
 // v_alignbit_b32: bits [sh, sh + 32) of the 64-bit value {hi, lo}
 __device__ __forceinline__ unsigned icl_alignbit(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
@@ -68,6 +73,8 @@ __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 #define ICL_PIN4(u) asm volatile("" : "+v"((u).x), "+v"((u).y), "+v"((u).z), "+v"((u).w))
 // nothing may be scheduled across this point (keeps software-prefetched LDS reads ahead of the MFMAs they overlap)
 #define ICL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// scheduling groups inside one region (LLVM AMDGPU masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read, 0x002 VALU)
+#define ICL_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
 // All lanes of a wave have executed what precedes this point before any lane continues.  On the GPU a wave runs in lockstep and
 // its LDS operations execute in issue order, so this is only a compiler scheduling fence (no instruction); the CPU emulation,

@@ -151,6 +151,19 @@ __global__ __launch_bounds__(256) void conv_bf16x3_split_weights_multi_kernel(Sp
   }
 }
 
+#if defined(BF3_DEBUG) && (BF3_DEBUG & 16)
+// in-kernel stamps (debug builds only): waves 0 and 4 of workgroup 0 (they share a SIMD) record s_memtime at the phase boundaries of
+// work items 2..4; read back with icl_debug_bf3_stamps (tools/bf3_stamps.py)
+__device__ long long g_bf3_stamps[2 * 3 * 32];
+#define BF3_STAMP(k)                                                                                          \
+  do {                                                                                                        \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (wid & 3) == 0 && lane == 0 && item_no >= 2 && item_no < 5)    \
+      g_bf3_stamps[((wid >> 2) * 3 + item_no - 2) * 32 + (k)] = clock64();                                    \
+  } while (0)
+#else
+#define BF3_STAMP(k) ((void)0)
+#endif
+
 template <int NBT, int TY, int V = 8>
 __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {
@@ -162,6 +175,12 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   // V & 16: operand fragments fetched one half-step ahead (see the multiply loop).  B fragments are double-buffered up to two cout
   // blocks; with three the second set does not fit the register budget (B of the next pair is then read behind the last MFMA)
   constexpr bool PIPE = (V & 16) != 0 && !EARLY, PIPE_B2 = NBT < 3;
+  // V & 32 (with 16): the reads of a half-step are not issued as a burst in front of its MFMAs but one behind every NBT-th MFMA
+  // (scheduling groups): in-kernel stamps showed a wave alone at 560-600 cycles per pair against 384 of matrix-pipe time — the
+  // burst's issue time — and the two waves of a SIMD in lockstep (same code, same barrier), bursting together
+  constexpr bool WEAVE = (V & 32) != 0 && PIPE;
+  constexpr bool WOVEN = WEAVE && BUFFER;
+  static_assert(!WOVEN || TC::ROUNDS <= 5, "one staging round per tap pair of the first dz stage");
   constexpr int WPL = WHOLE ? 3 : 1;                    // weight planes staged together
   constexpr int NB = 16 * NBT, PX = TC::PX, PY = TC::PY, NPOSP = TC::NPOSP, ROUNDS = TC::ROUNDS, NT = TC::NT;
   constexpr int WITEMS = WPL * 6 * Bf3::SLOTS * NB, WU = (WITEMS + NT - 1) / NT;      // 16-byte weight slots per staging step
@@ -181,7 +200,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   // ---- staging: item = (channel octet, halo position); lanes walk the positions of the tile in LDS order, so the three 16-byte
   // writes of an item land on consecutive LDS slots across the lanes (no bank conflicts) and the 8 loads of a wave-instruction
   // read runs of 18 consecutive floats.  Tile-invariant part of the addressing:
-  int s_zyx[ROUNDS], s_dst[ROUNDS], s_ch[ROUNDS];
+  int s_zyx[ROUNDS], s_dst[ROUNDS], s_ch[ROUNDS], s_rel[BUFFER ? ROUNDS : 1];
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int it = tid + r * NT;
@@ -190,14 +209,24 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
     s_zyx[r] = it < TC::ITEMS ? (pz << 16) | (py << 8) | px : -1;
     s_ch[r] = o * 8;                                    // first channel of the octet
     s_dst[r] = o * NPOSP + pos;
+    if (BUFFER) s_rel[r] = o * 8 * (int)DHW + (pz - 1) * (int)HW + (py - 1) * g.W + (px - 1);
   }
   float xv[ROUNDS][8];
-  auto load_x = [&](int tile, int chunk) {
+  // the (sample, z0, y0, x0) of a tile: five integer divisions of wave-uniform values (a reciprocal sequence on the VALU each) — once
+  // per work item, not once per staging round
+  struct Origin { const float* xb; int z0, y0, x0; };
+  auto origin_of = [&](int tile, int chunk) {
     const int b = tile / tiles_per, bt = tile % tiles_per;
-    const int x0 = (bt % g.ntx) * TC::TX, y0 = ((bt / g.ntx) % g.nty) * TC::TY, z0 = (bt / (g.ntx * g.nty)) * TC::TZ;
-    const float* xb = x + (long)b * g.x_bstride + (long)chunk * 16 * DHW;
+    Origin o;
+    o.x0 = (bt % g.ntx) * TC::TX, o.y0 = ((bt / g.ntx) % g.nty) * TC::TY, o.z0 = (bt / (g.ntx * g.nty)) * TC::TZ;
+    o.xb = x + (long)b * g.x_bstride + (long)chunk * 16 * DHW;
+    return o;
+  };
+  auto load_x_at = [&](const Origin& o, int r0, int r1) {
+    const float* xb = o.xb;
+    const int z0 = o.z0, y0 = o.y0, x0 = o.x0;
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
+    for (int r = r0; r < r1; ++r) {
       const int gz = z0 - 1 + (s_zyx[r] >> 16), gy = y0 - 1 + ((s_zyx[r] >> 8) & 255), gx = x0 - 1 + (s_zyx[r] & 255);
       // (bitwise &: the short-circuit form compiles to a chain of exec-mask branches)
       const bool ok = (s_zyx[r] >= 0) & ((unsigned)gz < (unsigned)g.D) & ((unsigned)gy < (unsigned)g.H) & ((unsigned)gx < (unsigned)g.W);
@@ -205,12 +234,11 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       const int off = ok ? s_ch[r] * (int)DHW + gz * (int)HW + gy * g.W + gx : 0;
       if (BUFFER) {
         const icl_rsrc_t xr = icl_make_rsrc(xb, (unsigned)(16 * DHW * 4));
-        unsigned boff = ok ? (unsigned)off * 4u : 0x80000000u;
+        // lane part: the tile-invariant offset of the lane's halo position and channel octet (s_rel) + the tile's origin; the
+        // channel plane c enters as the scalar offset of the load
+        const unsigned boff = ok ? (unsigned)(s_rel[r] + (z0 * (int)HW + y0 * g.W + x0)) * 4u : 0x80000000u;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          xv[r][c] = icl_buffer_load_f32(xr, boff);
-          boff += (unsigned)DHW * 4u;
-        }
+        for (int c = 0; c < 8; ++c) xv[r][c] = icl_buffer_load_f32(xr, boff, (unsigned)c * (unsigned)DHW * 4u);
       } else if (!STRAIGHT) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) xv[r][c] = ok ? (xb + c * DHW)[off] : 0.f;
@@ -224,6 +252,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       }
     }
   };
+  auto load_x = [&](int tile, int chunk) { load_x_at(origin_of(tile, chunk), 0, ROUNDS); };
   uint4 xsp[EARLY ? ROUNDS : 1][3];          // V = 1: the split planes of a staging round, produced during the multiply phase
   auto split_round = [&](int r) {
     bf3_split8(xv[r], xsp[EARLY ? r : 0][0], xsp[EARLY ? r : 0][1], xsp[EARLY ? r : 0][2]);
@@ -299,15 +328,21 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
     }
   }
   bool first_item = true;
+  int item_no = -1;
+  Origin nxt = {x, 0, 0, 0};
   while (tile < g.ntiles) {
     int ntile = tile, nchunk = chunk + 1;
     if (nchunk == g.nchunks) { nchunk = 0; ntile = next_tile(tile); }
+    ++item_no;
+    BF3_STAMP(0);
     __syncthreads();                       // everyone has finished reading the previous halo tile and weight plane
+    BF3_STAMP(1);
 #if !defined(BF3_DEBUG) || !(BF3_DEBUG & 2)
     store_x();
 #endif
     if (WHOLE && (g.nchunks > 1 || first_item)) store_w();
     first_item = false;
+    BF3_STAMP(2);
 #pragma unroll
     for (int dz = 0; dz < 3; ++dz) {
       if (!WHOLE) {
@@ -320,9 +355,16 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
         else if (ntile < g.ntiles) load_w(nchunk, 0);
       } else if (dz == 0) {
         __syncthreads();
+        BF3_STAMP(3);
         if (g.nchunks > 1 && ntile < g.ntiles) load_w(nchunk, 0);
       }
-      if (dz == 0 && ntile < g.ntiles) load_x(ntile, nchunk);
+      // WOVEN: the halo loads of the next work item are not issued here as one burst (in-kernel stamps: 2.7-4.1k of a 20k-cycle
+      // item during which both waves of a SIMD compute addresses and the matrix pipe idles) but one staging round per tap pair
+      // of the dz = 0 stage, inside that pair's scheduling region (buffer loads: no branches; past the last tile the current one
+      // is loaded again and never stored)
+      if (dz == 0 && ntile < g.ntiles && !WOVEN) load_x(ntile, nchunk);
+      if (WOVEN && dz == 0) nxt = origin_of(ntile < g.ntiles ? ntile : tile, ntile < g.ntiles ? nchunk : chunk);
+      if (dz == 0) BF3_STAMP(4);
       // stage dz holds the tap slots 10 dz .. 10 dz + 9 (27 taps + one zero slot = 14 pairs in stages of 5 / 5 / 4: a pair may
       // straddle two dz planes); lane group tp takes the first or the second tap of the pair: its halo offset is a select
       if constexpr (PIPE) {
@@ -337,9 +379,9 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
           const int offA = (tA / 9) * PY * PX + ((tA / 3) % 3) * PX + tA % 3, offB = (tB / 9) * PY * PX + ((tB / 3) % 3) * PX + tB % 3;
           return xa + (tp ? offB : offA);
         };
-        auto load_b = [&](int buf, int sdz, int spair) {
+        auto load_b = [&](int buf, int sdz, int spair, int s0 = 0, int s1 = 3) {
 #pragma unroll
-          for (int s = 0; s < 3; ++s)
+          for (int s = s0; s < s1; ++s)
 #pragma unroll
             for (int j = 0; j < NBT; ++j)
 #if defined(BF3_DEBUG) && (BF3_DEBUG & 8)
@@ -375,22 +417,34 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #pragma unroll
         for (int pair = 0; pair < np; ++pair) {
           const int cur = PIPE_B2 ? (5 * dz + pair) & 1 : 0;
+          if (WOVEN && dz == 0 && pair < ROUNDS) load_x_at(nxt, pair, pair + 1);
           load_x23(dz, pair);
-          ICL_SCHED_BARRIER();
+          if (!WEAVE) ICL_SCHED_BARRIER();
 #pragma unroll
           for (int sb = 2; sb >= 0; --sb)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
               for (int j = 0; j < NBT; ++j) acc[m][j] = icl_mfma_16x16x32_bf16(pa1[m], pb[cur][sb][j], acc[m][j]);
+          if (WEAVE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              ICL_SCHED_GROUP(0x008, NBT);
+              ICL_SCHED_GROUP(0x100, 1);
+            }
+            ICL_SCHED_GROUP(0x008, 4 * NBT);
+          }
           ICL_SCHED_BARRIER();
           const bool more = pair + 1 < np || (WHOLE && dz < 2);
           const int ndz = pair + 1 < np ? dz : dz + 1, npair = pair + 1 < np ? pair + 1 : 0;
           if (more) {
-            if (PIPE_B2) load_b(cur ^ 1, ndz, npair);
+            // in the order of first use by the next X half (b3, a1 of the four row blocks, b2, b1): woven between this half's MFMAs,
+            // every read is then issued 11-12 MFMAs before the product that needs it
+            if (PIPE_B2) load_b(cur ^ 1, ndz, npair, 2, 3);
             load_x1(ndz, npair);
+            if (PIPE_B2) load_b(cur ^ 1, ndz, npair, 0, 2);
           }
-          ICL_SCHED_BARRIER();
+          if (!WEAVE) ICL_SCHED_BARRIER();
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
             constexpr int sa[3] = {1, 0, 0}, sbb[3] = {0, 1, 0};      // a3 b1, a2 b2, a2 b1
@@ -399,8 +453,18 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #pragma unroll
               for (int j = 0; j < NBT; ++j) acc[m][j] = icl_mfma_16x16x32_bf16(pa23[m][sa[t]], pb[cur][sbb[t]][j], acc[m][j]);
           }
+          if (WEAVE && more) {
+            constexpr int R = 4 + (PIPE_B2 ? 3 * NBT : 0);      // reads of this half-step
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+              ICL_SCHED_GROUP(0x008, 1);
+              ICL_SCHED_GROUP(0x100, 1);
+            }
+            ICL_SCHED_GROUP(0x008, 12 * NBT - R);
+          }
           ICL_SCHED_BARRIER();
           if (more && !PIPE_B2) load_b(0, ndz, npair);
+          BF3_STAMP(5 + 5 * dz + pair);
         }
       } else {
 #pragma unroll
@@ -449,9 +513,11 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
           }
           ICL_SCHED_BARRIER();
         }
+        BF3_STAMP(5 + 5 * dz + pair);
       }
       }
     }
+    BF3_STAMP(20);
     if (chunk == g.nchunks - 1) {
       // ---- epilogue: lane holds x = 4 lq + r of row (wid, m), column co = n0 + 16 j + lr
       const int b = tile / tiles_per, bt = tile % tiles_per;
@@ -475,6 +541,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
         }
       }
     }
+    BF3_STAMP(21);
     tile = ntile;
     chunk = nchunk;
   }

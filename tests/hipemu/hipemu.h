@@ -275,11 +275,19 @@ static inline float icl_buffer_load_f32(icl_rsrc_t r, unsigned byte_off) {
   memcpy(&f, r.p + byte_off, 4);
   return f;
 }
+static inline float icl_buffer_load_f32(icl_rsrc_t r, unsigned byte_off, unsigned uniform_off) {
+  if ((uint64_t)byte_off + 4 > r.bytes) return 0.f;
+  if ((uint64_t)byte_off + uniform_off + 4 > r.bytes) { fprintf(stderr, "hipemu: buffer load past the descriptor through the scalar offset\n"); abort(); }
+  float f;
+  memcpy(&f, r.p + byte_off + uniform_off, 4);
+  return f;
+}
 static inline float icl_fast_exp(float x) { return expf(x); }
 static inline float4 icl_nt_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static inline void icl_nt_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 #define ICL_OPAQUE_INT(x) ((void)(x))
 #define ICL_SCHED_BARRIER() ((void)0)
+#define ICL_SCHED_GROUP(mask, n) ((void)0)
 #define ICL_PIN4(u) ((void)(u))
 #define ICL_WAVE_UNIFORM(x) ((void)(x))
 #define ICL_WAVE_SYNC() hipemu::yield_state(2)

@@ -1,11 +1,7 @@
-# forward split kernel ablations (compile-time BF3_DEBUG bits: 1 no MFMA, 2 no split/LDS store of x, 4 no output store, 8 no fragment reads (V = 24 only))
 R=$GRAFT_REPO_ROOT
 cd $R
-for lib in icl_amd/libicl_hip.so gpurun_in/libicl_dbg6.so gpurun_in/libicl_dbg14.so; do
-  for V in 8 24; do
-  echo "== lib '$lib' V=$V"
-  for shape in "16 16 96" "48 16 96" "32 32 48"; do
-    ICL_CONV_SPLIT_V=$V ICL_HIP_LIB=$R/$lib python3 tools/conv_one.py $shape fwd 5 2 2>&1 | tail -1
-  done
-  done
+for V in 60; do
+ICL_HIP_LIB=$R/gpurun_in/libicl_dbg16.so ICL_CONV_SPLIT_V=$V python3 tools/bf3_stamps.py 16 16 96 | grep -v 'item [34]'
+ICL_HIP_LIB=$R/gpurun_in/libicl_dbg16.so ICL_CONV_SPLIT_V=$V python3 tools/bf3_stamps.py 32 32 48 | grep -v 'item [34]'
 done
+python3 tools/conv_ab.py --shapes "16,16,96,fwd;48,16,96,fwd;16,48,96,fwd;32,32,48,fwd;96,32,48,fwd;48,48,96,fwd" --var ICL_CONV_SPLIT_V=24 --var ICL_CONV_SPLIT_V=56 --var ICL_CONV_SPLIT_V=60
