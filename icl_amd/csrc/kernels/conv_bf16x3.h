@@ -238,7 +238,11 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
         // channel plane c enters as the scalar offset of the load
         const unsigned boff = ok ? (unsigned)(s_rel[r] + (z0 * (int)HW + y0 * g.W + x0)) * 4u : 0x80000000u;
 #pragma unroll
+#if defined(BF3_DEBUG) && (BF3_DEBUG & 32)
+        for (int c = 0; c < 8; ++c) xv[r][c] = __uint_as_float(boff + c);      // ablation: the address arithmetic without the loads
+#else
         for (int c = 0; c < 8; ++c) xv[r][c] = icl_buffer_load_f32(xr, boff, (unsigned)c * (unsigned)DHW * 4u);
+#endif
       } else if (!STRAIGHT) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) xv[r][c] = ok ? (xb + c * DHW)[off] : 0.f;

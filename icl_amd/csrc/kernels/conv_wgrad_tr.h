@@ -53,6 +53,14 @@ struct WgTrT {
 // only stage; 126 registers, three / four waves per SIMD): 4 producers 11-12 % slower (the staging of a tile becomes the longer
 // side), 8 producers within 1 % of this kernel (16->16 @96^3 166 vs 168 us) — with one cout block the LDS is the co-bottleneck
 // (one transposing read per MFMA: ~55 % of its bandwidth, plus the staging writes), not the order of S and M inside a wave.
+// Also measured and dropped (round 3, after in-kernel stamps had priced a vector-memory instruction of the forward kernel at ~70
+// cycles of the issuing wave): staging by 16-byte loads — items of four x positions x four channels (four aligned buffer_load_dwordx4,
+// 44 wave-level load instructions per tile instead of 192), three ds_write_b64 per position with a lane-dependent rotation of the
+// position order for conflict-free banks: 16->16 @96^3 166 vs 166 us, 32->32 @48^3 84 vs 77, 96->32 202 vs 180, 48->48 @96^3 1539 vs
+// 1299 (spills).  The number of load instructions is not what bounds this kernel.  Neither is the placement of the transposing
+// reads: woven one behind every MFMA of the previous tap by scheduling groups (the forward kernel's -7..13 %) 16->16 @96^3 205 / 199 vs
+// 202 / 201 us, 32->32 @48^3 88 vs 84-85 on one box.  (hipcc 7.2 note from that experiment: casting the
+// elements of __builtin_amdgcn_raw_buffer_load_b128's result one by one narrows the load to one dword; cast the whole vector.)
 template <int NCB>
 __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                               float* __restrict__ gwp, Bf3WGeom g) {
