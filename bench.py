@@ -47,7 +47,9 @@ SPLIT_TERMS = 6
 # matrix-pipe busy fraction of the kernel's cycles, PMC (profiles/r3_pmc_conv.md; <2, 8> / <3, 8>: profiles/r2_pmc_conv.md), static
 PIPE_BUSY = {"conv3d_mfma_fwd_static_kernel": 0.81, "conv3d_bf16x3_fwd_kernel<1, 8, 8>": 0.50, "conv3d_bf16x3_fwd_kernel<2, 8, 8>": 0.52,
              "conv3d_bf16x3_fwd_kernel<3, 8, 8>": 0.62, "conv3d_wgrad_tr_kernel<1>": 0.44, "conv3d_wgrad_tr_kernel<2>": 0.49,
-             "conv3d_bf16x3_fwd_kernel<1, 8, 24>": 0.52, "conv3d_bf16x3_fwd_kernel<1, 8, 60>": 0.55}
+             "conv3d_bf16x3_fwd_kernel<1, 8, 24>": 0.52,
+             # variant 60 (profiles/r3_pmc_conv.md, second table)
+             "conv3d_bf16x3_fwd_kernel<1, 8, 60>": 0.56, "conv3d_bf16x3_fwd_kernel<2, 8, 60>": 0.54, "conv3d_bf16x3_fwd_kernel<3, 8, 60>": 0.68}
 
 
 def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
