@@ -29,6 +29,7 @@ __global__ __launch_bounds__(kNormThreads) void rowstats_partial_kernel(
   float n = 0.f, shift = 0.f, s1 = 0.f, s2 = 0.f;
   if ((S & 3) == 0) {   // 16 bytes per lane (chunk bounds are multiples of 4)
     const float4* x4 = reinterpret_cast<const float4*>(xr);
+#pragma unroll 4
     for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += kNormThreads) {
       const float4 v = x4[i];
       if (n == 0.f) shift = v.x;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_fwd_kernel(
     const float4* x4 = reinterpret_cast<const float4*>(xr);
     const float4* r4 = reinterpret_cast<const float4*>(rr);
     float4* y4 = reinterpret_cast<float4*>(yr);
+#pragma unroll 4
     for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += kNormThreads) {
       float4 v = x4[i];
       v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_partial_kernel(
     const float4* x4 = reinterpret_cast<const float4*>(xr);
     const float4* g4 = reinterpret_cast<const float4*>(gr);
     const float4* r4 = reinterpret_cast<const float4*>(rr);
+#pragma unroll 4
     for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += kNormThreads) {
       const float4 xv = x4[i], gv = g4[i];
       const float4 rv = rr ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -268,6 +271,7 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_apply_kernel(
     const float4* r4 = reinterpret_cast<const float4*>(rr);
     float4* o4 = reinterpret_cast<float4*>(o);
     float4* go4 = reinterpret_cast<float4*>(go);
+#pragma unroll 4
     for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += kNormThreads) {
       const float4 xv = x4[i], gv = g4[i];
       const float4 rv = rr ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
