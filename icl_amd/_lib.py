@@ -66,6 +66,9 @@ _SIGNATURES = {
     "icl_gather_rows_sum2": (c_int, [P, P, P, L, L, L, I, P]),
     "icl_im2col3": (c_int, [P, P, I, I, I, I, I, P]),
     "icl_im2col3_planes": (c_int, [P, P, I, I, I, I, I, P]),
+    "icl_conv3d_cin1_fwd": (c_int, [P, P, P, P, I, I, I, I, I, L, L, P]),
+    "icl_conv3d_cin1_wgrad_ws_bytes": (c_int64, [I, I, I]),
+    "icl_conv3d_cin1_wgrad": (c_int, [P, P, P, P, I, I, I, I, I, L, L, P]),
     "icl_col2im3": (c_int, [P, P, I, I, I, I, I, P]),
     "icl_linear_ws_bytes": (c_int64, [L, I, I, I]),
     "icl_linear_fwd": (c_int, [P, P, P, P, P, L, I, I, I, P]),

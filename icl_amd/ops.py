@@ -379,6 +379,14 @@ class _Conv3d(torch.autograd.Function):
             _lib.check(_lib.lib().icl_conv1x1_small(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), n, cin, cout, s, cin, 1, _stream(x)),
                        "conv1x1_small")
             return y
+        ctx.cin1 = (ks == 3 and cin == 1 and cout <= 16 and not ctx.needs_input_grad[0] and 120 * (w + 2) <= 65536
+                    and os.environ.get("ICL_CONV_CIN1", "1") != "0")
+        if ctx.cin1:
+            # the first convolution of the backbones (one input channel): K = 27, an HBM stream of the output (csrc/kernels/conv_cin1.h)
+            with _timed("conv_cin1_fwd_kernel", 2.0 * 27 * cout * s * n, 4.0 * n * s * (1 + cout), x):
+                _lib.check(_lib.lib().icl_conv3d_cin1_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), n, cout, d, h, w, cin * s, cout * s,
+                                                          _stream(x)), "conv3d_cin1_fwd")
+            return y
         wsf = ctx.wsd = None
         if ctx.needs_input_grad[0]:
             # the input gradient will need the flipped/transposed packing too: one launch for both, kept for backward
@@ -434,6 +442,11 @@ class _Conv3d(torch.autograd.Function):
                 with _timed("conv1x1_wgrad_kernel", flops, nbytes, x):
                     _lib.check(L.icl_conv1x1_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin, cout, s, cin * s,
                                                    cout * s, _stream(x)), "conv1x1_wgrad")
+            elif getattr(ctx, "cin1", False) and w % 4 == 0 and gb_arg is None and gy.data_ptr() % 16 == 0:
+                ws = _ws(L.icl_conv3d_cin1_wgrad_ws_bytes(n, d, h), x)
+                with _timed("conv_cin1_wgrad_kernel", flops, nbytes, x):
+                    _lib.check(L.icl_conv3d_cin1_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(ws), n, cout, d, h, w, cin * s, cout * s,
+                                                       _stream(x)), "conv3d_cin1_wgrad")
             elif ks == 3 and cin * 27 <= FIRST_CONV_PLANES_MAX_K and w % 4 == 0 and n * s >= CONV1X1_WGRAD_MIN_VOXELS * 64:
                 # first convolution (one input channel, big volume): 27 shifted planes + the same HBM-bound reduction; the implicit
                 # GEMM pads Cin to 16 and takes 300 us for 0.8 GFLOP (batch 2, 96^3), this takes ~130

@@ -193,6 +193,17 @@ int icl_im2col3(const float* x, float* cols, int n, int c, int d, int h, int w, 
 /* planes[b][ci*27 + tap][v] = x[b][ci][v + offset(tap)] (zero outside), w % 4 == 0: the first convolution's weight gradient
  * (Cin = 1: networks/unet_3D.py:27, utils.py:104) as icl_conv1x1_wgrad over 27 shifted planes instead of a Cin-padded implicit GEMM. */
 int icl_im2col3_planes(const float* x, float* planes, int n, int c, int d, int h, int w, void* stream);
+
+/* The same layer — nn.Conv3d(1, Cout <= 16, 3, padding 1), the first convolution of unet_3D(in_channels=1) (networks/unet_3D.py:27,
+ * networks/utils.py:104) — as dedicated kernels (kernels/conv_cin1.h): K = 27, both directions are HBM streams of the Cout-channel tensor.
+ * x [N][1][D][H][W] (sample stride x_bstride), w the nn.Conv3d weight [Cout][1][3][3][3], y / gy [N][Cout][D][H][W] (sample stride
+ * y_bstride / gy_bstride), gw like w.  The weight gradient needs W % 4 == 0, gy 16-byte aligned and a workspace of
+ * icl_conv3d_cin1_wgrad_ws_bytes bytes; partial sums are added in a fixed order. */
+int icl_conv3d_cin1_fwd(const float* x, const float* w, const float* bias, float* y, int n, int cout, int d, int h, int wd, int64_t x_bstride,
+                        int64_t y_bstride, void* stream);
+int64_t icl_conv3d_cin1_wgrad_ws_bytes(int n, int d, int h);
+int icl_conv3d_cin1_wgrad(const float* x, const float* gy, float* gw, void* ws, int n, int cout, int d, int h, int wd, int64_t x_bstride,
+                          int64_t gy_bstride, void* stream);
 int icl_col2im3(const float* g, float* dx, int n, int c, int d, int h, int w, void* stream);
 
 /* ---- ConvTranspose3d(kernel 2, stride 2, no bias) = GEMM + depth-to-space (MONAI UnetrUpBlock.transp_conv in SwinUNETR,

@@ -605,6 +605,30 @@ def test_first_conv_weight_gradient_through_shifted_planes(monkeypatch, n, cout,
     _conv_check(n, 1, cout, d, h, w, 3)
 
 
+@pytest.mark.parametrize("n,cout,d,h,w,zero_bias", [(2, 16, 5, 9, 12, True), (1, 12, 3, 8, 24, True), (1, 16, 4, 17, 16, True),
+                                                   (1, 16, 3, 6, 10, True), (2, 5, 2, 8, 8, False)])
+def test_first_conv_dedicated_kernels(n, cout, d, h, w, zero_bias):
+    """conv_cin1.h: the first convolution of the backbones (one input channel, the volume itself: no input gradient) forward and weight
+    gradient on their own kernels — partial x groups (W = 24, 12), H not a multiple of the 8-row slab, fewer than 16 output channels, a
+    width that is not a multiple of 4 and a bias whose gradient is wanted (both: weight gradient on the shifted-planes path)."""
+    x = _rand((n, 1, d, h, w), 21)
+    wt = (_rand((cout, 1, 3, 3, 3), 22) * 0.3).requires_grad_()
+    b = (_rand((cout,), 23) * 0.1).requires_grad_()
+    gy = _rand((n, cout, d, h, w), 24)
+    y = ops.conv3d(x, wt, b, zero_bias_grad=zero_bias)
+    assert _lib.lib().icl_last_kernel_name().decode() == "conv_cin1_fwd_kernel"
+    y.backward(gy)
+    wr, br = wt.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    yr = F.conv3d(x, wr, br, padding=1)
+    yr.backward(gy)
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    assert rel_err(wt.grad, wr.grad) < 1e-5
+    if not zero_bias:
+        assert rel_err(b.grad, br.grad) < 1e-5
+    else:
+        assert float(b.grad.abs().max()) == 0.0
+
+
 def test_conv1x1_big_volume_runs_as_batched_product(monkeypatch):
     """>= 65536 voxels (threshold lowered here): forward / input gradient of a 1x1x1 convolution with many channels are one
     batched product of csrc/kernels/gemm.h on the channel-major volume (bias indexed by the output row), with <= 16 channels the
