@@ -305,10 +305,10 @@ class PackedWeights:
     @staticmethod
     def note_volume(weight, voxels: int):
         """Called by the convolution with the size of the volume it runs on: weights that meet a volume of the split-product
-        kernels (>= 48^3 voxels unless ICL_CONV_SPLIT_MIN says otherwise) get their bf16 planes from the next begin_step() on."""
+        kernels (>= 24^3 voxels unless ICL_CONV_SPLIT_MIN says otherwise) get their bf16 planes from the next begin_step() on."""
         cache = PackedWeights.current if isinstance(weight, torch.nn.Parameter) else None
         e = cache.entries.get(id(weight)) if cache is not None else None
-        if e is not None and e[0] is weight and voxels >= int(os.environ.get("ICL_CONV_SPLIT_MIN", 48 ** 3)):
+        if e is not None and e[0] is weight and voxels >= int(os.environ.get("ICL_CONV_SPLIT_MIN", 24 ** 3)):
             e[7] = True
 
 
