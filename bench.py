@@ -411,8 +411,15 @@ def main():
                                  "vs_fp32_mfma_peak": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                  "algorithmic_gbs": round(tot_by / (tot_ms * 1e-3) / 1e9, 1),
                                  "hbm_frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+                    # every convolution kernel of the step; frac against that kernel's own matrix peak (bf16 / 6 for the split-product
+                    # kernels, fp32 MFMA for the others; a weight-gradient bracket includes its slab-sum launch).  Since round 3 the
+                    # 24^3 layers run on the split-product forward kernel too: launches that cannot fill the chip pull the average of
+                    # their instantiation down (<2, 8, 60>: 13 launches per step, 4 of them at 48^3)
                     "per_kernel": {k: {"launches_per_step": v[0] // 3, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
-                                       "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(conv.items())}}
+                                       "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2),
+                                       "frac": round(v[2] / (v[1] * 1e-3) / 1e12 /
+                                                     (PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS if ("bf16x3" in k or "wgrad_tr" in k) else PEAK_F32_MFMA_TFLOPS), 4)}
+                                   for k, v in sorted(conv.items())}}
             st = {k: v for k, v in summ.items() if k.startswith("linear_stream")}
             if st:   # the 13,824^2 token-axis MLP products: the weight matrix streamed once per launch (csrc/kernels/gemm.h)
                 roof["mlp2_weight_stream"] = {k: {"bound": "hbm", "launches_per_step": v[0] // 3, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
