@@ -766,20 +766,65 @@ def test_graph_replay_equals_eager_steps(dev):
     ops.StepRNG.tensor = None
 
 
+def test_first_convolution_dedicated_kernels(dev, monkeypatch):
+    """csrc/kernels/conv_cin1.h (one input channel -> 16, the first layer of the backbones): forward and weight gradient against an
+    fp64 convolution on a volume the CPU finishes quickly, and at 96^3 (batch 2) against the implicit-GEMM / shifted-planes path they
+    replace (ICL_CONV_CIN1=0)."""
+    import torch.nn.functional as F
+    from icl_amd import _lib, ops
+    torch.manual_seed(11)
+    x = torch.randn(2, 1, 20, 28, 40)
+    w = torch.randn(16, 1, 3, 3, 3) * 0.2
+    b = torch.randn(16) * 0.1
+    g = torch.randn(2, 16, 20, 28, 40)
+    wd = w.double().requires_grad_()
+    yd = F.conv3d(x.double(), wd, b.double(), padding=1)
+    yd.backward(g.double())
+    wg = w.to(dev).requires_grad_()
+    y = ops.conv3d(x.to(dev), wg, b.to(dev), zero_bias_grad=True)
+    assert _lib.lib().icl_last_kernel_name().decode() == "conv_cin1_fwd_kernel"
+    y.backward(g.to(dev))      # (autograd runs this on its device thread: the launcher's kernel-name slot is per thread)
+    assert rel_err(y.detach().cpu().double(), yd.detach()) < 2e-6
+    assert rel_err(wg.grad.cpu().double(), wd.grad) < 2e-6
+    # the weight-gradient entry point itself, through the C ABI
+    L = _lib.lib()
+    xg, gg = x.to(dev), g.to(dev)
+    gw = torch.empty(16, 1, 3, 3, 3, device=dev)
+    ws = torch.empty(L.icl_conv3d_cin1_wgrad_ws_bytes(2, 20, 28) // 4, device=dev)
+    s = 20 * 28 * 40
+    _lib.check(L.icl_conv3d_cin1_wgrad(xg.data_ptr(), gg.data_ptr(), gw.data_ptr(), ws.data_ptr(), 2, 16, 20, 28, 40, s, 16 * s,
+                                       ops._stream(xg)), "conv3d_cin1_wgrad")
+    assert L.icl_last_kernel_name().decode() == "conv_cin1_wgrad_kernel"
+    assert rel_err(gw.cpu().double(), wd.grad) < 2e-6
+    xb = synthetic_volume((2, 1, 96, 96, 96), 77).to(dev)
+    gb = torch.randn(2, 16, 96, 96, 96, device=dev)
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ICL_CONV_CIN1", mode)
+        wv = w.to(dev).requires_grad_()
+        yy = ops.conv3d(xb, wv, b.to(dev), zero_bias_grad=True)
+        yy.backward(gb)
+        outs.append((yy.detach(), wv.grad.detach().clone()))
+    assert rel_err(outs[0][0].cpu(), outs[1][0].cpu()) < 2e-6
+    assert rel_err(outs[0][1].cpu(), outs[1][1].cpu()) < 2e-5      # 1.8 M products per weight: two summation orders
+
+
 def test_aligner_side_stream_equals_single_stream(dev):
-    """ops.SideStream (aligner heads forked onto a second HIP stream, forward and backward) changes the schedule, not the result:
-    losses, every dense gradient and the factored mlp2 gradients of one step equal those of the single-stream run (every kernel
-    of the step sums in a fixed order; a race between the streams would show as garbage, not as 1e-6)."""
+    """ops.SideStream (aligner heads forked onto a second HIP stream, their resolution levels onto three more lanes — round 3 —,
+    forward and backward) changes the schedule, not the result: losses, every dense gradient and the factored mlp2 gradients of one
+    step equal those of the single-stream run (every kernel of the step sums in a fixed order; a race between the streams would
+    show as garbage, not as 1e-6)."""
     from icl_amd import ops
     from icl_amd.networks.unet_3D_icl import unet_3D_icl
     from icl_amd.trainer import ICLConfig, ICLTrainer
     vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
     lab = synthetic_labels((1, 96, 96, 96), 4242, 2).to(dev)
     runs = []
-    prev = ops.SideStream.enabled
+    prev, prev_lanes = ops.SideStream.enabled, ops.SideStream.lanes
     try:
-        for side in (False, True, True):        # the second two-stream run reuses the allocator state of the first
-            ops.SideStream.enabled = side
+        # one stream; aligner stream without lanes; with the three lanes, twice (the second run reuses the allocator state of the first)
+        for side, lanes in ((False, 0), (True, 0), (True, 3), (True, 3)):
+            ops.SideStream.enabled, ops.SideStream.lanes = side, lanes
             ops.StepRNG.tensor = None
             model = unet_3D_icl(n_classes=2, in_channels=1, device=dev)
             fill_like_reference_init(list(model.named_parameters()))
@@ -796,7 +841,7 @@ def test_aligner_side_stream_equals_single_stream(dev):
             del tr, model
             torch.cuda.empty_cache()
     finally:
-        ops.SideStream.enabled = prev
+        ops.SideStream.enabled, ops.SideStream.lanes = prev, prev_lanes
         ops.StepRNG.tensor = None
     base = runs[0]
     assert len(base[2]) == 8                      # four 13,824^2 and four 1,728^2 token-axis matrices stay factored
