@@ -49,6 +49,18 @@ struct Bf3T : Bf3Base {
   static constexpr int ws_u4(int nb) { return 6 * SLOTS * nb; }
   static constexpr size_t lds_bytes(int nbt, int planes = 1) { return (size_t)(XS_U4 + planes * ws_u4(16 * nbt)) * 16; }
 };
+// Flat tile for rows of 24 voxels (the 24^3 level, round 3): 2 x 8 x 24 = 384 outputs = 24 row blocks of 16 consecutive positions of
+// the flattened (z, y, x) index — three per wave — instead of 4 x 8 x 16 tiles whose second x tile is half empty.  A row block may wrap
+// from one row to the next (24 = 16 + 8): a lane's halo offsets of its three blocks are per-lane constants, not multiples of the pitch.
+struct Bf3F24 : Bf3Base {
+  static constexpr int TZ = 2, TY = 8, TX = 24, PZ = TZ + 2, PY = TY + 2, PX = TX + 2;
+  static constexpr int NPOS = PZ * PY * PX;
+  static constexpr int NPOSP = (NPOS + 1 + 15) / 16 * 16;
+  static constexpr int NW = 8, NT = 64 * NW, ITEMS = 2 * NPOS, ROUNDS = (ITEMS + NT - 1) / NT;
+  static constexpr int XS_U4 = 6 * NPOSP;
+  static constexpr int ws_u4(int nb) { return 6 * SLOTS * nb; }
+  static constexpr size_t lds_bytes(int nbt, int planes = 1) { return (size_t)(XS_U4 + planes * ws_u4(16 * nbt)) * 16; }
+};
 typedef Bf3Base Bf3;
 
 // Two fp32 -> their three bf16 terms, packed pairwise (low half = a).  Round-to-nearest splits: s1 = rn(v), s2 = rn(v - s1),
@@ -164,10 +176,12 @@ __device__ long long g_bf3_stamps[2 * 3 * 32];
 #define BF3_STAMP(k) ((void)0)
 #endif
 
-template <int NBT, int TY, int V = 8>
+template <int NBT, int TY, int V = 8, bool FLAT = false>
 __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {
-  typedef Bf3T<TY> TC;
+  typedef typename std::conditional<FLAT, Bf3F24, Bf3T<TY>>::type TC;
+  constexpr int MB = FLAT ? 3 : 4;                      // row blocks per wave
+  static_assert(!FLAT || (TY == 8 && (V & 48) == 48), "the flat tile exists for the pipelined schedule of eight waves");
   // three cout blocks: 48 accumulators + 36 weight-fragment + 24 weight-prefetch registers leave no room for the split planes
   // (432 B of scratch when tried): those instantiations take the straight-line loads of V = 1 and keep the split in the store phase
   constexpr bool EARLY = (V & 2) != 0 && NBT < 3;
@@ -304,7 +318,24 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 
   // ---- operand bases: wave w owns the (z, y) rows 4 w .. 4 w + 3 of the tile
   const int wz = (4 * wid) / TY, wy = (4 * wid) % TY;
-  const int lanepos = (wz * PY + wy) * PX + lr;
+  // halo offset of the lane's position in row block m of the wave, relative to block 0 (FLAT: block 3 wid + m of the flattened tile)
+  int moff[MB];
+  int lanepos;
+  if (FLAT) {
+    int off[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const int p = 16 * (MB * wid + m) + lr, pz = p / (TC::TY * TC::TX), py = (p / TC::TX) % TC::TY, px = p % TC::TX;
+      off[m] = (pz * PY + py) * PX + px;
+    }
+    lanepos = off[0];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) moff[m] = off[m] - off[0];
+  } else {
+    lanepos = (wz * PY + wy) * PX + lr;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) moff[m] = m * PX;      // compile-time constants after unrolling
+  }
   const uint4* xa = Xs + half * NPOSP + lanepos;        // + split * 2 * NPOSP + tap offset
   const uint4* wb = Ws + (half * Bf3::SLOTS + tp) * NB + lr;
 
@@ -398,20 +429,20 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
           const uint4* xp = frag_ptr(sdz, spair);
 #pragma unroll
 #if defined(BF3_DEBUG) && (BF3_DEBUG & 8)
-          for (int m = 0; m < 4; ++m) pa1[m] = make_uint4(m, lane, (unsigned)(size_t)xp, 1u);
+          for (int m = 0; m < MB; ++m) pa1[m] = make_uint4(m, lane, (unsigned)(size_t)xp, 1u);
 #else
-          for (int m = 0; m < 4; ++m) pa1[m] = xp[m * PX];
+          for (int m = 0; m < MB; ++m) pa1[m] = xp[moff[m]];
 #endif
         };
         auto load_x23 = [&](int sdz, int spair) {
           const uint4* xp = frag_ptr(sdz, spair);
 #pragma unroll
 #if defined(BF3_DEBUG) && (BF3_DEBUG & 8)
-          for (int m = 0; m < 4; ++m) { pa23[m][1] = make_uint4(m, lane, (unsigned)(size_t)xp, 2u); pa23[m][0] = make_uint4(m, lane, (unsigned)(size_t)xp, 3u); }
+          for (int m = 0; m < MB; ++m) { pa23[m][1] = make_uint4(m, lane, (unsigned)(size_t)xp, 2u); pa23[m][0] = make_uint4(m, lane, (unsigned)(size_t)xp, 3u); }
 #else
-          for (int m = 0; m < 4; ++m) pa23[m][1] = xp[4 * NPOSP + m * PX];      // a3 first: its products lead the Y half
+          for (int m = 0; m < MB; ++m) pa23[m][1] = xp[4 * NPOSP + moff[m]];      // a3 first: its products lead the Y half
 #pragma unroll
-          for (int m = 0; m < 4; ++m) pa23[m][0] = xp[2 * NPOSP + m * PX];
+          for (int m = 0; m < MB; ++m) pa23[m][0] = xp[2 * NPOSP + moff[m]];
 #endif
         };
         if (!WHOLE || dz == 0) {              // start of a barrier-free run: nothing was fetched ahead
@@ -427,16 +458,16 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #pragma unroll
           for (int sb = 2; sb >= 0; --sb)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
               for (int j = 0; j < NBT; ++j) acc[m][j] = icl_mfma_16x16x32_bf16(pa1[m], pb[cur][sb][j], acc[m][j]);
           if (WEAVE) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 2 * MB; ++i) {
               ICL_SCHED_GROUP(0x008, NBT);
               ICL_SCHED_GROUP(0x100, 1);
             }
-            ICL_SCHED_GROUP(0x008, 4 * NBT);
+            ICL_SCHED_GROUP(0x008, MB * NBT);
           }
           ICL_SCHED_BARRIER();
           const bool more = pair + 1 < np || (WHOLE && dz < 2);
@@ -453,18 +484,19 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
           for (int t = 0; t < 3; ++t) {
             constexpr int sa[3] = {1, 0, 0}, sbb[3] = {0, 1, 0};      // a3 b1, a2 b2, a2 b1
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
               for (int j = 0; j < NBT; ++j) acc[m][j] = icl_mfma_16x16x32_bf16(pa23[m][sa[t]], pb[cur][sbb[t]][j], acc[m][j]);
           }
           if (WEAVE && more) {
-            constexpr int R = 4 + (PIPE_B2 ? 3 * NBT : 0);      // reads of this half-step
+            constexpr int R = MB + (PIPE_B2 ? 3 * NBT : 0);      // reads of this half-step
+            constexpr int NM = 3 * MB * NBT;                     // its MFMAs
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
+            for (int i = 0; i < (R < NM ? R : NM); ++i) {
               ICL_SCHED_GROUP(0x008, 1);
               ICL_SCHED_GROUP(0x100, 1);
             }
-            ICL_SCHED_GROUP(0x008, 12 * NBT - R);
+            if (NM > R) ICL_SCHED_GROUP(0x008, NM - R);
           }
           ICL_SCHED_BARRIER();
           if (more && !PIPE_B2) load_b(0, ndz, npair);
@@ -526,15 +558,20 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       // ---- epilogue: lane holds x = 4 lq + r of row (wid, m), column co = n0 + 16 j + lr
       const int b = tile / tiles_per, bt = tile % tiles_per;
       const int x0 = (bt % g.ntx) * TC::TX, y0 = ((bt / g.ntx) % g.nty) * TC::TY, z0 = (bt / (g.ntx * g.nty)) * TC::TZ;
-      const int gz = z0 + wz, gx = x0 + 4 * lq;
       float* yb = y + (long)b * g.y_bstride;
 #pragma unroll
       for (int j = 0; j < NBT; ++j) {
         const int co = n0 + j * 16 + lr;
         const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int gy = y0 + wy + m;
+        for (int m = 0; m < MB; ++m) {
+          int gz, gy, gx;
+          if (FLAT) {      // the four positions 4 lq .. 4 lq + 3 of block 3 wid + m lie in one row (24 and 16 are multiples of 4)
+            const int p = 16 * (MB * wid + m) + 4 * lq;
+            gz = z0 + p / (TC::TY * TC::TX); gy = y0 + (p / TC::TX) % TC::TY; gx = x0 + p % TC::TX;
+          } else {
+            gz = z0 + wz; gy = y0 + wy + m; gx = x0 + 4 * lq;
+          }
 #if defined(BF3_DEBUG) && (BF3_DEBUG & 4)
           if (acc[m][j][0] == 12345.678f)
 #endif

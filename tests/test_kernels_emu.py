@@ -70,6 +70,9 @@ def test_conv3d_wgrad_row_window_kernel(monkeypatch, mode, n, cin, cout, d, h, w
     (1, 32, 16, 4, 8, 16),      # weight gradient: two cin blocks, forward and input gradient split as well
     (1, 20, 32, 3, 9, 24),      # weight gradient with two cout blocks per workgroup (2 x 8 x 16 tiles): ragged cin block, partial tiles
     (2, 16, 60, 2, 8, 16),      # ... two such workgroup columns, the last cout block ragged (60 -> 64), two samples
+    (1, 16, 16, 3, 9, 24),      # rows of 24 voxels: flat 2 x 8 x 24 tiles (row blocks that wrap from one row to the next), one cout block,
+    (2, 32, 48, 5, 10, 24),     # ... three cout blocks, two chunks, odd depth, partial y tile, two samples
+    (1, 32, 32, 4, 24, 24),     # ... two cout blocks, three y tiles
 ])
 @pytest.mark.parametrize("variant", ["60", "24", "8", "0", "4"])
 def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w, variant):

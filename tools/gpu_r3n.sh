@@ -1,4 +1,5 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
-python -m pytest tests/test_gpu_parity.py -q -x -k "first_convolution or side_stream" > $O/r3n_tests.log 2>&1
-grep -n 'passed\|failed\|Error\|error\|^E ' $O/r3n_tests.log | head -20
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_dropin.py -q -x > $O/r3n_tests.log 2>&1
+grep -n 'passed\|failed\|Error\|error' $O/r3n_tests.log | head -20
+for V in 1 0; do echo swin FLAT=$V; ICL_CONV_SPLIT_FLAT=$V python3 bench.py --model swinunetr_icl --no-cpu-baseline --no-exact-compare --no-kernel-timer --steps 10 2>&1 | tail -1 | cut -c140-170; done
