@@ -1,5 +1,7 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_dropin.py -q -x > $O/r3n_tests.log 2>&1
-grep -n 'passed\|failed\|Error\|error' $O/r3n_tests.log | head -20
-for V in 1 0; do echo swin FLAT=$V; ICL_CONV_SPLIT_FLAT=$V python3 bench.py --model swinunetr_icl --no-cpu-baseline --no-exact-compare --no-kernel-timer --steps 10 2>&1 | tail -1 | cut -c140-170; done
+for cfg in "ICL_ALIGNER_LANES=3" "ICL_ALIGNER_LANES=2" "ICL_ALIGNER_LANES=1" "ICL_ALIGNER_LANES=3 ICL_ALIGNER_LANE_MASK=1" "ICL_ALIGNER_LANES=3 ICL_ALIGNER_LANE_MASK=2" "ICL_ALIGNER_LANES=2 ICL_ALIGNER_LANE_MASK=2"; do
+  echo "== $cfg"
+  env $cfg python3 tools/aligner_probe.py 2>&1 | tail -1 | cut -c45-140
+  env $cfg python3 bench.py --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 20 2>&1 | tail -1 | cut -c140-170
+done
