@@ -61,6 +61,24 @@ struct WgTrT {
 // reads: woven one behind every MFMA of the previous tap by scheduling groups (the forward kernel's -7..13 %) 16->16 @96^3 205 / 199 vs
 // 202 / 201 us, 32->32 @48^3 88 vs 84-85 on one box.  (hipcc 7.2 note from that experiment: casting the
 // elements of __builtin_amdgcn_raw_buffer_load_b128's result one by one narrows the load to one dword; cast the whole vector.)
+// In-kernel stamps of round 3 (-DWGTR_DEBUG, tools/wgtr_stamps.py; 16->16 @96^3, a phase = one tile = ~6.0 k cycles, 1.3 k of them the
+// wave's 81 MFMAs): S -> M wave: split + store 2.1 k, issuing the 24 loads 1.5 k (~55 cycles per vector-memory instruction), multiply
+// 2.3 k; M -> S wave: multiply 2.6 k, split + store 1.1-1.6 k, loads 1.3 k, barrier wait 0.4-1.1 k.  Each wave's phase is the serial chain
+// S + L + M; the partner covers about half of it.  Tried on top and dropped: the S -> M wave's loads woven between the taps of its
+// multiply phase (multiply 2.3 -> 4.4 k cycles: 16->16 200 -> 214 us).
+#if defined(WGTR_DEBUG)
+// waves 0 and 4 of workgroup 0 (one SIMD: the S -> M and the M -> S wave of k-group 0) record s_memtime at the boundaries of phases
+// 4..7; read back with icl_debug_wgtr_stamps
+__device__ long long g_wgtr_stamps[2 * 4 * 8];
+#define WGTR_STAMP(k)                                                                                        \
+  do {                                                                                                       \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (wid & 3) == 0 && lane == 0 && phase_no >= 4 && phase_no < 8) \
+      g_wgtr_stamps[((wid >> 2) * 4 + phase_no - 4) * 8 + (k)] = clock64();                                  \
+  } while (0)
+#else
+#define WGTR_STAMP(k) ((void)0)
+#endif
+
 template <int NCB>
 __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                               float* __restrict__ gwp, Bf3WGeom g) {
@@ -221,20 +239,30 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
     uint4* cur = lds + par * C::BUF_U4;
     uint4* nxt = lds + (par ^ 1) * C::BUF_U4;
     const bool more = tile + 1 < t_end;
+    const int phase_no = tile - t_begin;
+    (void)phase_no;
+    WGTR_STAMP(0);
     if (th == 0) {
       if (more) {
         store_tile(nxt, OTHER());
+        WGTR_STAMP(1);
         if (tile + 1 + C::PF < t_end) load_tile(tile + 1 + C::PF, OTHER());
+        WGTR_STAMP(2);
       }
       multiply(cur, I0());
+      WGTR_STAMP(3);
     } else {
       multiply(cur, I1());
+      WGTR_STAMP(1);
       if (more) {
         store_tile(nxt, OTHER());
+        WGTR_STAMP(2);
         if (tile + 1 + C::PF < t_end) load_tile(tile + 1 + C::PF, OTHER());
+        WGTR_STAMP(3);
       }
     }
     __syncthreads();                                      // nxt is complete, cur has been read by everyone
+    WGTR_STAMP(4);
   };
   for (int tile = t_begin; tile < t_end; tile += 2) {
     phase(tile, I0());
