@@ -65,7 +65,12 @@ struct WgTrT {
 // wave's 81 MFMAs): S -> M wave: split + store 2.1 k, issuing the 24 loads 1.5 k (~55 cycles per vector-memory instruction), multiply
 // 2.3 k; M -> S wave: multiply 2.6 k, split + store 1.1-1.6 k, loads 1.3 k, barrier wait 0.4-1.1 k.  Each wave's phase is the serial chain
 // S + L + M; the partner covers about half of it.  Tried on top and dropped: the S -> M wave's loads woven between the taps of its
-// multiply phase (multiply 2.3 -> 4.4 k cycles: 16->16 200 -> 214 us).
+// multiply phase (multiply 2.3 -> 4.4 k cycles: 16->16 200 -> 214 us); three tap groups of nine taps — twelve waves, three per SIMD at
+// 144 registers, rotated S L M / M S L / S M L so that exactly one wave of a SIMD multiplies at any time — 16->16 @96^3 166.1 vs 166.4
+// us, 48->16 474 vs 488: a third wave per SIMD does not shorten the phase either.  What the stamps suggest instead: a wave's split +
+// store takes 2.1 k cycles beside its partner's MFMAs and 1.1-1.6 k beside its loads — VALU and MFMA instructions of a SIMD's waves
+// share one issue pipe, so the ~200 VALU instructions per wave and tile (two thirds of them the operand split) are paid on top of the
+// 81 MFMAs, not beside them.  Fewer VALU instructions per staged value (planes written by the producer) is the lever, not the schedule.
 #if defined(WGTR_DEBUG)
 // waves 0 and 4 of workgroup 0 (one SIMD: the S -> M and the M -> S wave of k-group 0) record s_memtime at the boundaries of phases
 // 4..7; read back with icl_debug_wgtr_stamps
