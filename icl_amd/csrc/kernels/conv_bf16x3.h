@@ -176,6 +176,23 @@ __device__ long long g_bf3_stamps[2 * 3 * 32];
 #define BF3_STAMP(k) ((void)0)
 #endif
 
+#if defined(BF3_PLANES_PROBE)
+// fp32 [N][C][S] -> planes [split 3][N][C / 8][S] of 8 packed bf16 (probe builds: what a producer would write)
+__global__ __launch_bounds__(256) void conv_bf16x3_split_planes_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int N, int C, long S) {
+  const long total = (long)N * (C / 8) * S;
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long pos = it % S, no = it / S;
+    const int oct = (int)(no % (C / 8)), n = (int)(no / (C / 8));
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = x[((long)n * C + oct * 8 + c) * S + pos];
+    uint4 o1, o2, o3;
+    bf3_split8(v, o1, o2, o3);
+    planes[it] = o1; planes[it + total] = o2; planes[it + 2 * total] = o3;
+  }
+}
+#endif
+
 template <int NBT, int TY, int V = 8, bool FLAT = false>
 __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {
@@ -226,14 +243,21 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
     if (BUFFER) s_rel[r] = o * 8 * (int)DHW + (pz - 1) * (int)HW + (py - 1) * g.W + (px - 1);
   }
   float xv[ROUNDS][8];
+#if defined(BF3_PLANES_PROBE)
+  // PROBE BUILD ONLY (tools/planes_probe.py; result, round 3: 16->16 @96^3 154-162 us against 161-172, 48->16 429 / 484, 32->32 @48^3
+  // 73.0 / 73.5, 48->48 @96^3 1040 / 1027 — a producer-side split is worth 0-11 % of this kernel): `x` holds the operand planes already — [split 3][sample][octet][D][H][W] of 8 packed bf16,
+  // written by conv_bf16x3_split_planes_kernel — and a staging item is three 16-byte loads and three LDS stores, no VALU split
+  uint4 xpl[ROUNDS][3];
+#endif
   // the (sample, z0, y0, x0) of a tile: five integer divisions of wave-uniform values (a reciprocal sequence on the VALU each) — once
   // per work item, not once per staging round
-  struct Origin { const float* xb; int z0, y0, x0; };
+  struct Origin { const float* xb; int z0, y0, x0, b, chunk; };
   auto origin_of = [&](int tile, int chunk) {
     const int b = tile / tiles_per, bt = tile % tiles_per;
     Origin o;
     o.x0 = (bt % g.ntx) * TC::TX, o.y0 = ((bt / g.ntx) % g.nty) * TC::TY, o.z0 = (bt / (g.ntx * g.nty)) * TC::TZ;
     o.xb = x + (long)b * g.x_bstride + (long)chunk * 16 * DHW;
+    o.b = b; o.chunk = chunk;
     return o;
   };
   auto load_x_at = [&](const Origin& o, int r0, int r1) {
@@ -246,6 +270,19 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       const bool ok = (s_zyx[r] >= 0) & ((unsigned)gz < (unsigned)g.D) & ((unsigned)gy < (unsigned)g.H) & ((unsigned)gx < (unsigned)g.W);
       // 32-bit lane offset against a wave-uniform channel base (16 channels x D*H*W < 2^31 elements, checked by the launcher)
       const int off = ok ? s_ch[r] * (int)DHW + gz * (int)HW + gy * g.W + gx : 0;
+#if defined(BF3_PLANES_PROBE)
+      if (BUFFER) {
+        // o.xb was computed for fp32 planes: recover (sample, chunk) from it
+        const int bb = o.b, ch = o.chunk;
+        const int oct = s_ch[r] >> 3, nb = g.ntiles / (g.ntz * g.nty * g.ntx);
+        const icl_rsrc_t pr = icl_make_rsrc(x, (unsigned)((long)3 * nb * (g.Cin / 8) * DHW * 16));
+        const long plane = (long)nb * (g.Cin / 8) * DHW;
+        const long pos = ((long)bb * (g.Cin / 8) + ch * 2 + oct) * DHW + (long)gz * HW + (long)gy * g.W + gx;
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) xpl[r][sp] = icl_buffer_load_u32x4(pr, ok ? (unsigned)((pos + sp * plane) * 16) : 0x80000000u);
+        continue;
+      }
+#endif
       if (BUFFER) {
         const icl_rsrc_t xr = icl_make_rsrc(xb, (unsigned)(16 * DHW * 4));
         // lane part: the tile-invariant offset of the lane's halo position and channel octet (s_rel) + the tile's origin; the
@@ -284,6 +321,14 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
     for (int r = 0; r < ROUNDS; ++r) {
       if (s_zyx[r] < 0) continue;
       uint4* d = Xs + s_dst[r];
+#if defined(BF3_PLANES_PROBE)
+      if (BUFFER) {
+        d[0] = xpl[r][0];
+        d[2 * NPOSP] = xpl[r][1];
+        d[4 * NPOSP] = xpl[r][2];
+        continue;
+      }
+#endif
       if (!EARLY) {
         uint4 o1, o2, o3;
         bf3_split8(xv[r], o1, o2, o3);
@@ -364,7 +409,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   }
   bool first_item = true;
   int item_no = -1;
-  Origin nxt = {x, 0, 0, 0};
+  Origin nxt = {x, 0, 0, 0, 0, 0};
   while (tile < g.ntiles) {
     int ntile = tile, nchunk = chunk + 1;
     if (nchunk == g.nchunks) { nchunk = 0; ntile = next_tile(tile); }
