@@ -1,6 +1,5 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
-for cfg in "ICL_ALIGNER_LANES=3" "ICL_ALIGNER_LANES=4 ICL_ALIGNER_GUIDED_MAP=1,2,4" "ICL_ALIGNER_LANES=4 ICL_ALIGNER_GUIDED_MAP=1,1,4 ICL_ALIGNER_OWN_MAP=2,2,3" "ICL_ALIGNER_LANES=3 ICL_ALIGNER_GUIDED_MAP=1,1,2 ICL_ALIGNER_OWN_MAP=1,1,3" "ICL_ALIGNER_LANES=3 ICL_ALIGNER_GUIDED_MAP=2,1,3 ICL_ALIGNER_OWN_MAP=1,2,3" "ICL_ALIGNER_LANES=3"; do
-  echo "== $cfg"
-  env $cfg python3 bench.py --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 20 2>&1 | tail -1 | cut -c140-170
-done
+python -m pytest tests -q -x -m gpu > $O/r3n_tests.log 2>&1
+grep -n 'passed\|failed\|Error\|error' $O/r3n_tests.log | head -20
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
