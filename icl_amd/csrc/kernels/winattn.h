@@ -238,6 +238,105 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_fwd_kernel(const float
   }
 }
 
+// Forward with an ONLINE softmax over chunks of four key blocks (round 3): the wave keeps 16 score registers
+// instead of 4 * NKB (88 for 343 tokens), so the kernel needs ~100 registers instead of 218 and FOUR waves per SIMD (two workgroups per
+// CU, which the 58 KB of LDS always allowed) hide the exp / LDS latencies that two could not.  Per chunk: scores (16 MFMAs), chunk row
+// maximum (two lane-group shuffles), rescale of the running sum and of the O accumulators by exp(m_old - m_new) — O rows are queries
+// 4 lg + r, the factor of query q lives in the lanes with lr = q: four shuffles —, P V (16 MFMAs).  Same outputs as
+// window_attn_fwd_kernel (out, lse = m + log l).
+template <int DH>
+__global__ __launch_bounds__(kWaThreads, 2) void window_attn_fwd_online_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                                               const int* __restrict__ regions, float* __restrict__ out,
+                                                                               float* __restrict__ lse, WinAttnGeom g) {
+  constexpr int LD = WaCfg<DH>::LD, DT = WaCfg<DH>::DT, CH = 4;
+  ICL_DYN_LDS(float, lds);
+  float* Ks = lds;
+  float* Vs = Ks + g.npad * LD;
+  int* rid = reinterpret_cast<int*>(Vs + g.npad * LD);
+  const int b_ = blockIdx.x / g.heads, h = blockIdx.x % g.heads;
+  const int C = g.heads * DH, nkb = g.npad / 16;
+  const long rs = 3L * C;
+  const float* base = qkv + (long)b_ * g.n * rs + h * DH;
+  wa_stage_rows<DH>(Ks, base + C, rs, g.n, g.npad, 1.f);
+  wa_stage_rows<DH>(Vs, base + 2 * C, rs, g.n, g.npad, 1.f);
+  __shared__ int mixed;
+  if (threadIdx.x == 0) mixed = 0;
+  __syncthreads();
+  wa_stage_regions(rid, &mixed, regions, (long)(b_ % g.nW) * g.n, g.n, g.npad);
+  __syncthreads();
+  const bool masked = regions != nullptr && mixed != 0;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  for (int qb = wid; qb < nkb; qb += kWaWaves) {
+    const int query = qb * 16 + lr, qc = query < g.n ? query : g.n - 1;
+    WaFrag<DH> qf;
+    qf.load(base + (long)qc * rs, lg, g.scale);
+    const int rq = rid[qc];
+    const float* brow = bias + ((long)h * g.n + qc) * g.npad;
+    float m = -3.0e38f, l = 0.f;
+    f32x4 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < nkb; c0 += CH) {
+      f32x4 s[CH];
+      float mc = -3.0e38f;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        if (c0 + k < nkb) {
+          s[k] = wa_scores_t<DH>(Ks, c0 + k, lr, lg, qf, brow, rid, rq, masked);
+          mc = fmaxf(mc, fmaxf(fmaxf(s[k][0], s[k][1]), fmaxf(s[k][2], s[k][3])));
+        }
+      }
+      mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
+      mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+      const float mn = fmaxf(m, mc);
+      const float alpha = wa_exp(m - mn);                 // 0 on the first chunk (m = -3e38), 1 when the maximum did not move
+      l *= alpha;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        if (c0 + k < nkb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = wa_exp(s[k][r] - mn);
+            s[k][r] = pv;
+            l += pv;
+          }
+        }
+      }
+      // O row 4 lg + r belongs to query 4 lg + r: its factor sits in the lanes with lr = 4 lg + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ar = __shfl(alpha, lg * 4 + r, 64);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) o[t][r] *= ar;
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        if (c0 + k < nkb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+              o[t] = icl_mfma_16x16x4(s[k][r], Vs[((c0 + k) * 16 + lg * 4 + r) * LD + t * 16 + lr], o[t]);
+        }
+      }
+      m = mn;
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (lg == 0 && query < g.n) lse[((long)b_ * g.heads + h) * g.n + query] = m + logf(l);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = qb * 16 + lg * 4 + r;
+      const float iv = __shfl(inv, lg * 4 + r, 64);
+      if (q < g.n) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) out[((long)b_ * g.n + q) * C + h * DH + t * 16 + lr] = o[t][r] * iv;
+      }
+    }
+  }
+}
+
 // dK and dV.  grid = B_ * heads; LDS = (2 * npad * (DH + 4) + 3 * npad) * 4 bytes (scale*Q, dO, log-sum-exp, delta, region ids of
 // every query of the window); waves own key blocks, their K / V rows come straight from HBM as MFMA operands.
 // S layout: lane -> query 4*lg + r of the block, key lr.  dqkv has the layout of qkv; only the k and v thirds are written here.

@@ -156,9 +156,13 @@ def _window_attention_torch(qkv, table, index, regions, heads, scale):
 
 @pytest.mark.parametrize("dims,shifted,batch,heads", [((14, 14, 14), True, 1, 2), ((7, 7, 7), False, 3, 1), ((6, 6, 6), False, 2, 3),
                                                      ((4, 4, 4), False, 1, 2), ((7, 14, 7), True, 2, 1)])
-def test_window_attention_kernel_fwd_bwd(dims, shifted, batch, heads):
+@pytest.mark.parametrize("online", ["0", "2"])
+def test_window_attention_kernel_fwd_bwd(monkeypatch, dims, shifted, batch, heads, online):
     """The fused MFMA kernels (csrc/kernels/winattn.h) against the torch formula: output, dqkv and the bias gradient summed
-    over all windows; n = 343 (22 key blocks, 7 padded keys), 216 and 64, with and without the shift mask."""
+    over all windows; n = 343 (22 key blocks, 7 padded keys), 216 and 64, with and without the shift mask.  online: the forward with
+    the whole score row block in registers (0) / with the online softmax over chunks of four key blocks (2 = forced: the launcher
+    only picks it for >= 512 workgroups); the backward kernels consume the log-sum-exp of either."""
+    monkeypatch.setenv("ICL_WINATTN_ONLINE", online)
     ws, ss = SW.get_window_size(dims, (7, 7, 7), (3, 3, 3))
     n = ws[0] * ws[1] * ws[2]
     nw = (dims[0] // ws[0]) * (dims[1] // ws[1]) * (dims[2] // ws[2])
