@@ -115,6 +115,21 @@ __device__ __forceinline__ f32x4 wa_scores_t(const float* Ks, int kb, int lr, in
   return acc;
 }
 
+// ... with the bias quad of the key block already in registers (fetched one key block ahead by the caller)
+template <int DH>
+__device__ __forceinline__ f32x4 wa_scores_t_b(const float* Ks, int kb, int lr, int lg, const WaFrag<DH>& qf, float4 b4, const int* rid,
+                                               int rq, bool masked) {
+  WaFrag<DH> kf;
+  kf.load(Ks + (kb * 16 + lr) * WaCfg<DH>::LD, lg);
+  f32x4 acc = wa_dot<DH>(kf, qf, f32x4{b4.x, b4.y, b4.z, b4.w});
+  if (masked) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (rid[kb * 16 + lg * 4 + r] != rq) acc[r] += kWaMaskAdd;
+  }
+  return acc;
+}
+
 // bias[h][i][j] = table[index[i * idx_stride + j]][h] for j < n, kWaPad for n <= j < npad
 // (relative_position_bias_table[relative_position_index[:n, :n]], swinunetr_icl.py:733-737; idx_stride = 343).
 __global__ __launch_bounds__(256) void relpos_bias_gather_kernel(const float* __restrict__ table, const long* __restrict__ index,
@@ -276,13 +291,24 @@ __global__ __launch_bounds__(kWaThreads, 2) void window_attn_fwd_online_kernel(c
     f32x4 o[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias quads of a chunk are fetched (from L2) one chunk ahead
+    float4 bq[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) bq[k] = *reinterpret_cast<const float4*>(brow + (k < nkb ? k : 0) * 16 + lg * 4);
     for (int c0 = 0; c0 < nkb; c0 += CH) {
       f32x4 s[CH];
+      float4 bc[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        bc[k] = bq[k];
+        const int nk = c0 + CH + k;
+        bq[k] = *reinterpret_cast<const float4*>(brow + (nk < nkb ? nk : 0) * 16 + lg * 4);
+      }
       float mc = -3.0e38f;
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         if (c0 + k < nkb) {
-          s[k] = wa_scores_t<DH>(Ks, c0 + k, lr, lg, qf, brow, rid, rq, masked);
+          s[k] = wa_scores_t_b<DH>(Ks, c0 + k, lr, lg, qf, bc[k], rid, rq, masked);
           mc = fmaxf(mc, fmaxf(fmaxf(s[k][0], s[k][1]), fmaxf(s[k][2], s[k][3])));
         }
       }
@@ -392,17 +418,32 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_kv_kernel(const fl
     f32x4 dk[DT], dv[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) { dk[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // the four bias values of a query block (rows 4 lg + r, column `key`) come from L2: fetched one query block ahead, and they
+    // enter as the accumulator of the score MFMAs (round 3: they were loaded inside the dependent chain load -> add -> exp)
+    const float* bcol = bias + (long)h * g.n * np + key;
+    auto load_bias = [&](int qb) {
+      f32x4 b;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = qb * 16 + lg * 4 + r, qc = q < g.n ? q : g.n - 1;
+        b[r] = bcol[(long)qc * np];
+      }
+      return b;
+    };
+    f32x4 bnext = load_bias(0);
 #pragma unroll 2
     for (int qb = 0; qb < nkb; ++qb) {
+      const f32x4 bcur = bnext;
+      if (qb + 1 < nkb) bnext = load_bias(qb + 1);
       WaFrag<DH> qf, gf;
       qf.load(Qs + (qb * 16 + lr) * LD, lg);
       gf.load(Gs + (qb * 16 + lr) * LD, lg);
-      const f32x4 s = wa_dot<DH>(qf, kf);
+      const f32x4 s = wa_dot<DH>(qf, kf, bcur);
       const f32x4 dp = wa_dot<DH>(gf, vf);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int q = qb * 16 + lg * 4 + r, qc = q < g.n ? q : g.n - 1;
-        float sv = s[r] + bias[((long)h * g.n + qc) * np + key];
+        float sv = s[r];
         if (masked && rid[qc] != rk) sv += kWaMaskAdd;
         const float p = wa_exp(sv - Ls[q]);
         const float ds = p * (dp[r] - Ds[q]);
@@ -481,10 +522,13 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_q_bias_kernel(cons
     f32x4 dq[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bq = *reinterpret_cast<const float4*>(brow + lg * 4);      // bias quad of key block 0; the next one is fetched under this one's work
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       if (EXACT || kb < nkb) {
-        const f32x4 s = wa_scores_t<DH>(Ks, kb, lr, lg, qf, brow, rid, rq, masked);
+        const float4 bcur = bq;
+        if (kb + 1 < NKB && (EXACT || kb + 1 < nkb)) bq = *reinterpret_cast<const float4*>(brow + (kb + 1) * 16 + lg * 4);
+        const f32x4 s = wa_scores_t_b<DH>(Ks, kb, lr, lg, qf, bcur, rid, rq, masked);
         WaFrag<DH> vf;
         vf.load(Vs + (kb * 16 + lr) * LD, lg);
         const f32x4 dp = wa_dot<DH>(vf, gf);

@@ -1,5 +1,5 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
-python -m pytest tests -q -x -m gpu -k "swin or window or Swin" > $O/r3n_tests.log 2>&1
+python -m pytest tests -q -x -m gpu > $O/r3n_tests.log 2>&1
 grep -n 'passed\|failed\|Error\|error' $O/r3n_tests.log | head -20
-for V in 1 0 1 0; do echo swin ONLINE=$V; ICL_WINATTN_ONLINE=$V python3 bench.py --model swinunetr_icl --no-cpu-baseline --no-exact-compare --no-kernel-timer --steps 10 2>&1 | tail -1 | cut -c140-170; done
+for i in 1 2; do python3 bench.py --model swinunetr_icl --no-cpu-baseline --no-exact-compare --no-kernel-timer --steps 10 2>&1 | tail -1 | cut -c140-170; done
