@@ -1,4 +1,11 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
-for V in 0 64 32 16 0 32; do echo swin SPLIT_MAX=$V; ICL_GEMM_SPLIT_MAX=$V python3 bench.py --model swinunetr_icl --no-cpu-baseline --no-exact-compare --no-kernel-timer --steps 10 2>&1 | tail -1 | cut -c140-170; done
-for V in 0 32; do echo unet SPLIT_MAX=$V; ICL_GEMM_SPLIT_MAX=$V python3 bench.py --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 20 2>&1 | tail -1 | cut -c140-170; done
+B="python3 bench.py --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 20"
+run() { echo "$1"; env $1 $B 2>&1 | tail -1 | cut -c140-170; }
+run "X=0"
+run "HIP_FORCE_DEV_KERNARG=1"
+run "HIP_FORCE_DEV_KERNARG=0"
+run "HSA_ENABLE_INTERRUPT=0"
+run "X=0"
+run "HIP_FORCE_DEV_KERNARG=1"
+run "HSA_ENABLE_INTERRUPT=0"
