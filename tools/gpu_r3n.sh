@@ -1,6 +1,10 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
-python3 -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -2
-python -m pytest tests -q -x -m gpu > $O/r3n_tests.log 2>&1
-grep -n 'passed\|failed\|Error\|error' $O/r3n_tests.log | head -5
-python3 bench.py 2>/dev/null | tail -1 | cut -c1-250
+B="python3 bench.py --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 20"
+run() { echo "$1"; env $1 $B 2>&1 | tail -1 | cut -c140-170; }
+run "X=0"
+run "ICL_STREAM_DEPTH=6"
+run "ICL_STREAM_MAXLEN=1024"
+run "ICL_STREAM_MAXLEN=2048"
+run "X=0"
+run "ICL_STREAM_DEPTH=6"
