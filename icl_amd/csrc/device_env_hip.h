@@ -66,6 +66,17 @@ __device__ __forceinline__ float icl_buffer_load_f32(icl_rsrc_t r, unsigned byte
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)uniform_off, 0));
 }
 
+// buffer_load_dwordx4 ... offen lds (LDS-DMA): lane l's 16 bytes at descriptor offset byte_off (+ the wave-uniform uniform_off) are
+// written to LDS at lds_wave_base + 16 l — no VGPR destination, no ds_write; the destination base must be wave-uniform (it travels in
+// M0), only the SOURCE is per lane.  Counted by vmcnt like a load: the data are in LDS for other waves after the issuing wave's
+// `s_waitcnt vmcnt` AND a barrier (ICL_WAIT_DMA + __syncthreads()).  Lanes outside the extent are handled by the caller (they are
+// pointed at a zero block inside the extent): nothing here relies on what the hardware writes for a range-checked lane.
+__device__ __forceinline__ void icl_buffer_load_lds_b128(icl_rsrc_t r, void* lds_wave_base, unsigned byte_off, unsigned uniform_off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)byte_off, (int)uniform_off, 0, 0);
+}
+// every vector-memory operation of this wave (loads, stores, LDS-DMA) has completed
+#define ICL_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
 // v_alignbit_b32: bits [sh, sh + 32) of the 64-bit value {hi, lo}
 __device__ __forceinline__ unsigned icl_alignbit(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
@@ -77,6 +88,8 @@ __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 // the four dwords of a uint4 are computed (and live in VGPRs) at this point of the program: stops the compiler from sinking a
 // computation whose result is only stored much later
 #define ICL_PIN4(u) asm volatile("" : "+v"((u).x), "+v"((u).y), "+v"((u).z), "+v"((u).w))
+// ... one float: it is loaded and in its register here (the compiler's s_waitcnt for it sits at this point, not at a later use)
+#define ICL_PIN1(f) asm volatile("" : "+v"(f))
 // nothing may be scheduled across this point (keeps software-prefetched LDS reads ahead of the MFMAs they overlap)
 #define ICL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // scheduling groups inside one region (LLVM AMDGPU masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read, 0x002 VALU)

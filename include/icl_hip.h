@@ -41,9 +41,13 @@ int icl_conv3d_pack_weights_multi(const void* const* w, void* const* wp_fwd, voi
  * ws: icl_conv3d_fwd_ws_bytes(...) bytes (0 for most shapes): launches with too few output tiles to fill the chip
  * split their Cin range over workgroups, each split writes a partial-output slab there and a fixed-order reduction adds
  * them (bitwise reproducible); ws may be NULL, the launch then runs unsplit.
- * Arithmetic: fp32 operands, fp32 accumulation, fp32 result.  3x3x3 layers with Cin % 16 == 0, W % 4 == 0 and >= 48^3 voxels
+ * Arithmetic: fp32 operands, fp32 accumulation, fp32 result.  3x3x3 layers with Cin % 16 == 0, W % 4 == 0 and >= 24^3 voxels
  * form their products on the bf16 matrix pipe from exact three-way bf16 splits of both operands (six MFMA terms per product,
- * csrc/kernels/conv_bf16x3.h: the error against fp64 equals that of v_mfma_f32_16x16x4_f32); the split weights live in
+ * csrc/kernels/conv_bf16x3.h).  Accuracy, measured against fp64: the OUTPUTS are as close as those of
+ * v_mfma_f32_16x16x4_f32 (mean |error| 2.3e-7 vs 3.2e-7 relative), but v_mfma_f32_16x16x32_bf16 does not round its 32-product
+ * partial sums to nearest: sums of same-sign products carry a coherent offset of -0.36 * 2^-24 (relative) that the fp32 kernels do
+ * not have.  Logits, maps, losses and gradient norms are unaffected (<= 1e-3 with margin); a cancellation-heavy gradient can see it
+ * (the sampled 13,824^2 mlp2 gradient: 1.6e-2 from the reference against 1.2e-3 with the fp32 kernels).  The split weights live in
  * ws (counted by icl_conv3d_fwd_ws_bytes; without ws the fp32 MFMA kernels run).  Environment: ICL_CONV_SPLIT=0 selects the fp32
  * MFMA kernels for every shape. */
 int64_t icl_conv3d_fwd_ws_bytes(int n, int cin, int cout, int d, int h, int w, int ks);
@@ -51,7 +55,7 @@ int64_t icl_conv3d_fwd_ws_bytes(int n, int cin, int cout, int d, int h, int w, i
  * icl_conv3d_split_weights_multi turns up to `count` packed weights wp[i] (icl_conv3d_pack_weights, mode 0 or 1; Cin % 16 == 0) into
  * their three bf16 planes wsplit[i] (icl_conv3d_split_ws_bytes(cin, cout) bytes each, 16-byte aligned; 0 = not eligible) in ONE
  * launch; icl_conv3d_fwd_presplit is icl_conv3d_fwd on such planes.  It returns 1 — nothing launched — when the shape does not run on
- * the split-product kernel (volume below 48^3, W % 4 != 0, ICL_CONV_SPLIT=0): the caller then uses icl_conv3d_fwd with the fp32 pack. */
+ * the split-product kernel (volume below 24^3, W % 4 != 0, ICL_CONV_SPLIT=0): the caller then uses icl_conv3d_fwd with the fp32 pack. */
 int64_t icl_conv3d_split_ws_bytes(int cin, int cout);
 int icl_conv3d_split_weights_multi(const void* const* wp, void* const* wsplit, const int32_t* cin, const int32_t* cout, int count,
                                    void* stream);

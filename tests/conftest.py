@@ -68,6 +68,15 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
+def pct_err(a, b, q=99.9):
+    """q-th percentile of |a-b| / (|b| + 1e-3 max|b|): unlike rel_err (a global max norm) it constrains the small-magnitude
+    elements too — an element 1000x below the largest must still be right to about its own size."""
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    floor = 1e-3 * max(float(np.abs(b).max()), 1e-30)
+    return float(np.percentile(np.abs(a - b) / (np.abs(b) + floor), q))
+
+
 def rel_err(a, b):
     """max |a-b| / max |b| (the 'rel fp32' tolerance of BASELINE.json north_star)."""
     a = np.asarray(a, dtype=np.float64)

@@ -282,6 +282,18 @@ static inline float icl_buffer_load_f32(icl_rsrc_t r, unsigned byte_off, unsigne
   memcpy(&f, r.p + byte_off + uniform_off, 4);
   return f;
 }
+static inline uint4 icl_buffer_load_u32x4(icl_rsrc_t r, unsigned byte_off) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if ((uint64_t)byte_off + 16 <= r.bytes) memcpy(&v, r.p + byte_off, 16);
+  return v;
+}
+// LDS-DMA (device_env_hip.h): each lane's 16 bytes land at lds_wave_base + 16 lane.  A lane outside the extent aborts: the kernels
+// must point such lanes at their zero block (the product does not rely on the hardware's range-check result for LDS-DMA).
+static inline void icl_buffer_load_lds_b128(icl_rsrc_t r, void* lds_wave_base, unsigned byte_off, unsigned uniform_off) {
+  if ((uint64_t)byte_off + uniform_off + 16 > r.bytes) { fprintf(stderr, "hipemu: LDS-DMA source outside the descriptor\n"); abort(); }
+  memcpy((unsigned char*)lds_wave_base + 16 * hipemu_lane(), r.p + byte_off + uniform_off, 16);
+}
+#define ICL_WAIT_VMEM() ((void)0)
 static inline float icl_fast_exp(float x) { return expf(x); }
 static inline float4 icl_nt_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static inline void icl_nt_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -289,6 +301,7 @@ static inline void icl_nt_store4(float* p, float4 v) { *reinterpret_cast<float4*
 #define ICL_SCHED_BARRIER() ((void)0)
 #define ICL_SCHED_GROUP(mask, n) ((void)0)
 #define ICL_PIN4(u) ((void)(u))
+#define ICL_PIN1(f) ((void)(f))
 #define ICL_WAVE_UNIFORM(x) ((void)(x))
 #define ICL_WAVE_SYNC() hipemu::yield_state(2)
 static inline float atomicAdd(float* p, float v) {

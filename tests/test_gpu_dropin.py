@@ -82,7 +82,12 @@ def _check_step(model, g, losses_got, grads, elementwise, norm_skip=lambda k: Fa
     assert not off, off[:8]
 
 
-def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root):
+# (convolution path, band of the sampled mlp2 gradient): the two paths are asserted SEPARATELY so that neither can regress behind the
+# other's band — exact-fp32 MFMA convolutions measure 1.2e-3 (band 3e-3 = 2x the 1.5e-3 an input perturbation of 1e-7 moves the sample),
+# split products 1.6e-2 (band 3e-2).
+@pytest.mark.parametrize("conv_split,mlp2_band", [("1", 3e-2), ("0", 3e-3)])
+def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root, monkeypatch, conv_split, mlp2_band):
+    monkeypatch.setenv("ICL_CONV_SPLIT", conv_split)
     from networks.net_factory_3d import net_factory_3d
     g = load_golden("model_unet3d_icl_nc2.npz")
     model = net_factory_3d(net_type="unet_3D_icl", in_chns=1, class_num=2)
@@ -104,7 +109,7 @@ def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root):
         # convolutions 1.6e-2 — their products are closer to exact than an fp32 multiply, but v_mfma_f32_16x16x32_bf16 does not round
         # its 32-product sums to nearest (-0.36 * 2^-24 coherent offset, test_split_bf16_convolution_all_positive_sums_carry_no_bias),
         # and this cancellation-heavy gradient sees it.  Losses, maps, gradient norms and the other tensors are unchanged.
-        ("sspa.class_decoders.2.mlp2.fc1.weight", lambda t: t[::432, ::432], 3e-2),
+        ("sspa.class_decoders.2.mlp2.fc1.weight", lambda t: t[::432, ::432], mlp2_band),
         ("center.conv2.0.weight", lambda t: t[::16, ::16], 2e-2),
     ]
     # conv biases in front of an InstanceNorm and attn_convs1 biases in front of the class softmax: the true gradient is exactly 0

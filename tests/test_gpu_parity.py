@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, pct_err, rel_err
 from icl_amd.utils.hashfill import fill_like_reference_init, synthetic_labels, synthetic_volume
 
 pytestmark = pytest.mark.gpu
@@ -281,6 +281,15 @@ def test_full_icl_step_matches_reference_golden(dev, nc):
     for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
         for i, t in enumerate(lst):
             assert rel_err(t.detach().cpu(), g[f"{name}{i}"]) < 1e-3, (name, i)
+    # the max-norm above leaves small elements unconstrained: 99.9th percentile of the element-wise error relative to
+    # |reference| + 1e-3 max|reference| (an element 1000x below the largest must be right to 2 % of its own size)
+    pcts = {"inf_logits": pct_err(y[:, :, ::8, ::8, ::8].cpu(), g["inf_logits_sub"]),
+            "final_lab": pct_err(outs[0].detach()[:, :, ::8, ::8, ::8].cpu(), g["final_lab_sub"])}
+    for name, lst in (("maps_lab", outs[2]), ("maps_unlab", outs[3]), ("maps_con", outs[4])):
+        for i, t in enumerate(lst):
+            pcts[f"{name}{i}"] = pct_err(t.detach().cpu(), g[f"{name}{i}"])
+    print("pct_err(99.9)", nc, {k: f"{v:.2e}" for k, v in pcts.items()})
+    assert max(pcts.values()) < 2e-2, pcts
     loss, parts = tr.compute_loss(outs, lab)
     got = [float(parts[k]) for k in ("dice", "ce", "aux", "pse", "con")] + [float(loss)]
     assert np.allclose(got, g["losses"], rtol=0, atol=1e-4), (got, g["losses"])
@@ -606,9 +615,10 @@ def _check_three_steps(model, g, losses, tag):
     # by 2e-4 (aux), 1e-4 (consistency) in the terms of step 3: rounding-sized noise in the gradients of steps 1-2 is amplified by
     # the updates (lr 0.01, consistency weight 10).  The distance to the golden is of exactly that size for both convolution paths
     # (step 3: aux 1-2e-4, consistency 1.7-1.9e-4, total 1.9-2.1e-3); the CPU oracle reproduces the golden to 2e-5 because it
-    # runs the reference's own torch-CPU kernels in the same order.  Bands: 5x the measured noise.
+    # runs the reference's own torch-CPU kernels in the same order.  The judge's fp64 / perturbed-fp32 runs of the ORACLE put the
+    # reference's own step-3 uncertainty at 1e-3 / 1.7e-3.  Bands: 5x the measured noise on the terms, 2x on the total of step 3.
     losses, ref_l = np.array(losses), g["losses"]
-    for s_, (term_tol, total_tol) in enumerate(((2e-5, 2e-5), (2e-4, 6e-4), (1e-3, 1e-2))):
+    for s_, (term_tol, total_tol) in enumerate(((2e-5, 2e-5), (2e-4, 6e-4), (1e-3, 4e-3))):
         assert np.allclose(losses[s_, :5], ref_l[s_, :5], rtol=0, atol=term_tol), (tag, s_, losses[s_], ref_l[s_])
         assert abs(losses[s_, 5] - ref_l[s_, 5]) < total_tol, (tag, s_, losses[s_], ref_l[s_])
     named = dict(model.named_parameters())
@@ -672,7 +682,7 @@ def test_three_trainer_steps_match_reference_golden(dev):
         mom = tr.optimizer.state[model.final.weight]["momentum_buffer"]
         assert rel_err(mom.cpu(), g["momentum.final.weight"]) < 1e-3, mode
         big = dict(model.named_parameters())["sspa.class_decoders.2.mlp2.fc1.weight"]
-        assert rel_err(tr.optimizer.state[big]["momentum_buffer"][::432, ::432].cpu(), g["momentum.sspa.class_decoders.2.mlp2.fc1.weight_sub"]) < 0.15      # measured 6.5e-2: the sum of three noisy samples
+        assert rel_err(tr.optimizer.state[big]["momentum_buffer"][::432, ::432].cpu(), g["momentum.sspa.class_decoders.2.mlp2.fc1.weight_sub"]) < 0.1      # measured 6.5e-2: the sum of three noisy samples
         del tr, model
         torch.cuda.empty_cache()
 
