@@ -30,6 +30,7 @@ struct Bf3PGeom {
   long ppitch;                // planes_pitch(D*H*W), uint4 units
   long p_bstride;             // uint4 units between samples of the planes tensor (all chunks of the buffer x 6 x ppitch)
   long y_bstride;
+  int dbg;                    // timing ablations (probe builds; results are wrong when set): 1 no halo DMA after the first item, 2 no output stores
 };
 
 // fp32 [N][C][S] (sample stride x_bstride) -> planes of chunks chunk0 .. of a planes tensor with p_bstride uint4 per sample.
@@ -55,21 +56,58 @@ __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __res
   }
 }
 
-template <int NBT, bool FLAT = false>
-__global__ __launch_bounds__(512) void conv3d_planes_fwd_kernel(const uint4* __restrict__ planes, const uint4* __restrict__ wsplit,
-                                                                const float* __restrict__ bias, float* __restrict__ y, Bf3PGeom g) {
-  typedef typename std::conditional<FLAT, Bf3F24, Bf3T<8>>::type TC;
-  constexpr int MB = FLAT ? 3 : 4;                      // row blocks per wave
-  constexpr bool WHOLE = NBT == 1, PIPE_B2 = NBT < 3;
-  constexpr int WPL = WHOLE ? 3 : 1;                    // weight planes resident together
-  constexpr int NB = 16 * NBT, PX = TC::PX, PY = TC::PY, NT = 512;
-  constexpr int NPOSP = 1088, NBLK = NPOSP / 64;        // LDS plane pitch: 17 DMA blocks of 64 positions (both tile shapes)
-  static_assert(TC::NPOS + 1 <= NPOSP && TC::NPOS > 16 * 64, "halo positions + the zero slot's over-read fit 17 blocks");
-  constexpr int WITEMS = WPL * 6 * Bf3::SLOTS * NB, WU = (WITEMS + NT - 1) / NT;
+// Configurations (NBT cout blocks of 16, TY rows of y per tile, NWV waves, DBUF):
+//   <1, 8, 8, false>  one workgroup per CU, 4 x 8 x 16 tile, the three weight planes of a chunk resident (by DMA): the halo DMA of the
+//                     next item is issued behind the multiply phase and lands beside the epilogue only — measured 0.91-0.97x of the
+//                     shipped kernel on the 96^3 layers (profiles/r4_planes_dma_v1_probe.txt): the landing time is exposed.
+//   <1, 4, 4, false>  4 x 4 x 16 tile, four waves, 77 KB: TWO workgroups per CU — while one waits for its halo tile the other multiplies.
+//   <2, 4, 8, true>   4 x 4 x 16 tile, eight waves of two row blocks, the halo tile DOUBLE-buffered (2 x 62 KB + one 30 KB weight plane):
+//                     the DMA of item i + 1 is issued at the top of item i.
+//   <2|3, 8, 8, false> as the shipped kernel with the halo by DMA (weights one dz plane at a time through registers).
+// FLAT: the 2 x 8 x 24 tile of the 24^3 level (eight waves of three row blocks).
+template <int NBT, int TY, int NWV, bool DBUF, bool FLAT = false>
+struct PlanesCfg {
+  typedef typename std::conditional<FLAT, Bf3F24, Bf3T<TY>>::type TC;
+  static constexpr int MB = FLAT ? 3 : 4 * TY / NWV;                    // row blocks of 16 outputs per wave
+  static constexpr int NT = 64 * NWV;
+  static constexpr bool WHOLE = NBT == 1 && TY == 8 && !DBUF && !FLAT;  // three weight planes resident, filled by DMA
+  static constexpr int NPOSP = (TC::NPOS + 1 + 15) / 16 * 16;           // LDS plane pitch (a multiple of 16: the halves stay 256 B-aligned apart)
+  static constexpr int NBLK = (NPOSP + 63) / 64;                        // DMA blocks of 64 positions per plane (the last one may be partial)
+  static constexpr int KT = (NBLK + NWV - 1) / NWV;                     // position blocks per wave
+  static constexpr int XBUF = 6 * NPOSP;                                // uint4 per halo buffer
+  static constexpr int WPL = WHOLE ? 3 : 1;
+  static constexpr int WS_U4 = WPL * 6 * Bf3::SLOTS * 16 * NBT;
+  static constexpr size_t LDS_BYTES = (size_t)((DBUF ? 2 : 1) * XBUF + WS_U4) * 16;
+  static_assert(MB * NWV * 16 == TC::TZ * TC::TY * TC::TX, "the waves cover the tile");
+};
+
+#if defined(PLANES_STAMPS)
+// in-kernel stamps (probe builds): waves 0 and NWV / 2 of workgroup 0 record s_memtime at the phase boundaries of work items 2..4
+__device__ long long g_planes_stamps[2 * 3 * 16];
+#define PL_STAMP(k)                                                                                                   \
+  do {                                                                                                                \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (wid == 0 || wid == NWV / 2) && lane == 0 && item_no >= 2 && item_no < 5) \
+      g_planes_stamps[((wid ? 1 : 0) * 3 + item_no - 2) * 16 + (k)] = clock64();                                      \
+  } while (0)
+#else
+#define PL_STAMP(k) ((void)0)
+#endif
+
+template <int NBT, int TY, int NWV, bool DBUF, bool FLAT = false>
+__global__ __launch_bounds__(64 * NWV) void conv3d_planes_fwd_kernel(const uint4* __restrict__ planes, const uint4* __restrict__ wsplit,
+                                                                     const float* __restrict__ bias, float* __restrict__ y, Bf3PGeom g) {
+  typedef PlanesCfg<NBT, TY, NWV, DBUF, FLAT> C;
+  typedef typename C::TC TC;
+  constexpr int MB = C::MB, NT = C::NT, NPOSP = C::NPOSP, NBLK = C::NBLK, KT = C::KT, XBUF = C::XBUF;
+  constexpr bool WHOLE = C::WHOLE, PIPE_B2 = NBT < 3;
+  constexpr int NB = 16 * NBT, PX = TC::PX, PY = TC::PY;
+  constexpr int WITEMS = C::WS_U4, WU = (WITEMS + NT - 1) / NT;
   static_assert(!WHOLE || WITEMS % 64 == 0, "whole DMA blocks");
+  // the ragged last round of position blocks (block NBLK - 1 alone): dealt over the waves by plane instead of all six to wave 0
+  constexpr bool LAST_BY_PLANE = NBLK - NWV * (KT - 1) == 1 && NWV >= 6;
   ICL_DYN_LDS(uint4, lds);
   uint4* Xs = lds;
-  uint4* Ws = lds + 6 * NPOSP;
+  uint4* Ws = lds + (DBUF ? 2 : 1) * XBUF;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   int wid = tid >> 6;
   ICL_WAVE_UNIFORM(wid);
@@ -79,44 +117,49 @@ __global__ __launch_bounds__(512) void conv3d_planes_fwd_kernel(const uint4* __r
   const long DHW = (long)g.D * HW;
   const int tiles_per = g.ntz * g.nty * g.ntx;
 
-  // ---- halo DMA: wave w moves the position blocks w, w + 8 of all six planes and (waves 0..5) block 16 of plane w.  Tile-invariant
-  // part of a lane's source offset: its halo position relative to the tile origin
-  int t_rel[3], t_zyx[3];
+  // ---- halo DMA: wave w moves the position blocks w, w + NWV, .. of all six planes.  Tile-invariant part of a lane's source offset:
+  // its halo position relative to the tile origin; t_zyx < 0: a pad position of the LDS image (reads the plane's zero positions),
+  // t_zyx == -2: beyond the image (the lane takes no part: a partial last block)
+  int t_rel[KT], t_zyx[KT];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int pos = (k < 2 ? wid + 8 * k : NBLK - 1) * 64 + lane;
+  for (int k = 0; k < KT; ++k) {
+    const int pbk = (LAST_BY_PLANE && k == KT - 1) ? NBLK - 1 : wid + NWV * k;
+    const int pos = pbk * 64 + lane;
     const int px = pos % PX, row = pos / PX, py = row % PY, pz = row / PY;
-    t_zyx[k] = pos < TC::NPOS ? (pz << 16) | (py << 8) | px : -1;
+    t_zyx[k] = pos < TC::NPOS ? (pz << 16) | (py << 8) | px : pos < NPOSP ? -1 : -2;
     t_rel[k] = (pz - 1) * HW + (py - 1) * g.W + (px - 1);
   }
-  auto issue_x = [&](int tile, int chunk) {
+  auto issue_x = [&](int tile, int chunk, uint4* dst) {
     const int b = tile / tiles_per, bt = tile % tiles_per;
     const int x0 = (bt % g.ntx) * TC::TX, y0 = ((bt / g.ntx) % g.nty) * TC::TY, z0 = (bt / (g.ntx * g.nty)) * TC::TZ;
     const icl_rsrc_t xr = icl_make_rsrc(planes + (long)b * g.p_bstride + (long)chunk * 6 * g.ppitch, (unsigned)(6 * g.ppitch * 16));
     const int toff = z0 * HW + y0 * g.W + x0;
-    unsigned vo[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int gz = z0 - 1 + (t_zyx[k] >> 16), gy = y0 - 1 + ((t_zyx[k] >> 8) & 255), gx = x0 - 1 + (t_zyx[k] & 255);
-      const bool ok = (t_zyx[k] >= 0) & ((unsigned)gz < (unsigned)g.D) & ((unsigned)gy < (unsigned)g.H) & ((unsigned)gx < (unsigned)g.W);
-      vo[k] = ok ? (unsigned)(t_rel[k] + toff) * 16u : (unsigned)DHW * 16u;      // outside: the plane's zero positions
-    }
     const unsigned pb = (unsigned)g.ppitch * 16u;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      icl_buffer_load_lds_b128(xr, Xs + q * NPOSP + wid * 64, vo[0], q * pb);
-      icl_buffer_load_lds_b128(xr, Xs + q * NPOSP + (wid + 8) * 64, vo[1], q * pb);
+    for (int k = 0; k < KT; ++k) {
+      const int gz = z0 - 1 + (t_zyx[k] >> 16), gy = y0 - 1 + ((t_zyx[k] >> 8) & 255), gx = x0 - 1 + (t_zyx[k] & 255);
+      const bool ok = (t_zyx[k] >= 0) & ((unsigned)gz < (unsigned)g.D) & ((unsigned)gy < (unsigned)g.H) & ((unsigned)gx < (unsigned)g.W);
+      const unsigned vo = ok ? (unsigned)(t_rel[k] + toff) * 16u : (unsigned)DHW * 16u;      // outside: the plane's zero positions
+      if (LAST_BY_PLANE && k == KT - 1) {
+        if (wid < 6 && t_zyx[k] != -2) icl_buffer_load_lds_b128(xr, dst + wid * NPOSP + (NBLK - 1) * 64, vo, wid * pb);
+      } else if (wid + NWV * k < NBLK) {
+        const bool full = (wid + NWV * k + 1) * 64 <= NPOSP;      // wave-uniform; a partial block masks its lanes beyond the image
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          if (full) icl_buffer_load_lds_b128(xr, dst + q * NPOSP + (wid + NWV * k) * 64, vo, q * pb);
+          else if (t_zyx[k] != -2) icl_buffer_load_lds_b128(xr, dst + q * NPOSP + (wid + NWV * k) * 64, vo, q * pb);
+        }
+      }
     }
-    if (wid < 6) icl_buffer_load_lds_b128(xr, Xs + wid * NPOSP + (NBLK - 1) * 64, vo[2], wid * pb);
   };
-  // weights (already split: conv_bf16x3_split_weights_kernel).  One cout block: the three dz planes of a chunk (45 blocks of 64 slots)
-  // by DMA; more: one dz plane at a time through registers, as in conv3d_bf16x3_fwd_kernel
+  // weights (already split: conv_bf16x3_split_weights_kernel).  WHOLE: the three dz planes of a chunk (45 blocks of 64 slots) by DMA;
+  // else one dz plane at a time through registers, as in conv3d_bf16x3_fwd_kernel
   auto issue_w = [&](int chunk) {
     const uint4* src = wsplit + (long)chunk * 3 * 6 * Bf3::SLOTS * g.CoutP + n0;
     const icl_rsrc_t wr = icl_make_rsrc(src, (unsigned)((3 * 6 * Bf3::SLOTS * g.CoutP - n0) * 16));
 #pragma unroll
-    for (int i = 0; i < (WITEMS / 64 + 7) / 8; ++i) {
-      const int blk = wid + 8 * i;
+    for (int i = 0; i < (WITEMS / 64 + NWV - 1) / NWV; ++i) {
+      const int blk = wid + NWV * i;
       if (blk < WITEMS / 64) icl_buffer_load_lds_b128(wr, Ws + blk * 64, (unsigned)((blk * 4 + (lane >> 4)) * g.CoutP + (lane & 15)) * 16u, 0u);
     }
   };
@@ -138,8 +181,8 @@ __global__ __launch_bounds__(512) void conv3d_planes_fwd_kernel(const uint4* __r
     }
   };
 
-  // ---- operand bases: wave w owns the (z, y) rows 4 w .. 4 w + 3 of the tile (FLAT: row blocks 3 w .. 3 w + 2 of the flattened tile)
-  const int wz = (4 * wid) / TC::TY, wy = (4 * wid) % TC::TY;
+  // ---- operand bases: wave w owns the (z, y) rows MB w .. MB w + MB - 1 of the tile (FLAT: row blocks 3 w .. 3 w + 2 of the flattened tile)
+  const int wz = (MB * wid) / TC::TY, wy = (MB * wid) % TC::TY;
   int moff[MB];
   int lanepos;
   if (FLAT) {
@@ -157,7 +200,7 @@ __global__ __launch_bounds__(512) void conv3d_planes_fwd_kernel(const uint4* __r
 #pragma unroll
     for (int m = 0; m < MB; ++m) moff[m] = m * PX;
   }
-  const uint4* xa = Xs + half * NPOSP + lanepos;
+  const uint4* xa0 = Xs + half * NPOSP + lanepos;
   const uint4* wb = Ws + (half * Bf3::SLOTS + tp) * NB + lr;
 
   // the bias is fetched (and waited for) before the first DMA is issued: an ordinary load whose result is first used while LDS-DMA
@@ -170,10 +213,10 @@ __global__ __launch_bounds__(512) void conv3d_planes_fwd_kernel(const uint4* __r
     bv[j] = (bias && co < g.Cout) ? bias[co] : 0.f;
     ICL_PIN1(bv[j]);
   }
-  f32x4 acc[4][NBT];
-  uint4 pa1[4], pa23[4][2], pb[PIPE_B2 ? 2 : 1][3][NBT];
+  f32x4 acc[MB][NBT];
+  uint4 pa1[MB], pa23[MB][2], pb[PIPE_B2 ? 2 : 1][3][NBT];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MB; ++m)
 #pragma unroll
     for (int j = 0; j < NBT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -185,51 +228,63 @@ __global__ __launch_bounds__(512) void conv3d_planes_fwd_kernel(const uint4* __r
   if (tile >= xcd_end) tile = g.ntiles;
   if (tile < g.ntiles) {
     if (WHOLE) issue_w(0); else load_w(0, 0);
-    issue_x(tile, 0);
+    issue_x(tile, 0, Xs);
   }
-
-  auto frag_ptr = [&](int sdz, int spair) {
-    const int tA = 10 * sdz + 2 * spair, tB = tA + 1 < 27 ? tA + 1 : 26;
-    const int offA = (tA / 9) * PY * PX + ((tA / 3) % 3) * PX + tA % 3, offB = (tB / 9) * PY * PX + ((tB / 3) % 3) * PX + tB % 3;
-    return xa + (tp ? offB : offA);
-  };
-  auto load_b = [&](int buf, int sdz, int spair, int s0 = 0, int s1 = 3) {
-#pragma unroll
-    for (int s = s0; s < s1; ++s)
-#pragma unroll
-      for (int j = 0; j < NBT; ++j)
-        pb[buf][s][j] = wb[((WHOLE ? sdz * 6 : 0) * Bf3::SLOTS + s * 2 * Bf3::SLOTS + spair * 2) * NB + j * 16];
-  };
-  auto load_x1 = [&](int sdz, int spair) {
-    const uint4* xp = frag_ptr(sdz, spair);
-#pragma unroll
-    for (int m = 0; m < MB; ++m) pa1[m] = xp[moff[m]];
-  };
-  auto load_x23 = [&](int sdz, int spair) {
-    const uint4* xp = frag_ptr(sdz, spair);
-#pragma unroll
-    for (int m = 0; m < MB; ++m) pa23[m][1] = xp[4 * NPOSP + moff[m]];      // a3 first: its products lead the Y half
-#pragma unroll
-    for (int m = 0; m < MB; ++m) pa23[m][0] = xp[2 * NPOSP + moff[m]];
-  };
+  int buf = 0;                                 // DBUF: the halo buffer of the current item
+  int item_no = -1;
+  (void)item_no;
 
   while (tile < g.ntiles) {
     int ntile = tile, nchunk = chunk + 1;
     if (nchunk == g.nchunks) { nchunk = 0; ntile = next_tile(tile); }
+    ++item_no;
+    PL_STAMP(0);
+    const uint4* xa = xa0 + (DBUF && buf ? XBUF : 0);
+    auto frag_ptr = [&](int sdz, int spair) {
+      const int tA = 10 * sdz + 2 * spair, tB = tA + 1 < 27 ? tA + 1 : 26;
+      const int offA = (tA / 9) * PY * PX + ((tA / 3) % 3) * PX + tA % 3, offB = (tB / 9) * PY * PX + ((tB / 3) % 3) * PX + tB % 3;
+      return xa + (tp ? offB : offA);
+    };
+    auto load_b = [&](int bi, int sdz, int spair, int s0 = 0, int s1 = 3) {
+#pragma unroll
+      for (int s = s0; s < s1; ++s)
+#pragma unroll
+        for (int j = 0; j < NBT; ++j)
+          pb[bi][s][j] = wb[((WHOLE ? sdz * 6 : 0) * Bf3::SLOTS + s * 2 * Bf3::SLOTS + spair * 2) * NB + j * 16];
+    };
+    auto load_x1 = [&](int sdz, int spair) {
+      const uint4* xp = frag_ptr(sdz, spair);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) pa1[m] = xp[moff[m]];
+    };
+    auto load_x23 = [&](int sdz, int spair) {
+      const uint4* xp = frag_ptr(sdz, spair);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) pa23[m][1] = xp[4 * NPOSP + moff[m]];      // a3 first: its products lead the Y half
+#pragma unroll
+      for (int m = 0; m < MB; ++m) pa23[m][0] = xp[2 * NPOSP + moff[m]];
+    };
 #pragma unroll
     for (int dz = 0; dz < 3; ++dz) {
       if (WHOLE) {
         if (dz == 0) {
           ICL_WAIT_VMEM();                     // this wave's share of the halo tile (and weights) has landed ...
+          PL_STAMP(1);
           __syncthreads();                     // ... and everybody else's
+          PL_STAMP(2);
         }
       } else {
-        if (dz > 0) __syncthreads();           // the previous plane's weights are no longer read (dz = 0: the barrier that ended the last item)
+        // dz = 0: the barrier that ended the last item (!DBUF) / the one below (DBUF) has retired every read of the weight plane
+        if (dz > 0 || DBUF) __syncthreads();
         store_w();
-        if (dz == 0) ICL_WAIT_VMEM();
+        if (dz == 0) ICL_WAIT_VMEM();          // this wave's share of the halo tile has landed
+        if (dz == 0) PL_STAMP(1);
         __syncthreads();
+        if (dz == 0) PL_STAMP(2);
         if (dz < 2) load_w(chunk, dz + 1);
         else if (ntile < g.ntiles) load_w(nchunk, 0);
+        // DBUF: the other buffer was last read by the previous item, which everybody has left: fill it with the next item now
+        if (DBUF && dz == 0 && ntile < g.ntiles && !(g.dbg & 1)) issue_x(ntile, nchunk, Xs + (buf ? 0 : XBUF));
       }
       // A pair's 24 NBT products in two halves: X = the a1 terms (a1 b3, a1 b2, a1 b1), Y = (a3 b1, a2 b2, a2 b1); the LDS reads of a half
       // are issued behind the MFMAs of the half before it (conv_bf16x3.h, variant 60)
@@ -283,13 +338,18 @@ __global__ __launch_bounds__(512) void conv3d_planes_fwd_kernel(const uint4* __r
         ICL_SCHED_BARRIER();
         if (more && !PIPE_B2) load_b(0, ndz, npair);
       }
+      PL_STAMP(3 + dz);
     }
-    __syncthreads();                           // everyone has finished reading the halo tile and the weights
-    if (ntile < g.ntiles) {
-      issue_x(ntile, nchunk);                  // lands while the outputs below are written
-      if (WHOLE && g.nchunks > 1) issue_w(nchunk);
+    if (!DBUF) {
+      __syncthreads();                         // everyone has finished reading the halo tile and the weights
+      PL_STAMP(6);
+      if (ntile < g.ntiles && !(g.dbg & 1)) {
+        issue_x(ntile, nchunk, Xs);            // lands while the outputs below are written
+        if (WHOLE && g.nchunks > 1) issue_w(nchunk);
+      }
     }
-    if (chunk == g.nchunks - 1) {
+    PL_STAMP(7);
+    if (chunk == g.nchunks - 1 && !(g.dbg & 2)) {
       // ---- epilogue: lane holds x = 4 lq + r of row (wid, m), column co = n0 + 16 j + lr
       const int b = tile / tiles_per, bt = tile % tiles_per;
       const int x0 = (bt % g.ntx) * TC::TX, y0 = ((bt / g.ntx) % g.nty) * TC::TY, z0 = (bt / (g.ntx * g.nty)) * TC::TZ;
@@ -313,8 +373,10 @@ __global__ __launch_bounds__(512) void conv3d_planes_fwd_kernel(const uint4* __r
         }
       }
     }
+    PL_STAMP(8);
     tile = ntile;
     chunk = nchunk;
+    buf ^= 1;
   }
 }
 

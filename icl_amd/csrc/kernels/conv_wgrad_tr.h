@@ -140,8 +140,11 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_tr_kernel(const float* __res
     tile_origin(tile, b, x0, y0, z0);
     // buffer loads: the descriptor spans the channel planes of this block that exist in sample b, so an offset beyond them — a
     // ragged octet, or the 2^31 handed to out-of-volume and idle lanes — reads 0 in hardware: no address clamps, no selects
-    const icl_rsrc_t xr = icl_make_rsrc(x + (long)b * g.x_bstride + (long)c0 * DHW, (unsigned)((long)(g.Cin - c0) * DHW * 4));
-    const icl_rsrc_t gr = icl_make_rsrc(gy + (long)b * g.gy_bstride + (long)co0 * DHW, (unsigned)((long)(g.Cout - co0) * DHW * 4));
+    // (extents clamped to the block's own 16 / 16 NCB channel planes: with all remaining channels the byte count could pass 2^31 —
+    // the sentinel would then be IN range — or wrap at 2^32; the launcher admits D*H*W * 192 <= 2^31 only)
+    const int xch = g.Cin - c0 < 16 ? g.Cin - c0 : 16, gch = g.Cout - co0 < 16 * NCB ? g.Cout - co0 : 16 * NCB;
+    const icl_rsrc_t xr = icl_make_rsrc(x + (long)b * g.x_bstride + (long)c0 * DHW, (unsigned)((long)xch * DHW * 4));
+    const icl_rsrc_t gr = icl_make_rsrc(gy + (long)b * g.gy_bstride + (long)co0 * DHW, (unsigned)((long)gch * DHW * 4));
     const int org = (z0 - 1) * (int)HW + (y0 - 1) * g.W + x0 - 1;
 #pragma unroll
     for (int r = 0; r < C::ROUNDS; ++r) {

@@ -33,6 +33,8 @@ class FusedSGD(torch.optim.Optimizer):
             for p in group["params"]:
                 if getattr(p, "_icl_factors", None) is not None:
                     p._icl_factors = None
+        # a step that was skipped or failed after its backward pass must not make the next one raise "updated twice"
+        self._updated_in_backward.clear()
         super().zero_grad(set_to_none=set_to_none)
 
     def _step_factored(self, L, p, factors, lr, mom, wd):
@@ -91,7 +93,7 @@ class FusedSGD(torch.optim.Optimizer):
         rank, world = st.pop("momentum_shard")
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() != world:
             raise RuntimeError("FusedSGD: a row-sharded momentum buffer can only be completed by the process group that sharded it "
-                               f"(world size {world}); call optimizer.state_dict() / consolidate_momentum() before leaving the group")
+                               f"(world size {world}); call consolidate_momentum() before leaving the group")
         m = st["momentum_buffer"]
         rows = m.shape[0] // world
         mine = m[rank * rows:(rank + 1) * rows]
@@ -108,8 +110,14 @@ class FusedSGD(torch.optim.Optimizer):
                     self._gather_momentum(p)
 
     def state_dict(self):
-        """Collective when a data-parallel step has row-sharded a momentum buffer: the saved buffers are complete on every rank."""
-        self.consolidate_momentum()
+        """LOCAL, like torch.optim.Optimizer.state_dict (the usual `if rank == 0: torch.save(opt.state_dict())` must not deadlock).
+        If a data-parallel step has row-sharded a momentum buffer, only this rank's rows of it are current: saving that silently
+        would write a wrong checkpoint, so this raises and names the fix — every rank calls ``consolidate_momentum()`` (a
+        collective, outside any graph capture) first; ``ICLTrainer.optimizer_state_dict()`` does both."""
+        pending = [i for g in self.param_groups for i, p in enumerate(g["params"]) if self.state.get(p, {}).get("momentum_shard") is not None]
+        if pending:
+            raise RuntimeError(f"FusedSGD.state_dict(): {len(pending)} momentum buffer(s) are row-sharded over the data-parallel group; "
+                               "call optimizer.consolidate_momentum() on EVERY rank first (collective), then state_dict() on any rank")
         return super().state_dict()
 
     def can_update_in_backward(self, p, rows: int) -> bool:

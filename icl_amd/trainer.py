@@ -239,6 +239,14 @@ class ICLTrainer:
         return self
 
 
+def optimizer_state_dict(optimizer):
+    """Checkpoint helper for data-parallel runs: EVERY rank calls it (``FusedSGD.consolidate_momentum()`` is a collective when a
+    step has row-sharded a momentum buffer); the returned dict is complete on every rank and ``state_dict()`` itself stays local."""
+    if hasattr(optimizer, "consolidate_momentum"):
+        optimizer.consolidate_momentum()
+    return optimizer.state_dict()
+
+
 def backbone_state_dict(model: torch.nn.Module):
     """The checkpoint the reference trainers save: every key without 'sspa'/'uscl' (…BraTS.py:158-162)."""
     from collections import OrderedDict

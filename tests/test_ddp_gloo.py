@@ -1,4 +1,4 @@
-"""World-size-2 checks of the data-parallel gradient reducer on the gloo backend (CPU).
+"""World-size 2 / 3 / 4 checks of the data-parallel gradient reducer on the gloo backend (CPU).
 
 SURVEY.md §8e: W ranks == W independent reference steps with averaged gradients; parameters whose grad is None
 are skipped, never zero-filled (torch SGD skips them too, so weight decay must not touch them)."""
@@ -88,9 +88,12 @@ def _worker_factored(rank, world, port, tmp):
     ops.FactoredGrads.min_elems = 1000
     # two passes: every rank applies the whole gathered update / the crossover form (each rank updates its rows, then the ranks
     # all-gather the updated rows: GradientReducer.post_update)
-    for shard_rows in (0, 1):
+    for shard_rows, nrows in ((0, 48), (1, 48), (1, 50)):
+        # 48 rows divide by every tested world size; 50 only by 2: with 3 or 4 ranks the row-sharded form is not available
+        # (p.shape[0] % world != 0) and the reducer must fall back to the whole gathered update without being told
+        can_shard = bool(shard_rows) and nrows % world == 0
         torch.manual_seed(3)
-        lin = Linear(64, 48)
+        lin = Linear(64, nrows)
         red = GradientReducer(lin, world, shard_min_rows=shard_rows)
         red.broadcast_parameters()
         w0, b0 = lin.weight.detach().clone(), lin.bias.detach().clone()
@@ -107,7 +110,7 @@ def _worker_factored(rank, world, port, tmp):
             assert lin.weight.grad is None and lin.weight._icl_factors
             red.reduce_gradients()
             assert lin.weight._icl_factors[0][0].shape[0] == 6 * world
-            assert (lin.weight._icl_shard is not None) == bool(shard_rows)
+            assert (lin.weight._icl_shard is not None) == can_shard
             opt.step()
             red.post_update()
             # reference: dense gradients of every shard on one process, averaged, torch SGD
@@ -119,7 +122,7 @@ def _worker_factored(rank, world, port, tmp):
                 gb += rb.grad / world
             rw.grad, rb.grad = gw, gb
             ref_opt.step()
-            assert torch.allclose(lin.weight.detach(), rw.detach(), rtol=1e-5, atol=1e-6), (shard_rows, step)
+            assert torch.allclose(lin.weight.detach(), rw.detach(), rtol=1e-5, atol=1e-6), (shard_rows, nrows, step)
             assert torch.allclose(lin.bias.detach(), rb.detach(), rtol=1e-5, atol=1e-6)
             assert lin.weight._icl_shard is None      # consumed by the step: the decision never outlives its factors
     # the shard decision flips between steps (sharded, sharded, whole, sharded, whole): the momentum rows the other ranks own are
@@ -151,7 +154,12 @@ def _worker_factored(rank, world, port, tmp):
         rw.grad, rb.grad = gw, gb
         ref_opt.step()
         assert torch.allclose(lin.weight.detach(), rw.detach(), rtol=1e-5, atol=1e-6), step
-        if step == 3:     # saved right after a sharded step: state_dict() completes the buffer (collective)
+        if step == 3:     # saved right after a sharded step
+            if sharded:
+                # state_dict() is LOCAL (rank 0 alone may call it): with rows still sharded it refuses instead of communicating
+                with pytest.raises(RuntimeError, match="consolidate_momentum"):
+                    opt.state_dict()
+            opt.consolidate_momentum()      # the collective, on every rank
             sd = opt.state_dict()
             m = sd["state"][0]["momentum_buffer"]
             assert torch.allclose(m, ref_opt.state[rw]["momentum_buffer"], rtol=1e-5, atol=1e-6)
@@ -160,16 +168,16 @@ def _worker_factored(rank, world, port, tmp):
 
 
 @pytest.mark.timeout(300)
-def test_factored_gradient_exchange_world2(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_factored_gradient_exchange(tmp_path, world):
     from hipemu.build_emu import build_emu  # noqa: F401  (build once, before the workers race for it)
     build_emu()
     mp.spawn(_worker_factored, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
 
 
 @pytest.mark.timeout(300)
-def test_gradient_reducer_world2(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_gradient_reducer(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
 
 

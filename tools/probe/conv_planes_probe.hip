@@ -4,6 +4,7 @@
 //   tools/probe/planesprobe 16 16 96        (cin cout side [rounds])
 // Prints whether the outputs are bit-identical and median / min launch times of interleaved rounds; first a micro-test of what the
 // hardware writes to LDS for a range-checked LDS-DMA lane (information only: the kernel does not rely on it).
+#define PLANES_STAMPS 1
 #include "device_env_hip.h"
 #include "kernels/common.h"
 #include "kernels/conv_bf16x3.h"
@@ -45,28 +46,32 @@ void launch_old(const float* x, const uint4* ws, const float* bias, float* y, ic
     hipLaunchKernelGGL((icl::conv3d_bf16x3_fwd_kernel<NBT, 8, 60>), dim3(gx, gy), dim3(512), lds, 0, x, ws, bias, y, g);
   }
 }
-template <int NBT>
-void launch_new(const uint4* planes, const uint4* ws, const float* bias, float* y, icl::Bf3PGeom g, bool flat) {
+template <int NBT, int TY, int NWV, bool DBUF, bool FLAT>
+void launch_cfg(const uint4* planes, const uint4* ws, const float* bias, float* y, icl::Bf3PGeom g, int maxw) {
+  typedef icl::PlanesCfg<NBT, TY, NWV, DBUF, FLAT> C;
   const int gy = (g.CoutP + 16 * NBT - 1) / (16 * NBT);
-  const int gx = g.ntiles < 256 ? (g.ntiles + 7) / 8 * 8 : 256;
-  const size_t lds = (size_t)(6 * 1088 + (NBT == 1 ? 3 : 1) * 60 * 16 * NBT) * 16;
-  if (flat) {
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_planes_fwd_kernel<NBT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((icl::conv3d_planes_fwd_kernel<NBT, true>), dim3(gx, gy), dim3(512), lds, 0, planes, ws, bias, y, g);
-  } else {
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_planes_fwd_kernel<NBT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((icl::conv3d_planes_fwd_kernel<NBT, false>), dim3(gx, gy), dim3(512), lds, 0, planes, ws, bias, y, g);
-  }
+  if (!FLAT) { g.nty = (g.H + TY - 1) / TY; g.ntiles = 2 * g.ntz * g.nty * g.ntx; }
+  const int gx = g.ntiles < maxw ? (g.ntiles + 7) / 8 * 8 : maxw;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_planes_fwd_kernel<NBT, TY, NWV, DBUF, FLAT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL((icl::conv3d_planes_fwd_kernel<NBT, TY, NWV, DBUF, FLAT>), dim3(gx, gy), dim3(64 * NWV), C::LDS_BYTES, 0, planes, ws, bias, y, g);
+}
+// cfg 0: <NBT, 8, 8, single> one workgroup per CU; 1: <1, 4, 4, single> two workgroups per CU; 2: <NBT, 4, 8, double-buffered>
+template <int NBT>
+void launch_new(const uint4* planes, const uint4* ws, const float* bias, float* y, icl::Bf3PGeom g, bool flat, int cfg) {
+  if (flat) { launch_cfg<NBT, 8, 8, false, true>(planes, ws, bias, y, g, 256); return; }
+  if (cfg == 1) { if constexpr (NBT == 1) launch_cfg<1, 4, 4, false, false>(planes, ws, bias, y, g, 512); return; }
+  if (cfg == 2) { if constexpr (NBT <= 2) launch_cfg<NBT, 4, 8, true, false>(planes, ws, bias, y, g, 256); return; }
+  launch_cfg<NBT, 8, 8, false, false>(planes, ws, bias, y, g, 256);
 }
 
 int main(int argc, char** argv) {
   const int cin = argc > 1 ? atoi(argv[1]) : 16, cout = argc > 2 ? atoi(argv[2]) : 16, R = argc > 3 ? atoi(argv[3]) : 96;
-  const int rounds = argc > 4 ? atoi(argv[4]) : 7;
+  const int rounds = argc > 4 ? atoi(argv[4]) : 7, cfg = argc > 5 ? atoi(argv[5]) : 0;
   const int nbt = cout % 48 == 0 ? 3 : cout % 32 == 0 ? 2 : 1, N = 2;
   const int D = R, H = R, W = R;
   const bool flat = W == 24;
   const long S = (long)D * H * W;
-  {
+  if (getenv("PROBE_OOB")) {
     std::vector<uint4> hg(64);
     for (int i = 0; i < 64; ++i) hg[i] = make_uint4(100u + i, 0u, 0u, 0u);
     uint4 *dg, *dout;
@@ -112,10 +117,11 @@ int main(int argc, char** argv) {
   icl::Bf3PGeom p{};
   p.Cout = cout; p.CoutP = coutP; p.D = D; p.H = H; p.W = W; p.ntz = g.ntz; p.nty = g.nty; p.ntx = g.ntx; p.ntiles = g.ntiles;
   p.nchunks = g.nchunks; p.ppitch = pitch; p.p_bstride = pbs; p.y_bstride = g.y_bstride;
+  p.dbg = 0;
 
   auto split = [&]() { hipLaunchKernelGGL(icl::planes_from_f32_kernel, dim3(2048), dim3(256), 0, 0, dx, dpl, N, cin, S, (long)cin * S, pbs); };
   auto go_old = [&]() { if (nbt == 1) launch_old<1>(dx, dws, db, dy0, g, flat); else if (nbt == 2) launch_old<2>(dx, dws, db, dy0, g, flat); else launch_old<3>(dx, dws, db, dy0, g, flat); };
-  auto go_new = [&]() { if (nbt == 1) launch_new<1>(dpl, dws, db, dy1, p, flat); else if (nbt == 2) launch_new<2>(dpl, dws, db, dy1, p, flat); else launch_new<3>(dpl, dws, db, dy1, p, flat); };
+  auto go_new = [&]() { if (nbt == 1) launch_new<1>(dpl, dws, db, dy1, p, flat, cfg); else if (nbt == 2) launch_new<2>(dpl, dws, db, dy1, p, flat, cfg); else launch_new<3>(dpl, dws, db, dy1, p, flat, cfg); };
   split(); go_old(); go_new();
   CK(hipDeviceSynchronize());
   CK(hipGetLastError());
@@ -127,7 +133,7 @@ int main(int argc, char** argv) {
     if (memcmp(&h0[i], &h1[i], 4)) { if (ndiff++ < 5) printf("  diff at %zu: shipped %g planes %g\n", i, h0[i], h1[i]); }
     const double d = fabs((double)h0[i] - h1[i]); if (d > maxd || d != d) maxd = d;
   }
-  printf("%d->%d @%d^3 n=%d nbt=%d%s: %zu of %zu outputs differ bitwise (max |diff| %.3e)\n", cin, cout, R, N, nbt, flat ? " flat24" : "", ndiff, h0.size(), maxd);
+  printf("%d->%d @%d^3 n=%d nbt=%d%s cfg %d: %zu of %zu outputs differ bitwise (max |diff| %.3e)\n", cin, cout, R, N, nbt, flat ? " flat24" : "", cfg, ndiff, h0.size(), maxd);
   // race screen: repeat the planes kernel and compare with its first result
   for (int rep = 0; rep < 10; ++rep) {
     CK(hipMemset(dy1, 0xee, (size_t)N * cout * S * 4));
@@ -157,5 +163,21 @@ int main(int argc, char** argv) {
   const double fl = 2.0 * 27 * cin * cout * N * S;
   printf("  shipped <%d,8,60>: median %.1f us (min %.1f) %.1f TF | planes + LDS-DMA: median %.1f us (min %.1f) %.1f TF = %.3fx | stand-alone split kernel %.1f us\n",
          nbt, med(t_old), mn(t_old), fl / med(t_old) * 1e-6, med(t_new), mn(t_new), fl / med(t_new) * 1e-6, med(t_old) / med(t_new), med(t_split));
+  {
+    long long st[96];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(icl::g_planes_stamps), sizeof(st)));
+    for (int w = 0; w < 2; ++w)
+      for (int it = 0; it < 3; ++it) {
+        const long long* q = st + (w * 3 + it) * 16;
+        printf("  stamps wave %s item %d: dma-wait %lld | barrier %lld | dz0 %lld dz1 %lld dz2 %lld | end-barrier %lld issue %lld epilogue %lld | item total %lld\n",
+               w ? "N/2" : "0", it + 2, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5], q[7] - q[6], q[8] - q[7], q[8] - q[0]);
+      }
+  }
+  for (int dbg = 1; dbg <= 3; ++dbg) {
+    p.dbg = dbg;
+    std::vector<double> t;
+    for (int r = 0; r < 4; ++r) { const double a = timed(go_new); if (r) t.push_back(a); }
+    printf("  ablation dbg=%d (%s): median %.1f us\n", dbg, dbg == 1 ? "no halo DMA after the first item" : dbg == 2 ? "no output stores" : "neither", med(t));
+  }
   return ndiff ? 1 : 0;
 }
