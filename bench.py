@@ -229,6 +229,9 @@ def main():
     if use_ddp:
         ddp = GradientReducer(model, world, force=args.force_ddp)
         ddp.broadcast_parameters()
+        # measure the node's all-gather / all-reduce rates on a parameter-sized buffer (MAX over ranks) and set the crossover of the
+        # factored exchange from them instead of the assumed 300 GB/s; the chosen plan is printed on the JSON line (config.ddp_plan)
+        ddp.calibrate()
     cfg = ICLConfig(num_classes=nc, labeled_bs=1, base_lr=0.02 if nc == 16 else 0.01,
                     w_pse=0.1 if nc == 16 else 1.0)
     trainer = ICLTrainer(model, cfg, ddp)
@@ -456,7 +459,8 @@ def main():
             "config": {"workload": f"{'SwinUNETR' if args.model == 'swinunetr_icl' else '3D U-Net'} ICL BraTS-shape synthetic 96x96x96, num_classes={nc}, "
                                    f"batch=2 per GPU (1 labeled + 1 unlabeled), full ICL step incl. SGD",
                        "global_batch": 2 * world, "parallelism": f"dp{world}",
-                       **({"rccl_ranks": torch.distributed.get_world_size(), "collective_backend": torch.distributed.get_backend()}
+                       **({"rccl_ranks": torch.distributed.get_world_size(), "collective_backend": torch.distributed.get_backend(),
+                           "ddp_plan": {"rates": ddp.rates, "matrices": ddp.last_plan}}
                           if use_ddp else {}),
                        "launch": ("eager" if not graphed else "hipGraph replay" if ddp is None else
                                   "hipGraph replay (forward/backward, optimiser) + eager RCCL collectives"),

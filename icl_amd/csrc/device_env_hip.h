@@ -90,6 +90,8 @@ __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 #define ICL_PIN4(u) asm volatile("" : "+v"((u).x), "+v"((u).y), "+v"((u).z), "+v"((u).w))
 // ... one float: it is loaded and in its register here (the compiler's s_waitcnt for it sits at this point, not at a later use)
 #define ICL_PIN1(f) asm volatile("" : "+v"(f))
+// s_setprio: issue priority of this wave among the waves of its SIMD (0 lowest .. 3)
+#define ICL_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
 // nothing may be scheduled across this point (keeps software-prefetched LDS reads ahead of the MFMAs they overlap)
 #define ICL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // scheduling groups inside one region (LLVM AMDGPU masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read, 0x002 VALU)

@@ -33,6 +33,11 @@ struct Bf3Geom {
   int ntz, nty, ntx, ntiles;  // tiles per sample, ntiles = batch * ntz * nty * ntx
   int nchunks;                // Cin / 16
   long x_bstride, y_bstride;
+  int flags;                  // bit 1: non-temporal output stores (round 4, batch 2: 16->48 @96^3 348 vs 368 us, 32->32 @48^3 67.7 vs
+                              // 69.7, 16->16 @96^3 137 vs 139: the launcher sets it for three cout blocks).  (Bit 0 was a y-slowest
+                              // tile order inside an XCD's share of the tile list, so that z- and x-neighbours run at the same time
+                              // and their shared halo lines hit the XCD's L2: measured +-1 % on every layer, removed —
+                              // profiles/r4_tile_order_nt_probe.txt.)
 };
 
 // Output tile 4 x TY x 16 voxels, one wave per four (z, y) rows: TY = 8 -> 8 waves, 120-150 KB of LDS (one workgroup per CU);
@@ -604,6 +609,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       const int b = tile / tiles_per, bt = tile % tiles_per;
       const int x0 = (bt % g.ntx) * TC::TX, y0 = ((bt / g.ntx) % g.nty) * TC::TY, z0 = (bt / (g.ntx * g.nty)) * TC::TZ;
       float* yb = y + (long)b * g.y_bstride;
+      const bool nt = (g.flags & 2) != 0;
 #pragma unroll
       for (int j = 0; j < NBT; ++j) {
         const int co = n0 + j * 16 + lr;
@@ -620,9 +626,11 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #if defined(BF3_DEBUG) && (BF3_DEBUG & 4)
           if (acc[m][j][0] == 12345.678f)
 #endif
-          if (co < g.Cout && gz < g.D && gy < g.H && gx < g.W)
-            *reinterpret_cast<float4*>(yb + (long)co * DHW + gz * HW + (long)gy * g.W + gx) =
-                make_float4(acc[m][j][0] + bv, acc[m][j][1] + bv, acc[m][j][2] + bv, acc[m][j][3] + bv);
+          if (co < g.Cout && gz < g.D && gy < g.H && gx < g.W) {
+            float* dst = yb + (long)co * DHW + gz * HW + (long)gy * g.W + gx;
+            const float4 v = make_float4(acc[m][j][0] + bv, acc[m][j][1] + bv, acc[m][j][2] + bv, acc[m][j][3] + bv);
+            if (nt) icl_nt_store4(dst, v); else *reinterpret_cast<float4*>(dst) = v;
+          }
           acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }

@@ -23,6 +23,47 @@ import torch
 import torch.distributed as dist
 
 
+# Factored SGD update of ONE 13,824^2 matrix on one MI355X as a function of the gathered factor rows (tools/sgd_probe.py, rounds 2-3:
+# fp32 MFMA below 192 rows, split products from there on), ms.  Other matrix sizes scale with their element count (the update is a
+# stream over p and m plus rows x n x k multiply-adds).
+_UPDATE_ROWS_MS = ((16, 0.52), (32, 0.55), (64, 0.70), (128, 0.80), (256, 1.03), (512, 1.77), (1024, 3.2), (1536, 4.8))
+_REF_ELEMS = 13824 * 13824
+ASSUMED_ALLGATHER_GBPS = 300.0      # per rank, before the node has been measured (calibrate())
+
+
+def update_ms(rows: float, elems: int = _REF_ELEMS) -> float:
+    """Projected time of the factored update of an `elems`-element matrix from `rows` gathered factor rows."""
+    t = _UPDATE_ROWS_MS
+    if rows <= t[0][0]:
+        ms = t[0][1]
+    elif rows >= t[-1][0]:
+        ms = t[-1][1] * rows / t[-1][0]
+    else:
+        for (r0, m0), (r1, m1) in zip(t, t[1:]):
+            if r0 <= rows <= r1:
+                ms = m0 + (m1 - m0) * (rows - r0) / (r1 - r0)
+                break
+    return ms * elems / _REF_ELEMS
+
+
+def exchange_plan(rows_gathered: int, elems: int, world: int, allgather_gbps: float, allreduce_gbps: float = None, divisible: bool = True):
+    """The three ways a rank can apply the averaged gradient of a token-axis matrix, priced with the node's measured rates:
+    whole   every rank applies the rank-(rows W) update of the whole matrix from the gathered factors;
+    shard   rank r updates rows [r N/W, (r+1) N/W) and the ranks all-gather the updated rows (4 B per weight over xGMI);
+    dense   the layer forms its dense gradient, the ranks all-reduce it (8 (W-1)/W B per weight) and apply the 20 B/weight update.
+    Returns (mode, {mode: projected ms})."""
+    nbytes = 4.0 * elems
+    cost = {"whole": update_ms(rows_gathered, elems)}
+    if divisible and world > 1:
+        cost["shard"] = update_ms(rows_gathered, elems) / world + nbytes / (allgather_gbps * 1e6)
+    if allreduce_gbps and world > 1:
+        local_rows = rows_gathered / world
+        form = 2.0 * local_rows * elems / 100e12 * 1e3                       # dW = g^T x on the fp32 MFMA tile kernel (~100 TFLOP/s)
+        cost["dense"] = form + 2.0 * (world - 1) / world * nbytes / (allreduce_gbps * 1e6) + 20.0 * elems / 5.5e12 * 1e3
+    mode = min(cost, key=cost.get)
+    return mode, {k: round(v, 3) for k, v in cost.items()}
+
+
 class GradientReducer:
     """``reduce_gradients()`` = ``pack()`` (device-side preparation) + ``communicate()`` (the collectives, nothing else) +
     ``rebind()`` (Python-side: ``p.grad`` / ``p._icl_factors`` now name the reduced buffers).  ICLTrainer.capture() records
@@ -54,10 +95,67 @@ class GradientReducer:
             shard_min_rows = int(os.environ.get("ICL_DDP_SHARD_ROWS", "768"))
         self.shard_min_rows = shard_min_rows
         self._sharded = []       # parameters whose update of this step is row-sharded
+        self._names = {id(p): n for n, p in model.named_parameters()}
+        self.rates = {"allgather_gbps": ASSUMED_ALLGATHER_GBPS, "allreduce_gbps": None, "measured": False}
+        self.last_plan = []      # per factored matrix of the last step: mode and projected ms (bench.py prints it)
 
     @property
     def active(self) -> bool:
         return self.world > 1 or self.force
+
+    def calibrate(self, nbytes: int = 4 * _REF_ELEMS, iters: int = 2):
+        """Collective (every rank, outside graph capture): measures what the node's RCCL actually delivers on the two exchanges the
+        crossover depends on — the in-place all-gather of a parameter-sized buffer (764 MB) and the all-reduce of the same buffer —
+        takes the MAX time over ranks, and derives `shard_min_rows` (smallest gathered row count from which the row-sharded update +
+        all-gather beats the whole update) and ops.FactoredGrads.max_rows_gathered (where forming and all-reducing the dense gradient
+        would win) from the measured rates instead of the assumed 300 GB/s.  With one rank there is nothing to measure."""
+        if self.world <= 1 or not dist.is_initialized():
+            return self.rates
+        import time
+        p0 = self.params[0]
+        n = nbytes // 4 // self.world * self.world
+        buf = torch.empty(n, dtype=torch.float32, device=p0.device)
+        mine = buf[dist.get_rank() * (n // self.world):(dist.get_rank() + 1) * (n // self.world)]
+
+        def sync():
+            if buf.is_cuda:
+                torch.cuda.synchronize(buf.device)
+
+        def timed(fn):
+            fn()                                                        # warm-up: connection set-up is not the steady rate
+            sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            sync()
+            t = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64, device=p0.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        if self._avg:
+            t_ag = timed(lambda: dist.all_gather_into_tensor(buf, mine))
+        else:
+            t_ag = timed(lambda: dist.all_gather(list(buf.chunk(self.world)), mine.clone()))
+        t_ar = timed(lambda: dist.all_reduce(buf))
+        self.rates = {"allgather_gbps": round(4.0 * n / t_ag / 1e9, 1), "allreduce_gbps": round(4.0 * n / t_ar / 1e9, 1), "measured": True,
+                      "allgather_ms_764MB": round(t_ag * 1e3, 3), "allreduce_ms_764MB": round(t_ar * 1e3, 3)}
+        del buf
+        # thresholds for the 13,824^2 matrices (they are 97 % of the model) from the priced alternatives
+        shard_from = dense_from = None
+        for rows in range(16 * self.world, 4097, 16 * self.world):
+            mode, _ = exchange_plan(rows, _REF_ELEMS, self.world, self.rates["allgather_gbps"], self.rates["allreduce_gbps"])
+            if shard_from is None and mode == "shard":
+                shard_from = rows
+            if dense_from is None and mode == "dense":
+                dense_from = rows
+        self.shard_min_rows = shard_from if shard_from is not None else 0
+        from . import ops
+        if dense_from is not None:
+            ops.FactoredGrads.max_rows_gathered = dense_from - 1
+        self.rates["shard_min_rows"] = self.shard_min_rows
+        self.rates["max_rows_gathered"] = ops.FactoredGrads.max_rows_gathered
+        return self.rates
 
     def broadcast_parameters(self, src: int = 0):
         for p in self.params:
@@ -159,10 +257,16 @@ class GradientReducer:
                 p.grad = flat[off:off + n].view_as(p)
                 off += n
         self._sharded = []
+        self.last_plan = []
         for p, G, X in self._fac:
             p._icl_factors = [(G, X)]
             shard = (self.world > 1 and self.shard_min_rows > 0 and G.shape[0] >= self.shard_min_rows and p.shape[0] % self.world == 0
                      and p.is_contiguous())
+            if p.numel() >= (1 << 22):      # the plan line of bench.py: what this matrix does and what the alternatives would cost
+                _, cost = exchange_plan(G.shape[0], p.numel(), self.world, self.rates["allgather_gbps"], self.rates["allreduce_gbps"],
+                                        p.shape[0] % max(self.world, 1) == 0)
+                self.last_plan.append({"param": self._names.get(id(p), "?"), "shape": list(p.shape), "rows_gathered": int(G.shape[0]),
+                                       "mode": "shard" if shard else "whole", "projected_ms": cost})
             # consumed (and cleared) by FusedSGD._step_factored together with these factors: the decision never outlives its step
             p._icl_shard = (dist.get_rank(), self.world) if shard else None
             if shard:

@@ -302,6 +302,7 @@ static inline void icl_nt_store4(float* p, float4 v) { *reinterpret_cast<float4*
 #define ICL_SCHED_GROUP(mask, n) ((void)0)
 #define ICL_PIN4(u) ((void)(u))
 #define ICL_PIN1(f) ((void)(f))
+#define ICL_SETPRIO(p) ((void)0)
 #define ICL_WAVE_UNIFORM(x) ((void)(x))
 #define ICL_WAVE_SYNC() hipemu::yield_state(2)
 static inline float atomicAdd(float* p, float v) {

@@ -175,6 +175,42 @@ def test_factored_gradient_exchange(tmp_path, world):
     mp.spawn(_worker_factored, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
 
 
+def _worker_calibrate(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from icl_amd import ops
+    from icl_amd.ddp import GradientReducer, exchange_plan
+    red = GradientReducer(Tiny(), world)
+    before = ops.FactoredGrads.max_rows_gathered
+    rates = red.calibrate(nbytes=1 << 20, iters=1)
+    assert rates["measured"] and rates["allgather_gbps"] > 0 and rates["allreduce_gbps"] > 0
+    everyone = [None] * world
+    dist.all_gather_object(everyone, (rates, red.shard_min_rows, ops.FactoredGrads.max_rows_gathered))
+    assert all(e == everyone[0] for e in everyone)        # MAX-reduced times: every rank derives the same thresholds
+    # the thresholds are the crossovers of the priced alternatives at the measured rates
+    if red.shard_min_rows:
+        assert exchange_plan(red.shard_min_rows, 13824 * 13824, world, rates["allgather_gbps"], rates["allreduce_gbps"])[0] == "shard"
+    ops.FactoredGrads.max_rows_gathered = before
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_reducer_calibration_sets_the_same_crossover_on_every_rank(tmp_path):
+    mp.spawn(_worker_calibrate, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def test_exchange_plan_prices_the_alternatives():
+    from icl_amd.ddp import exchange_plan, update_ms
+    assert abs(update_ms(128) - 0.80) < 1e-9 and update_ms(192) > update_ms(128)
+    # a slow all-gather keeps the whole update; a fast one shards from a few hundred rows on; indivisible rows never shard
+    assert exchange_plan(512, 13824 * 13824, 8, 100.0)[0] == "whole"
+    assert exchange_plan(512, 13824 * 13824, 8, 1000.0)[0] == "shard"
+    assert "shard" not in exchange_plan(512, 13824 * 13824, 8, 1000.0, divisible=False)[1]
+    # nc = 16 at 8 ranks (1024 / 512 gathered rows): projected per-matrix time at the assumed 300 GB/s
+    mode, cost = exchange_plan(1024, 13824 * 13824, 8, 300.0, 250.0)
+    assert mode == "shard" and cost["shard"] < cost["whole"] < cost["dense"]
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_gradient_reducer(tmp_path, world):

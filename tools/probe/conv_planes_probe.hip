@@ -1,14 +1,16 @@
 // Standalone A/B of csrc/kernels/conv_planes.h (halo tiles by LDS-DMA from producer-written operand planes) against the shipped
 // conv3d_bf16x3_fwd_kernel<NBT, 8, 60> (fp32 input, split while staging):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I icl_amd/csrc tools/probe/conv_planes_probe.hip -o tools/probe/planesprobe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I icl_amd/csrc -I tools/probe tools/probe/conv_planes_probe.hip -o tools/probe/planesprobe
 //   tools/probe/planesprobe 16 16 96        (cin cout side [rounds])
 // Prints whether the outputs are bit-identical and median / min launch times of interleaved rounds; first a micro-test of what the
 // hardware writes to LDS for a range-checked LDS-DMA lane (information only: the kernel does not rely on it).
 #define PLANES_STAMPS 1
+#define WS_STAMPS 1
 #include "device_env_hip.h"
 #include "kernels/common.h"
 #include "kernels/conv_bf16x3.h"
-#include "kernels/conv_planes.h"
+#include "probe_kernels/conv_planes.h"
+#include "probe_kernels/conv_bf16x3_ws.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -54,6 +56,21 @@ void launch_cfg(const uint4* planes, const uint4* ws, const float* bias, float* 
   const int gx = g.ntiles < maxw ? (g.ntiles + 7) / 8 * 8 : maxw;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_planes_fwd_kernel<NBT, TY, NWV, DBUF, FLAT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((icl::conv3d_planes_fwd_kernel<NBT, TY, NWV, DBUF, FLAT>), dim3(gx, gy), dim3(64 * NWV), C::LDS_BYTES, 0, planes, ws, bias, y, g);
+}
+// cfg 3: conv_bf16x3_ws.h — fp32 input, eight consumer waves + four loader waves
+template <int NBT>
+void launch_ws(const float* x, const uint4* ws, const float* bias, float* y, icl::Bf3Geom g, bool flat) {
+  const int gy = (g.CoutP + 16 * NBT - 1) / (16 * NBT);
+  const int gx = g.ntiles < 256 ? (g.ntiles + 7) / 8 * 8 : 256;
+  if (flat) {
+    const size_t lds = icl::Bf3F24::lds_bytes(NBT, NBT == 1 ? 3 : 1);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_bf16x3_fwd_ws_kernel<NBT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((icl::conv3d_bf16x3_fwd_ws_kernel<NBT, true>), dim3(gx, gy), dim3(768), lds, 0, x, ws, bias, y, g);
+  } else {
+    const size_t lds = icl::Bf3T<8>::lds_bytes(NBT, NBT == 1 ? 3 : 1);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_bf16x3_fwd_ws_kernel<NBT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((icl::conv3d_bf16x3_fwd_ws_kernel<NBT, false>), dim3(gx, gy), dim3(768), lds, 0, x, ws, bias, y, g);
+  }
 }
 // cfg 0: <NBT, 8, 8, single> one workgroup per CU; 1: <1, 4, 4, single> two workgroups per CU; 2: <NBT, 4, 8, double-buffered>
 template <int NBT>
@@ -121,7 +138,10 @@ int main(int argc, char** argv) {
 
   auto split = [&]() { hipLaunchKernelGGL(icl::planes_from_f32_kernel, dim3(2048), dim3(256), 0, 0, dx, dpl, N, cin, S, (long)cin * S, pbs); };
   auto go_old = [&]() { if (nbt == 1) launch_old<1>(dx, dws, db, dy0, g, flat); else if (nbt == 2) launch_old<2>(dx, dws, db, dy0, g, flat); else launch_old<3>(dx, dws, db, dy0, g, flat); };
-  auto go_new = [&]() { if (nbt == 1) launch_new<1>(dpl, dws, db, dy1, p, flat, cfg); else if (nbt == 2) launch_new<2>(dpl, dws, db, dy1, p, flat, cfg); else launch_new<3>(dpl, dws, db, dy1, p, flat, cfg); };
+  auto go_ws = [&]() { if (nbt == 1) launch_ws<1>(dx, dws, db, dy1, g, flat); else if (nbt == 2) launch_ws<2>(dx, dws, db, dy1, g, flat); else launch_ws<3>(dx, dws, db, dy1, g, flat); };
+  // cfg 10 + f: the shipped kernel with Bf3Geom::flags = f (1 y-slowest tile order, 2 non-temporal output stores)
+  auto go_flags = [&]() { icl::Bf3Geom gf = g; gf.flags = cfg - 10; if (nbt == 1) launch_old<1>(dx, dws, db, dy1, gf, flat); else if (nbt == 2) launch_old<2>(dx, dws, db, dy1, gf, flat); else launch_old<3>(dx, dws, db, dy1, gf, flat); };
+  auto go_new = [&]() { if (cfg >= 10) { go_flags(); return; } if (cfg == 3) { go_ws(); return; } if (nbt == 1) launch_new<1>(dpl, dws, db, dy1, p, flat, cfg); else if (nbt == 2) launch_new<2>(dpl, dws, db, dy1, p, flat, cfg); else launch_new<3>(dpl, dws, db, dy1, p, flat, cfg); };
   split(); go_old(); go_new();
   CK(hipDeviceSynchronize());
   CK(hipGetLastError());
@@ -163,6 +183,23 @@ int main(int argc, char** argv) {
   const double fl = 2.0 * 27 * cin * cout * N * S;
   printf("  shipped <%d,8,60>: median %.1f us (min %.1f) %.1f TF | planes + LDS-DMA: median %.1f us (min %.1f) %.1f TF = %.3fx | stand-alone split kernel %.1f us\n",
          nbt, med(t_old), mn(t_old), fl / med(t_old) * 1e-6, med(t_new), mn(t_new), fl / med(t_new) * 1e-6, med(t_old) / med(t_new), med(t_split));
+  if (cfg >= 10) return ndiff ? 1 : 0;
+  if (cfg == 3) {
+    long long st[144];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(icl::g_ws_stamps), sizeof(st)));
+    for (int w = 0; w < 2; ++w)
+      for (int it = 0; it < 3; ++it) {
+        const long long* q = st + (w * 3 + it) * 16;
+        printf("  ws stamps consumer wave %d item %d: wait-A %lld | dz0 %lld dz1 %lld dz2 %lld | epilogue %lld | wait-B %lld | item total %lld\n",
+               4 * w, it + 2, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5], q[6] - q[0]);
+      }
+    for (int it = 0; it < 3; ++it) {
+      const long long* q = st + (2 * 3 + it) * 16;
+      printf("  ws stamps loader wave 8 item %d: wait-A %lld | phase0 %lld phase1 %lld phase2+split %lld | wait-B %lld | deposit %lld | item total %lld\n",
+             it + 2, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5], q[6] - q[0]);
+    }
+    return ndiff ? 1 : 0;
+  }
   {
     long long st[96];
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(icl::g_planes_stamps), sizeof(st)));
