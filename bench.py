@@ -470,12 +470,13 @@ def main():
                        # bf16 MFMA terms per product, fp32 accumulate): outputs as close to fp64 as the fp32 MFMA kernels'
                        # (tests/test_gpu_parity.py::test_split_bf16_convolution_is_as_accurate_as_the_fp32_mfma_path); the
                        # bf16 MFMA's internal 32-product sums are not rounded to nearest (-0.36 * 2^-24 coherent offset on same-sign
-                       # sums), which a cancellation-heavy gradient sees: "accuracy_trade" states it on the line
+                       # sums); "accuracy_trade" states what was measured on the most cancellation-heavy gradient of the step
                        "conv_products": ("exact 3-way bf16 splits of fp32 operands, 6 MFMA terms, fp32 accumulate (ICL_CONV_SPLIT=1)"
                                          if os.environ.get("ICL_CONV_SPLIT", "1") != "0" else "v_mfma_f32_16x16x4_f32"),
                        **({"accuracy_trade": "split products: logits/maps/losses/gradient norms within 1e-3 of the reference as with the "
                                              "fp32 MFMA kernels; bf16 MFMA accumulation offset -0.36*2^-24 on same-sign sums; sampled "
-                                             "13,824^2 mlp2 gradient 1.6e-2 from the reference vs 1.2e-3 with ICL_CONV_SPLIT=0"}
+                                             "13,824^2 mlp2 gradient: 1.2e-3 between the two paths, both 1.6e-2 from the reference = the "
+                                             "rounding floor of that sample (profiles/r4_mlp2_grad_sensitivity.txt)"}
                           if os.environ.get("ICL_CONV_SPLIT", "1") != "0" else {}),
                        **({"exact_fp32_mfma_convolutions": exact} if exact else {}),
                        **({"feed": feed} if feed else {})},

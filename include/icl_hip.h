@@ -46,8 +46,9 @@ int icl_conv3d_pack_weights_multi(const void* const* w, void* const* wp_fwd, voi
  * csrc/kernels/conv_bf16x3.h).  Accuracy, measured against fp64: the OUTPUTS are as close as those of
  * v_mfma_f32_16x16x4_f32 (mean |error| 2.3e-7 vs 3.2e-7 relative), but v_mfma_f32_16x16x32_bf16 does not round its 32-product
  * partial sums to nearest: sums of same-sign products carry a coherent offset of -0.36 * 2^-24 (relative) that the fp32 kernels do
- * not have.  Logits, maps, losses and gradient norms are unaffected (<= 1e-3 with margin); a cancellation-heavy gradient can see it
- * (the sampled 13,824^2 mlp2 gradient: 1.6e-2 from the reference against 1.2e-3 with the fp32 kernels).  The split weights live in
+ * not have.  Logits, maps, losses, gradient norms and every compared gradient are unaffected: on the most cancellation-heavy tensor of the
+ * step (the sampled 13,824^2 mlp2 gradient) the two paths differ by 1.2e-3 while the quantity itself is only defined to 1.6e-2 (an input
+ * perturbation of 1e-7 moves it that far on the fp32 kernels; round 4, profiles/r4_mlp2_grad_sensitivity.txt).  The split weights live in
  * ws (counted by icl_conv3d_fwd_ws_bytes; without ws the fp32 MFMA kernels run).  Environment: ICL_CONV_SPLIT=0 selects the fp32
  * MFMA kernels for every shape. */
 int64_t icl_conv3d_fwd_ws_bytes(int n, int cin, int cout, int d, int h, int w, int ks);

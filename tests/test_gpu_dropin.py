@@ -82,42 +82,52 @@ def _check_step(model, g, losses_got, grads, elementwise, norm_skip=lambda k: Fa
     assert not off, off[:8]
 
 
-# (convolution path, band of the sampled mlp2 gradient): the two paths are asserted SEPARATELY so that neither can regress behind the
-# other's band — exact-fp32 MFMA convolutions measure 1.2e-3 (band 3e-3 = 2x the 1.5e-3 an input perturbation of 1e-7 moves the sample),
-# split products 1.6e-2 (band 3e-2).
-@pytest.mark.parametrize("conv_split,mlp2_band", [("1", 3e-2), ("0", 3e-3)])
-def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root, monkeypatch, conv_split, mlp2_band):
-    monkeypatch.setenv("ICL_CONV_SPLIT", conv_split)
+def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root, monkeypatch):
+    """The reference loop body on both convolution paths (ICL_CONV_SPLIT=1, the default split products, and =0, exact-fp32 MFMA), each
+    against the golden with its own assertion, and against EACH OTHER on the one tensor where a difference could hide: the sampled
+    13,824^2 mlp2 gradient.  Measured (tests/diag/mlp2_grad_sensitivity.py, round 4, profiles/r4_mlp2_grad_sensitivity.txt): both paths
+    are 1.62e-2 from the golden on that sample — and so is the exact path from ITSELF when the input volume is scaled by (1 + 1e-7)
+    (1.61e-2): the sample (1,024 elements of size 1e-6 of a cancellation-heavy gradient) is defined to 1.6e-2 by the reference's own
+    rounding; the two paths differ from each other by 1.2e-3.  (Round 3 had reported "exact 1.2e-3 from the golden": that was the
+    split-vs-exact number.)"""
     from networks.net_factory_3d import net_factory_3d
     g = load_golden("model_unet3d_icl_nc2.npz")
-    model = net_factory_3d(net_type="unet_3D_icl", in_chns=1, class_num=2)
-    assert model.training and next(model.parameters()).is_cuda and list(model.state_dict().keys()) == list(g["keys"])
-    fill_like_reference_init(list(model.named_parameters()))
-    _parity_mode(model)
-    dev = next(model.parameters()).device
-    vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
-    lab = synthetic_labels((1, 96, 96, 96), 4242, 2).to(dev)
-    got, grads = _reference_loop_body(model, vol, lab, labeled_bs=1, num_classes=2, base_lr=0.01)
-    full = lambda t: t                                             # noqa: E731
-    elementwise = [
-        ("final.weight", full, 1e-3), ("final.bias", full, 1e-3), ("conv1.conv1.0.weight", full, 2e-2), ("sspa.guided_Q", full, 5e-3),
-        ("sspa.class_decoders.0.attn.fc_q.weight", full, 5e-3), ("uscl.attn_convs1.2.weight", full, 5e-3),
-        ("sspa.attn_convs0.2.block.depthwise.weight", full, 5e-3), ("sspa.query_convs.0.weight", full, 5e-3),
-        # dense 13,824^2 gradient of stock SGD, 1,024 sampled elements of size 1e-6.  Measured (tests/diag/mlp2_grad_sensitivity.py,
-        # round 3): exact-fp32 convolutions 1.2e-3 from the golden; the same kernels with the input volume scaled by (1 + 1e-7)
-        # move the sample by 1.5e-3 (rounding-sized perturbations flip ReLU / max-pool decisions); the split-product
-        # convolutions 1.6e-2 — their products are closer to exact than an fp32 multiply, but v_mfma_f32_16x16x32_bf16 does not round
-        # its 32-product sums to nearest (-0.36 * 2^-24 coherent offset, test_split_bf16_convolution_all_positive_sums_carry_no_bias),
-        # and this cancellation-heavy gradient sees it.  Losses, maps, gradient norms and the other tensors are unchanged.
-        ("sspa.class_decoders.2.mlp2.fc1.weight", lambda t: t[::432, ::432], mlp2_band),
-        ("center.conv2.0.weight", lambda t: t[::16, ::16], 2e-2),
-    ]
-    # conv biases in front of an InstanceNorm and attn_convs1 biases in front of the class softmax: the true gradient is exactly 0
-    skip = lambda k: k.endswith(".0.bias") or ("attn_convs1" in k and k.endswith("bias"))   # noqa: E731
-    _check_step(model, g, got, grads, elementwise, skip)
-    assert rel_err(model.final.weight.detach().cpu(), g["post_sgd.final.weight"]) < 1e-5
-    # the first convolution's gradient is the deepest of the model (2e-2 band above); times lr = 0.01 on O(0.3) weights
-    assert rel_err(model.conv1.conv1[0].weight.detach().cpu(), g["post_sgd.conv1.conv1.0.weight"]) < 1e-4
+    big = "sspa.class_decoders.2.mlp2.fc1.weight"
+    samples = {}
+    for conv_split in ("1", "0"):
+        monkeypatch.setenv("ICL_CONV_SPLIT", conv_split)
+        model = net_factory_3d(net_type="unet_3D_icl", in_chns=1, class_num=2)
+        assert model.training and next(model.parameters()).is_cuda and list(model.state_dict().keys()) == list(g["keys"])
+        fill_like_reference_init(list(model.named_parameters()))
+        _parity_mode(model)
+        dev = next(model.parameters()).device
+        vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
+        lab = synthetic_labels((1, 96, 96, 96), 4242, 2).to(dev)
+        got, grads = _reference_loop_body(model, vol, lab, labeled_bs=1, num_classes=2, base_lr=0.01)
+        full = lambda t: t                                             # noqa: E731
+        elementwise = [
+            ("final.weight", full, 1e-3), ("final.bias", full, 1e-3), ("conv1.conv1.0.weight", full, 2e-2), ("sspa.guided_Q", full, 5e-3),
+            ("sspa.class_decoders.0.attn.fc_q.weight", full, 5e-3), ("uscl.attn_convs1.2.weight", full, 5e-3),
+            ("sspa.attn_convs0.2.block.depthwise.weight", full, 5e-3), ("sspa.query_convs.0.weight", full, 5e-3),
+            # dense 13,824^2 gradient of stock SGD, 1,024 sampled elements: 2x the measured rounding floor of the quantity (docstring)
+            (big, lambda t: t[::432, ::432], 3e-2),
+            ("center.conv2.0.weight", lambda t: t[::16, ::16], 2e-2),
+        ]
+        # conv biases in front of an InstanceNorm and attn_convs1 biases in front of the class softmax: the true gradient is exactly 0
+        skip = lambda k: k.endswith(".0.bias") or ("attn_convs1" in k and k.endswith("bias"))   # noqa: E731
+        _check_step(model, g, got, grads, elementwise, skip)
+        assert rel_err(model.final.weight.detach().cpu(), g["post_sgd.final.weight"]) < 1e-5
+        # the first convolution's gradient is the deepest of the model (2e-2 band above); times lr = 0.01 on O(0.3) weights
+        assert rel_err(model.conv1.conv1[0].weight.detach().cpu(), g["post_sgd.conv1.conv1.0.weight"]) < 1e-4
+        samples[conv_split] = {k: grads[k].detach()[::432, ::432].cpu().numpy() if k == big else grads[k].detach().cpu().numpy()
+                               for k in (big, "final.weight", "center.conv2.0.weight")}
+        del model, grads
+        torch.cuda.empty_cache()
+    # the accuracy statement proper: split products against the exact-fp32 kernels, same inputs, same everything else
+    # (measured 1.2e-3 / 2.7e-7 / 3.1e-4; bands 2.5x)
+    assert rel_err(samples["1"][big], samples["0"][big]) < 3e-3
+    assert rel_err(samples["1"]["final.weight"], samples["0"]["final.weight"]) < 1e-5
+    assert rel_err(samples["1"]["center.conv2.0.weight"], samples["0"]["center.conv2.0.weight"]) < 1e-3
 
 
 def test_reference_loop_body_swinunetr_icl_through_compat_root(compat_root):

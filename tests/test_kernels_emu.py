@@ -74,13 +74,17 @@ def test_conv3d_wgrad_row_window_kernel(monkeypatch, mode, n, cin, cout, d, h, w
     (2, 32, 48, 5, 10, 24),     # ... three cout blocks, two chunks, odd depth, partial y tile, two samples
     (1, 32, 32, 4, 24, 24),     # ... two cout blocks, three y tiles
 ])
-@pytest.mark.parametrize("variant", ["60", "24", "8", "0", "4"])
+@pytest.mark.parametrize("variant", ["default", "60", "24", "8", "0", "4"])
 def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w, variant):
     """conv_bf16x3.h: forward and input gradient with each fp32 operand split exactly into three bf16 terms (six bf16 MFMA terms per
     product, fp32 accumulation) — same tolerance as the fp32-MFMA kernels, and the two paths agree to fp32 rounding.  variant: the
     schedule of the forward kernel (8 = all weight planes of a chunk in LDS for one cout block, the default; 0 = one plane per dz
-    stage; 4 = buffer loads); the weight gradient runs on conv_wgrad_tr.h (transposing LDS reads)."""
-    monkeypatch.setenv("ICL_CONV_SPLIT_V", variant)
+    stage; 4 = buffer loads; default = loader waves for one cout block); the weight gradient runs on conv_wgrad_tr.h (transposing LDS reads)."""
+    # "default": one cout block on 4 x 8 x 16 tiles runs conv_bf16x3_ws.h (eight consumer + four loader waves), the rest variant 60
+    if variant == "default":
+        monkeypatch.delenv("ICL_CONV_SPLIT_V", raising=False)
+    else:
+        monkeypatch.setenv("ICL_CONV_SPLIT_V", variant)
     monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
     monkeypatch.setenv("ICL_CONV_SPLIT", "1")
     monkeypatch.setenv("ICL_WGRAD_SPLIT", "2")      # split-product weight gradient for every Cout (the default)

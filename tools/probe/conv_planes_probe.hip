@@ -10,7 +10,7 @@
 #include "kernels/common.h"
 #include "kernels/conv_bf16x3.h"
 #include "probe_kernels/conv_planes.h"
-#include "probe_kernels/conv_bf16x3_ws.h"
+#include "kernels/conv_bf16x3_ws.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

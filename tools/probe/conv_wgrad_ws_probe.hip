@@ -44,7 +44,7 @@ int run(int cin, int cout, int R, int rounds) {
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_wgrad_tr_kernel<NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_wgrad_tr_ws_kernel<NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   auto go_old = [&]() { hipLaunchKernelGGL((icl::conv3d_wgrad_tr_kernel<NCB>), dim3(nsplit, pairs), dim3(512), C::LDS_BYTES, 0, dx, dg, s0, g); };
-  auto go_new = [&]() { hipLaunchKernelGGL((icl::conv3d_wgrad_tr_ws_kernel<NCB>), dim3(nsplit, pairs), dim3(768), C::LDS_BYTES, 0, dx, dg, s1, g); };
+  auto go_new = [&]() { hipLaunchKernelGGL((icl::conv3d_wgrad_tr_ws_kernel<NCB>), dim3(nsplit, pairs), dim3(512 + 64 * WSW_PRODUCERS), C::LDS_BYTES, 0, dx, dg, s1, g); };
   CK(hipMemset(s0, 0xff, (size_t)nsplit * pe * 4)); CK(hipMemset(s1, 0xee, (size_t)nsplit * pe * 4));
   go_old(); go_new();
   CK(hipDeviceSynchronize()); CK(hipGetLastError());
@@ -53,7 +53,7 @@ int run(int cin, int cout, int R, int rounds) {
   CK(hipMemcpy(h1.data(), s1, h1.size() * 4, hipMemcpyDeviceToHost));
   size_t ndiff = 0;
   for (size_t i = 0; i < h0.size(); ++i) if (memcmp(&h0[i], &h1[i], 4)) { if (ndiff++ < 5) printf("  diff at %zu: shipped %g ws %g\n", i, h0[i], h1[i]); }
-  printf("%d->%d @%d^3 n=%d NCB=%d, %d workgroups x %d tiles: %zu of %zu slab values differ bitwise\n", cin, cout, R, N, NCB, nsplit * pairs, g.tiles_per_wg, ndiff, h0.size());
+  printf("[%d producer waves, priority %d] %d->%d @%d^3 n=%d NCB=%d, %d workgroups x %d tiles: %zu of %zu slab values differ bitwise\n", WSW_PRODUCERS, WSW_PRIO, cin, cout, R, N, NCB, nsplit * pairs, g.tiles_per_wg, ndiff, h0.size());
   for (int rep = 0; rep < 8; ++rep) {
     CK(hipMemset(s1, 0xee, (size_t)nsplit * pe * 4));
     go_new();

@@ -11,6 +11,12 @@
 
 namespace icl {
 
+#if !defined(WSW_PRODUCERS)
+#define WSW_PRODUCERS 4
+#endif
+#if !defined(WSW_PRIO)
+#define WSW_PRIO 0
+#endif
 #if defined(WGTR_WS_STAMPS)
 // consumer waves 0 and 4 (one SIMD) and producer wave 8 of workgroup 0 record s_memtime at the boundaries of phases 4..7
 __device__ long long g_wgtr_ws_stamps[3 * 4 * 8];
@@ -24,7 +30,7 @@ __device__ long long g_wgtr_ws_stamps[3 * 4 * 8];
 #endif
 
 template <int NCB>
-__global__ __launch_bounds__(768) void conv3d_wgrad_tr_ws_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+__global__ __launch_bounds__(512 + 64 * WSW_PRODUCERS) void conv3d_wgrad_tr_ws_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                               float* __restrict__ gwp, Bf3WGeom g) {
   typedef WgTrT<NCB> C;
   ICL_DYN_LDS(uint4, lds);
@@ -33,7 +39,7 @@ __global__ __launch_bounds__(768) void conv3d_wgrad_tr_ws_kernel(const float* __
   ICL_WAVE_UNIFORM(wid);
   const bool producer = wid >= 8;
   const int ptid = tid - 512;                            // producer thread index (256 of them)
-  constexpr int PNT = 256, PROUNDS = (C::ITEMS + PNT - 1) / PNT;
+  constexpr int PNT = 64 * WSW_PRODUCERS, PROUNDS = (C::ITEMS + PNT - 1) / PNT;
   const int kg = wid & 3, th = (wid >> 2) & 1;           // consumers: k-step of the tile, tap half
   const int lg = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
   const int ncb = (g.CinP + 15) / 16;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(768) void conv3d_wgrad_tr_ws_kernel(const float* __
   if (producer) {
     // ============================================================================================ producer waves
     // (a separate code path that ends in `return`: the consumers' 56 NCB accumulator registers are not live here)
-    ICL_SETPRIO(0);
+    ICL_SETPRIO(WSW_PRIO);
     if (t_begin < t_end) {
       load_tile(t_begin, I0());
       store_tile(lds, I0());
