@@ -49,7 +49,9 @@ PIPE_BUSY = {"conv3d_mfma_fwd_static_kernel": 0.81, "conv3d_bf16x3_fwd_kernel<1,
              "conv3d_bf16x3_fwd_kernel<3, 8, 8>": 0.62, "conv3d_wgrad_tr_kernel<1>": 0.44, "conv3d_wgrad_tr_kernel<2>": 0.49,
              "conv3d_bf16x3_fwd_kernel<1, 8, 24>": 0.52,
              # variant 60 (profiles/r3_pmc_conv.md, second table)
-             "conv3d_bf16x3_fwd_kernel<1, 8, 60>": 0.56, "conv3d_bf16x3_fwd_kernel<2, 8, 60>": 0.54, "conv3d_bf16x3_fwd_kernel<3, 8, 60>": 0.68}
+             "conv3d_bf16x3_fwd_kernel<1, 8, 60>": 0.56, "conv3d_bf16x3_fwd_kernel<2, 8, 60>": 0.55, "conv3d_bf16x3_fwd_kernel<3, 8, 60>": 0.66,
+             # round 4 (profiles/r4_pmc_conv.md): the loader-wave kernel for one cout block
+             "conv3d_bf16x3_fwd_ws_kernel<1>": 0.66}
 
 
 def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
@@ -90,7 +92,7 @@ def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
             "sample": f"{steps} full ICL step(s) of the same workload (2 volumes 96^3 each, nc={num_classes}) after a 32^3 conv warm-up: {t:.2f} s"}
 
 
-HBM_TRAFFIC_FILE = "profiles/r3_hbm_traffic.json"
+HBM_TRAFFIC_FILE = "profiles/r4_hbm_traffic.json"
 
 
 def hbm_traffic(kernel: str):

@@ -36,6 +36,9 @@ _SIGNATURES = {
     "icl_conv3d_split_ws_bytes": (c_int64, [I, I]),
     "icl_conv3d_split_weights_multi": (c_int, [P, P, P, P, I, P]),
     "icl_conv3d_fwd_presplit": (c_int, [P, P, P, P, I, I, I, I, I, I, L, L, P]),
+    "icl_conv3d_fwd_stats_slots": (c_int, [I, I, I, I, I, I]),
+    "icl_conv3d_fwd_presplit_stats": (c_int, [P, P, P, P, P, I, I, I, I, I, I, L, L, P]),
+    "icl_norm_fwd_given_stats": (c_int, [P, P, P, P, P, P, P, P, P, I, I, L, I, I, F, F, P, I, P]),
     "icl_conv3d_wgrad_ws_bytes": (c_int64, [I, I, I, I]),
     "icl_conv3d_wgrad": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, L, L, P]),
     "icl_norm_ws_bytes": (c_int64, [I, I, L]),
@@ -82,9 +85,10 @@ _SIGNATURES = {
     "icl_conv1x1_wgrad_ws_bytes": (c_int64, [I, L, I, I]),
     "icl_conv1x1_wgrad": (c_int, [P, P, P, P, P, I, I, I, L, L, L, P]),
     "icl_relpos_bias_fwd": (c_int, [P, P, P, I, I, I, P]),
-    "icl_relpos_bias_bwd": (c_int, [P, P, P, L, I, I, I, P]),
     "icl_window_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, F, P]),
     "icl_window_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "icl_window_attn_bwd_chunks": (c_int, [I, I, I, I, I]),
+    "icl_relpos_bias_bwd_sum": (c_int, [P, I, P, P, P, L, I, I, P]),
     "icl_layernorm_fwd": (c_int, [P, P, P, P, P, P, L, I, F, P]),
     "icl_layernorm_bwd_ws_bytes": (c_int64, [L, I]),
     "icl_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, L, I, P]),

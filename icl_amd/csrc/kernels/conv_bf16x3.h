@@ -33,6 +33,8 @@ struct Bf3Geom {
   int ntz, nty, ntx, ntiles;  // tiles per sample, ntiles = batch * ntz * nty * ntx
   int nchunks;                // Cin / 16
   long x_bstride, y_bstride;
+  float* stats;               // != nullptr: InstanceNorm statistics of the output, produced in the epilogue (bf3_stats_* below)
+  int nbatch;                 // samples (the statistics of a workgroup are written for every sample: zeros for the ones it never sees)
   int flags;                  // bit 1: non-temporal output stores (round 4, batch 2: 16->48 @96^3 348 vs 368 us, 32->32 @48^3 67.7 vs
                               // 69.7, 16->16 @96^3 137 vs 139: the launcher sets it for three cout blocks).  (Bit 0 was a y-slowest
                               // tile order inside an XCD's share of the tile list, so that z- and x-neighbours run at the same time
@@ -52,7 +54,7 @@ struct Bf3T : Bf3Base {
   static constexpr int NW = TZ * TY / 4, NT = 64 * NW, ITEMS = 2 * NPOS, ROUNDS = (ITEMS + NT - 1) / NT;
   static constexpr int XS_U4 = 6 * NPOSP;                        // uint4 (8 bf16) units
   static constexpr int ws_u4(int nb) { return 6 * SLOTS * nb; }
-  static constexpr size_t lds_bytes(int nbt, int planes = 1) { return (size_t)(XS_U4 + planes * ws_u4(16 * nbt)) * 16; }
+  static constexpr size_t lds_bytes(int nbt, int planes = 1) { return (size_t)(XS_U4 + planes * ws_u4(16 * nbt)) * 16 + 8 * 48 * 3 * 4; }
 };
 // Flat tile for rows of 24 voxels (the 24^3 level, round 3): 2 x 8 x 24 = 384 outputs = 24 row blocks of 16 consecutive positions of
 // the flattened (z, y, x) index — three per wave — instead of 4 x 8 x 16 tiles whose second x tile is half empty.  A row block may wrap
@@ -64,7 +66,7 @@ struct Bf3F24 : Bf3Base {
   static constexpr int NW = 8, NT = 64 * NW, ITEMS = 2 * NPOS, ROUNDS = (ITEMS + NT - 1) / NT;
   static constexpr int XS_U4 = 6 * NPOSP;
   static constexpr int ws_u4(int nb) { return 6 * SLOTS * nb; }
-  static constexpr size_t lds_bytes(int nbt, int planes = 1) { return (size_t)(XS_U4 + planes * ws_u4(16 * nbt)) * 16; }
+  static constexpr size_t lds_bytes(int nbt, int planes = 1) { return (size_t)(XS_U4 + planes * ws_u4(16 * nbt)) * 16 + 8 * 48 * 3 * 4; }
 };
 typedef Bf3Base Bf3;
 
@@ -89,6 +91,82 @@ __device__ __forceinline__ void bf3_split8(const float* v, uint4& o1, uint4& o2,
   bf3_split2(v[4], v[5], o1.z, o2.z, o3.z);
   bf3_split2(v[6], v[7], o1.w, o2.w, o3.w);
 }
+
+// ---- InstanceNorm statistics of the convolution output, from the epilogue's registers (round 4; reference: Conv3d -> InstanceNorm3d,
+// /root/reference/code/networks/utils.py:104-105).  The stand-alone statistics pass (norm.h rowstats_partial_kernel) re-reads the whole
+// output (113 MB for a 16-channel 96^3 x 2 tensor) to produce per-(sample, channel) chunk summaries (count, mean, M2) that the
+// normalisation kernel merges; here every WORKGROUP produces one such summary per output channel over all the tiles it computed — from
+// the fp32 values it is about to store — and the normalisation kernel merges gridDim.x of them: the same (count, mean, M2) format, the
+// same merge (Chan et al.), fixed order, no atomics.  Requires that a workgroup's tile list stays inside one sample (launcher).
+// Layout: stats[((sample * Cout + co) * slots + blockIdx.x) * 3 + {0, 1, 2}], slots = gridDim.x.
+template <int NBT>
+struct Bf3RunStats {
+  float n[NBT], mean[NBT], m2[NBT];      // of the tiles so far, per cout block j: channel n0 + 16 j + (lane & 15); equal in the four lane groups
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) n[j] = mean[j] = m2[j] = 0.f;
+  }
+};
+// one tile's values of cout block j in this lane: v[0 .. cnt), the first `cnt` of them valid (cnt is a multiple of 4 or 0 per row block)
+template <int NBT>
+__device__ __forceinline__ void bf3_stats_add(Bf3RunStats<NBT>& run, int j, const float* v, const bool* ok, int nv) {
+  float n = 0.f, shift = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i < nv && ok[i >> 2]) {
+      if (n == 0.f) shift = v[i];
+      const float d = v[i] - shift;
+      s1 += d;
+      s2 += d * d;
+      n += 1.f;
+    }
+  }
+  float mean = 0.f, m2 = 0.f;
+  if (n > 0.f) {
+    mean = shift + s1 / n;
+    m2 = s2 - s1 * s1 / n;
+    if (m2 < 0.f) m2 = 0.f;
+  }
+  // the four lane groups (lane >> 4) hold four x quads of the same channel: symmetric merges, every lane ends with the same value
+#pragma unroll
+  for (int sh = 16; sh <= 32; sh <<= 1) {
+    const float nb = __shfl_xor(n, sh, 64), mb = __shfl_xor(mean, sh, 64), qb = __shfl_xor(m2, sh, 64);
+    float na = n, ma = mean, qa = m2;
+    welford_merge(na, ma, qa, nb, mb, qb);
+    if (na > 0.f) { n = na; mean = ma; m2 = qa; }
+  }
+  welford_merge(run.n[j], run.mean[j], run.m2[j], n, mean, m2);
+}
+// End of the workgroup: the NW waves' summaries through LDS (`scratch`: NW x 16 NBT x 3 floats), merged in wave order by the first 16 NBT
+// threads, written for every sample (zeros for the samples this workgroup did not compute).  All (live) waves of the workgroup call it.
+template <int NBT, int NW>
+__device__ __forceinline__ void bf3_stats_flush(const Bf3RunStats<NBT>& run, float* scratch, float* stats, int my_sample, int nbatch, int cout,
+                                                int n0, int slots, int slot, int wid, int lane, int tid) {
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      float* d = scratch + ((wid * NBT + j) * 16 + lane) * 3;
+      d[0] = run.n[j]; d[1] = run.mean[j]; d[2] = run.m2[j];
+    }
+  }
+  __syncthreads();
+  if (tid < 16 * NBT) {
+    const int j = tid >> 4, lr = tid & 15, co = n0 + j * 16 + lr;
+    float n = 0.f, m = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float* d = scratch + ((w * NBT + j) * 16 + lr) * 3;
+      welford_merge(n, m, q, d[0], d[1], d[2]);
+    }
+    if (co < cout)
+      for (int b = 0; b < nbatch; ++b) {
+        float* o = stats + (((long)b * cout + co) * slots + slot) * 3;
+        const bool mine = b == my_sample;
+        o[0] = mine ? n : 0.f; o[1] = mine ? m : 0.f; o[2] = mine ? q : 0.f;
+      }
+  }
+}
+constexpr size_t kBf3StatsLdsBytes = 8 * 48 * 3 * 4;      // scratch of bf3_stats_flush behind the weight planes (every launch reserves it)
 
 // Split weights, ready for LDS: ws[chunk][stage 3][split * 2 + half][slot 10][CoutP] of 8 packed bf16, from the fp32 pack
 // wp[tap][CinP][CoutP] of the fp32 kernels: slot s of stage g is tap 10 g + s; the 28th slot (stage 2, slot 7) is the zero partner of
@@ -415,6 +493,9 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   bool first_item = true;
   int item_no = -1;
   Origin nxt = {x, 0, 0, 0, 0, 0};
+  Bf3RunStats<NBT> run;                  // InstanceNorm statistics of this workgroup's outputs (g.stats)
+  run.reset();
+  int my_sample = -1;
   while (tile < g.ntiles) {
     int ntile = tile, nchunk = chunk + 1;
     if (nchunk == g.nchunks) { nchunk = 0; ntile = next_tile(tile); }
@@ -614,6 +695,8 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       for (int j = 0; j < NBT; ++j) {
         const int co = n0 + j * 16 + lr;
         const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+        float sv[16];
+        bool sok[4] = {false, false, false, false};
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
           int gz, gy, gx;
@@ -623,22 +706,29 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
           } else {
             gz = z0 + wz; gy = y0 + wy + m; gx = x0 + 4 * lq;
           }
+          const float4 v = make_float4(acc[m][j][0] + bv, acc[m][j][1] + bv, acc[m][j][2] + bv, acc[m][j][3] + bv);
+          sv[4 * m] = v.x; sv[4 * m + 1] = v.y; sv[4 * m + 2] = v.z; sv[4 * m + 3] = v.w;
+          sok[m] = co < g.Cout && gz < g.D && gy < g.H && gx < g.W;
 #if defined(BF3_DEBUG) && (BF3_DEBUG & 4)
           if (acc[m][j][0] == 12345.678f)
 #endif
-          if (co < g.Cout && gz < g.D && gy < g.H && gx < g.W) {
+          if (sok[m]) {
             float* dst = yb + (long)co * DHW + gz * HW + (long)gy * g.W + gx;
-            const float4 v = make_float4(acc[m][j][0] + bv, acc[m][j][1] + bv, acc[m][j][2] + bv, acc[m][j][3] + bv);
             if (nt) icl_nt_store4(dst, v); else *reinterpret_cast<float4*>(dst) = v;
           }
           acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (g.stats) bf3_stats_add(run, j, sv, sok, 4 * MB);
       }
+      my_sample = b;
     }
     BF3_STAMP(21);
     tile = ntile;
     chunk = nchunk;
   }
+  if (g.stats)
+    bf3_stats_flush<NBT, TC::NW>(run, reinterpret_cast<float*>(Ws + WPL * TC::ws_u4(NB)), g.stats, my_sample, g.nbatch, g.Cout, n0, (int)gridDim.x,
+                                 (int)blockIdx.x, wid, lane, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient, split products

@@ -245,6 +245,9 @@ __global__ __launch_bounds__(768) void conv3d_bf16x3_fwd_ws_kernel(const float* 
   bool first_item = true;
   int item_no = -1;
   (void)item_no;
+  Bf3RunStats<NBT> run;                  // InstanceNorm statistics of this workgroup's outputs (g.stats, conv_bf16x3.h)
+  run.reset();
+  int my_sample = -1;
   while (tile < g.ntiles) {
     int ntile = tile, nchunk = chunk + 1;
     if (nchunk == g.nchunks) { nchunk = 0; ntile = next_tile(tile); }
@@ -335,6 +338,8 @@ __global__ __launch_bounds__(768) void conv3d_bf16x3_fwd_ws_kernel(const float* 
       for (int j = 0; j < NBT; ++j) {
         const int co = n0 + j * 16 + lr;
         const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+        float sv[16];
+        bool sok[4] = {false, false, false, false};
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
           int gz, gy, gx;
@@ -344,12 +349,15 @@ __global__ __launch_bounds__(768) void conv3d_bf16x3_fwd_ws_kernel(const float* 
           } else {
             gz = z0 + wz; gy = y0 + wy + m; gx = x0 + 4 * lq;
           }
-          if (co < g.Cout && gz < g.D && gy < g.H && gx < g.W)
-            *reinterpret_cast<float4*>(yb + (long)co * DHW + gz * HW + (long)gy * g.W + gx) =
-                make_float4(acc[m][j][0] + bv, acc[m][j][1] + bv, acc[m][j][2] + bv, acc[m][j][3] + bv);
+          const float4 v = make_float4(acc[m][j][0] + bv, acc[m][j][1] + bv, acc[m][j][2] + bv, acc[m][j][3] + bv);
+          sv[4 * m] = v.x; sv[4 * m + 1] = v.y; sv[4 * m + 2] = v.z; sv[4 * m + 3] = v.w;
+          sok[m] = co < g.Cout && gz < g.D && gy < g.H && gx < g.W;
+          if (sok[m]) *reinterpret_cast<float4*>(yb + (long)co * DHW + gz * HW + (long)gy * g.W + gx) = v;
           acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (g.stats) bf3_stats_add(run, j, sv, sok, 4 * MB);
       }
+      my_sample = b;
     };
     const bool last_chunk = chunk == g.nchunks - 1;
     if (last_chunk && wid < 4) epilogue();
@@ -360,6 +368,10 @@ __global__ __launch_bounds__(768) void conv3d_bf16x3_fwd_ws_kernel(const float* 
     tile = ntile;
     chunk = nchunk;
   }
+  // (the loader waves have returned: the barrier inside counts the eight consumer waves)
+  if (g.stats)
+    bf3_stats_flush<NBT, 8>(run, reinterpret_cast<float*>(Ws + WPL * TC::ws_u4(NB)), g.stats, my_sample, g.nbatch, g.Cout, n0, (int)gridDim.x,
+                            (int)blockIdx.x, wid, lane, tid);
 }
 
 }  // namespace icl

@@ -143,31 +143,24 @@ __global__ __launch_bounds__(256) void relpos_bias_gather_kernel(const float* __
   }
 }
 
-// dtable[index[i, j]][h] += dbias[h][i][j].  Up to 343 (i, j) pairs share one table row, so a workgroup first accumulates
-// its slice of one head into an LDS copy of that head's column (ds_add_f32), then adds the non-empty rows to HBM: 32 adders per
-// address instead of 343.  grid (chunks, heads), block 256, LDS = table_rows floats.  dtable zeroed by the launcher.
-__global__ __launch_bounds__(256) void relpos_bias_scatter_kernel(const float* __restrict__ dbias, const long* __restrict__ index,
-                                                                  float* __restrict__ dtable, int n, int npad, int heads, int idx_stride,
-                                                                  int table_rows) {
-  ICL_DYN_LDS(float, tab);
-  const int h = blockIdx.y;
-  for (int t = threadIdx.x; t < table_rows; t += blockDim.x) tab[t] = 0.f;
-  __syncthreads();
-  const long total = (long)n * npad;
-  const long per = (total + gridDim.x - 1) / gridDim.x;
-  const long lo = (long)blockIdx.x * per, hi = lo + per < total ? lo + per : total;
-  const float* src = dbias + (long)h * total;
-  for (long it = lo + threadIdx.x; it < hi; it += blockDim.x) {
-    const int j = (int)(it % npad);
-    if (j >= n) continue;
-    const int i = (int)(it / npad);
-    atomicAdd(tab + index[(long)i * idx_stride + j], src[it]);
+// dtable[t][h] = sum over the (i, j) with index[i, j] == t and over the window slices of dbias[slice][h][i][j], in a FIXED order: one
+// wave per (t, h); `inv` lists the padded positions i * npad + j sorted by t (stable), `offs[t] .. offs[t + 1]` its entries; lane l
+// takes entries l, l + 64, .. and adds the slices of an entry in order, then the xor-shuffle tree.  No atomics: the bias-table
+// gradient is bit-reproducible run to run.  grid (ceil(table_rows / 4), heads), block 256.
+__global__ __launch_bounds__(256) void relpos_bias_gather_sum_kernel(const float* __restrict__ dbias, const int* __restrict__ inv,
+                                                                     const int* __restrict__ offs, float* __restrict__ dtable, int table_rows,
+                                                                     int n, int npad, int heads, int chunks) {
+  const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y;
+  if (t >= table_rows) return;
+  const long slab = (long)heads * n * npad;
+  const float* src = dbias + (long)h * n * npad;
+  float acc = 0.f;
+  for (int e = offs[t] + lane; e < offs[t + 1]; e += 64) {
+    const int pos = inv[e];
+    for (int c = 0; c < chunks; ++c) acc += src[c * slab + pos];
   }
-  __syncthreads();
-  for (int t = threadIdx.x; t < table_rows; t += blockDim.x) {
-    const float v = tab[t];
-    if (v != 0.f) atomicAdd(dtable + (long)t * heads + h, v);
-  }
+  acc = wave_sum(acc);
+  if (lane == 0) dtable[(long)t * heads + h] = acc;
 }
 
 // grid = B_ * heads workgroups of kWaThreads threads; LDS = (2 * npad * (DH + 4) + npad) * 4 bytes.
@@ -472,7 +465,7 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_kv_kernel(const fl
 // dQ and d(bias).  Waves own a (head, query block) and walk over a slice of the windows: for every window K and V are staged
 // in LDS, dS is recomputed (S^T layout), dQ of the 16 queries is written, and dS is added to a register-resident 16 x n slab
 // of d(bias), which is summed over all windows of the batch and added to HBM once at the end.
-// grid (ceil(nkb/kWaWaves), heads, chunks); LDS = (2 * npad * (DH + 4) + npad) * 4 bytes.  dbias [heads, n, npad] zeroed (may be NULL).
+// grid (ceil(nkb/kWaWaves), heads, chunks); LDS = (2 * npad * (DH + 4) + npad) * 4 bytes.  dbias [chunks, heads, n, npad] (may be NULL).
 template <int NKB, int DH, bool EXACT>
 __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_q_bias_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
                                                                      const int* __restrict__ regions, const float* __restrict__ out,
@@ -551,14 +544,17 @@ __global__ __launch_bounds__(kWaThreads) void window_attn_bwd_q_bias_kernel(cons
     }
   }
   if (!qvalid || !dbias) return;
-  float* drow = dbias + ((long)h * g.n + query) * g.npad;
+  // this window slice's OWN slab dbias[blockIdx.z][h][query][.]: plain stores, every (query, key) written exactly once; the slabs are
+  // summed in a fixed order by relpos_bias_gather_sum_kernel (round 4: the float atomics here were the last run-to-run non-determinism
+  // of the SwinUNETR step)
+  float* drow = dbias + (((long)blockIdx.z * g.heads + h) * g.n + query) * g.npad;
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
     if (EXACT || kb < nkb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = kb * 16 + lg * 4 + r;
-        if (k < g.n) atomicAdd(drow + k, acc[kb][r]);
+        if (k < g.n) drow[k] = acc[kb][r];
       }
     }
   }

@@ -58,6 +58,10 @@ class ConvBlock(nn.Sequential):
         super().__init__(Conv3d(cin, cout, 3, device=device, kaiming_normal=True, feeds_instance_norm=True),
                          InstanceNormReLU(), _Identity())
 
+    def forward(self, x):
+        # the three children as ONE operator: the convolution's epilogue hands the normalisation its statistics (ops.py)
+        return ops.conv3d_instance_norm_act(x, self[0].weight, self[0].bias, act=1)
+
 
 class UnetConv3(nn.Module):
     """Two ConvBlocks (networks/utils.py:99-123)."""

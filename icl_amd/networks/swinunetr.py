@@ -328,10 +328,10 @@ class UnetResBlock(nn.Module):
             self.conv3 = _ConvOnly(cin, cout, 1, device=device)
 
     def forward(self, x):
-        out = ops.instance_norm_act(self.conv1(x), act=2)
-        out = self.conv2(out)
+        # conv -> InstanceNorm -> act as one operator each: the convolution's epilogue hands the normalisation its statistics (ops.py)
+        out = ops.conv3d_instance_norm_act(x, self.conv1.conv.weight, None, act=2)
         res = ops.instance_norm_act(self.conv3(x), act=0) if self.downsample else x
-        return ops.instance_norm_add_act(out, res, act=2)
+        return ops.conv3d_instance_norm_add_act(out, self.conv2.conv.weight, res, act=2)
 
 
 class UnetrBasicBlock(nn.Module):

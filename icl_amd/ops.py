@@ -314,8 +314,10 @@ class PackedWeights:
             e[7] = True
 
 
-def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_bstride, wsplit=None):
-    """``wsplit``: the pack's bf16 planes when the step's PackedWeights.begin_step() has split them already."""
+def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_bstride, wsplit=None, want_stats=False):
+    """``wsplit``: the pack's bf16 planes when the step's PackedWeights.begin_step() has split them already.
+    ``want_stats``: returns the InstanceNorm statistics of y — [n * cout, slots, 3] (count, mean, M2) summaries written by the
+    convolution's epilogue (icl_conv3d_fwd_presplit_stats) — or None when this shape / path does not produce them."""
     L = _lib.lib()
     s = d * h * w
     # algorithmic work of this launch (SURVEY.md Appendix B): 2*taps*Cin*Cout FLOP per voxel; 4*(I+O+W) bytes
@@ -324,6 +326,15 @@ def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_b
     need = L.icl_conv3d_fwd_ws_bytes(n, cin, cout, d, h, w, ks)
     ws = _ws(need, x) if need else None
     with _timed("conv3d_mfma_fwd_kernel", flops, nbytes, x):
+        if want_stats and wsplit is not None and ks == 3 and os.environ.get("ICL_CONV_STATS", "1") != "0":
+            slots = L.icl_conv3d_fwd_stats_slots(n, cin, cout, d, h, w)
+            if slots > 0:
+                stats = torch.empty((n * cout, slots, 3), dtype=torch.float32, device=x.device)
+                rc = L.icl_conv3d_fwd_presplit_stats(_ptr(x), _ptr(wsplit), _ptr(bias), _ptr(y), _ptr(stats), n, cin, cout, d, h, w,
+                                                     x_bstride, y_bstride, _stream(x))
+                if rc != 1:
+                    _lib.check(rc, "conv3d_fwd_presplit_stats")
+                    return stats
         if wsplit is not None and ks == 3:
             rc = L.icl_conv3d_fwd_presplit(_ptr(x), _ptr(wsplit), _ptr(bias), _ptr(y), n, cin, cout, d, h, w, x_bstride, y_bstride, _stream(x))
             if rc != 1:         # 1: this shape does not run on the split-product kernel -> the fp32 pack below
@@ -352,7 +363,19 @@ CONV1X1_SMALL_MAX_CHANNELS = 16       # 1x1x1 convolutions with <= 16 -> <= 16 c
 
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, zero_bias_grad=False):
+    def forward(ctx, x, weight, bias, zero_bias_grad=False, want_stats=False):
+        """want_stats: returns (y, stats) — stats = the InstanceNorm summaries of y from the convolution's epilogue, or an empty
+        tensor when this call did not produce them (the normalisation then runs its own statistics pass)."""
+        y = _Conv3d._forward(ctx, x, weight, bias, zero_bias_grad, want_stats)
+        if not want_stats:
+            return y
+        stats = ctx.stats if getattr(ctx, "stats", None) is not None else torch.empty(0, dtype=torch.float32, device=x.device)
+        ctx.stats = None
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def _forward(ctx, x, weight, bias, zero_bias_grad, want_stats):
         _require(x, weight, bias)
         x = x.contiguous()
         weight = weight.contiguous()
@@ -398,11 +421,11 @@ class _Conv3d(torch.autograd.Function):
                 PackedWeights.note_volume(weight, s)
         else:
             wp = pack_weights(weight, 0)
-        conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, cin * s, y, cout * s, wsplit=wsf)
+        ctx.stats = conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, cin * s, y, cout * s, wsplit=wsf, want_stats=want_stats)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gstats=None):
         x, weight = ctx.saved_tensors
         L = _lib.lib()
         gy = gy.contiguous()
@@ -463,7 +486,7 @@ class _Conv3d(torch.autograd.Function):
                 with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):
                     _lib.check(L.icl_conv3d_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin, cout, d, h, w, ks,
                                                   cin * s, cout * s, _stream(x)), "conv3d_wgrad")
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 class _Im2Col3(torch.autograd.Function):
@@ -512,13 +535,27 @@ def conv3d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return _Conv3d.apply(x, weight, bias, zero_bias_grad)
 
 
+def conv3d_instance_norm_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 1, eps: float = 1e-5):
+    """Conv3d(k=3, pad=1) -> InstanceNorm3d(affine=False) -> act (1 = ReLU): the block of UnetConv3
+    (/root/reference/code/networks/utils.py:104-106).  Where the convolution runs on the split-product kernels inside a trainer step,
+    its epilogue hands the normalisation the per-(sample, channel) statistics and the stand-alone statistics pass is skipped; everywhere
+    else this is conv3d followed by instance_norm_act."""
+    if (weight.shape[2] == 3 and x.shape[2] * x.shape[3] * x.shape[4] <= SMALL_CONV_MAX_VOXELS
+            and weight.numel() >= SMALL_CONV_MIN_WEIGHTS):
+        return _NormAct.apply(_conv3d_tiny_volume(x, weight, bias), None, None, None, None, 0, True, int(act), eps, 0.0, None)
+    y, stats = _Conv3d.apply(x, weight, bias, True, True)
+    return _NormAct.apply(y, None, None, None, None, 0, True, int(act), eps, 0.0, stats if stats.numel() else None)
+
+
 # --------------------------------------------------------------------------------------
 # InstanceNorm3d / BatchNorm3d (+ReLU) — networks/utils.py:105-109, unet_3D_icl.py:325-340
 # --------------------------------------------------------------------------------------
 
 class _NormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, mode, use_batch_stats, act, eps, momentum):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, mode, use_batch_stats, act, eps, momentum, stats=None):
+        """stats: [rows, slots, 3] (count, mean, M2) summaries of x written by its producer (conv3d_forward_raw) — the statistics
+        pass over x is skipped."""
         _require(x, gamma, beta, running_mean, running_var)
         L = _lib.lib()
         x = x.contiguous()
@@ -537,8 +574,14 @@ class _NormAct(torch.autograd.Function):
             rstd = torch.empty(groups, dtype=torch.float32, device=x.device)
             _lib.check(L.icl_rstd_from_var(_ptr(running_var), _ptr(rstd), c, eps, _stream(x)), "rstd_from_var")
             rm = rv = None
-        _lib.check(L.icl_norm_fwd(_ptr(x), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv),
-                                  n, c, s, mode, int(use_batch_stats), act, eps, momentum, _ptr(ws), _stream(x)), "norm_fwd")
+        if stats is not None and use_batch_stats:
+            assert mode == 0 and stats.shape[0] == n * c and stats.is_contiguous()
+            _lib.check(L.icl_norm_fwd_given_stats(_ptr(x), None, _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv),
+                                                  n, c, s, mode, act, eps, momentum, _ptr(stats), stats.shape[1], _stream(x)),
+                       "norm_fwd_given_stats")
+        else:
+            _lib.check(L.icl_norm_fwd(_ptr(x), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv),
+                                      n, c, s, mode, int(use_batch_stats), act, eps, momentum, _ptr(ws), _stream(x)), "norm_fwd")
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.cfg = (mode, int(use_batch_stats), act)
         return y
@@ -559,7 +602,7 @@ class _NormAct(torch.autograd.Function):
         ws = _ws(L.icl_norm_ws_bytes(n, c, s), x)
         _lib.check(L.icl_norm_bwd(_ptr(gy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(gx), _ptr(dg),
                                   _ptr(db), n, c, s, mode, ubs, act, _ptr(ws), _stream(x)), "norm_bwd")
-        return gx, dg, db, None, None, None, None, None, None, None
+        return gx, dg, db, None, None, None, None, None, None, None, None
 
 
 def instance_norm_relu(x: torch.Tensor, relu: bool = True, eps: float = 1e-5) -> torch.Tensor:
@@ -577,7 +620,7 @@ class _InstanceNormAddAct(torch.autograd.Function):
     produces both gx and gres)."""
 
     @staticmethod
-    def forward(ctx, x, res, act, eps):
+    def forward(ctx, x, res, act, eps, stats=None):
         _require(x, res)
         L = _lib.lib()
         x, res = x.contiguous(), res.contiguous()
@@ -585,11 +628,16 @@ class _InstanceNormAddAct(torch.autograd.Function):
         n, c = x.shape[0], x.shape[1]
         s = x.numel() // (n * c)
         y = torch.empty_like(x)
-        ws = _ws(L.icl_norm_ws_bytes(n, c, s), x)
         mean = torch.empty(n * c, dtype=torch.float32, device=x.device)
         rstd = torch.empty(n * c, dtype=torch.float32, device=x.device)
-        _lib.check(L.icl_norm_res_fwd(_ptr(x), _ptr(res), _ptr(y), _ptr(mean), _ptr(rstd), None, None, None, None, n, c, s, 0, 1, act,
-                                      eps, 0.0, _ptr(ws), _stream(x)), "norm_res_fwd")
+        if stats is not None:       # the producing convolution's epilogue wrote the (count, mean, M2) summaries (conv3d_forward_raw)
+            assert stats.shape[0] == n * c and stats.is_contiguous()
+            _lib.check(L.icl_norm_fwd_given_stats(_ptr(x), _ptr(res), _ptr(y), _ptr(mean), _ptr(rstd), None, None, None, None, n, c, s, 0, act,
+                                                  eps, 0.0, _ptr(stats), stats.shape[1], _stream(x)), "norm_fwd_given_stats")
+        else:
+            ws = _ws(L.icl_norm_ws_bytes(n, c, s), x)
+            _lib.check(L.icl_norm_res_fwd(_ptr(x), _ptr(res), _ptr(y), _ptr(mean), _ptr(rstd), None, None, None, None, n, c, s, 0, 1, act,
+                                          eps, 0.0, _ptr(ws), _stream(x)), "norm_res_fwd")
         ctx.save_for_backward(x, res, mean, rstd)
         ctx.act = act
         return y
@@ -606,11 +654,21 @@ class _InstanceNormAddAct(torch.autograd.Function):
         ws = _ws(L.icl_norm_ws_bytes(n, c, s), x)
         _lib.check(L.icl_norm_res_bwd(_ptr(gy), _ptr(x), _ptr(res), _ptr(mean), _ptr(rstd), None, None, _ptr(gx), _ptr(gres), None,
                                       None, n, c, s, 0, 1, ctx.act, _ptr(ws), _stream(x)), "norm_res_bwd")
-        return gx, gres, None, None
+        return gx, gres, None, None, None
 
 
 def instance_norm_add_act(x: torch.Tensor, res: torch.Tensor, act: int = 2, eps: float = 1e-5) -> torch.Tensor:
     return _InstanceNormAddAct.apply(x, res, int(act), eps)
+
+
+def conv3d_instance_norm_add_act(x: torch.Tensor, weight: torch.Tensor, res: torch.Tensor, act: int = 2, eps: float = 1e-5) -> torch.Tensor:
+    """act(InstanceNorm3d(Conv3d(x)) + res): the second half of MONAI's UnetResBlock (swinunetr_icl.py:128-229), the convolution's
+    epilogue handing the normalisation its statistics where it can (see conv3d_instance_norm_act)."""
+    if (weight.shape[2] == 3 and x.shape[2] * x.shape[3] * x.shape[4] <= SMALL_CONV_MAX_VOXELS
+            and weight.numel() >= SMALL_CONV_MIN_WEIGHTS):
+        return _InstanceNormAddAct.apply(_conv3d_tiny_volume(x, weight, None), res, int(act), eps)
+    y, stats = _Conv3d.apply(x, weight, None, True, True)
+    return _InstanceNormAddAct.apply(y, res, int(act), eps, stats if stats.numel() else None)
 
 
 def batch_norm_relu(x, gamma, beta, running_mean, running_var, training: bool, relu: bool = True,
@@ -1466,6 +1524,29 @@ def gather_rows_dup(src: torch.Tensor, idx: torch.Tensor, idx_back2: torch.Tenso
     return _GatherRowsDup.apply(src, idx, idx_back2)
 
 
+_RELPOS_INV = {}
+
+
+def _relpos_inverse(index: torch.Tensor, n: int, table_rows: int):
+    """(inv, offs) of ``relative_position_index[:n, :n]``: the padded positions i * npad + j sorted by table row (stable) and the
+    row offsets — what icl_relpos_bias_bwd_sum walks to add the bias gradient in a fixed order.  Built once per (index buffer, n) on the
+    host (a buffer that never changes); the first call must not happen under graph capture (every trainer warms up eagerly)."""
+    key = (index.data_ptr(), int(index._version), n, table_rows, str(index.device))
+    hit = _RELPOS_INV.get(key)
+    if hit is None:
+        if index.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("icl_amd window attention: the inverse of relative_position_index must be built before graph capture "
+                               "(run one eager backward first)")
+        npad = (n + 15) // 16 * 16
+        idx = index[:n, :n].reshape(-1).to("cpu", torch.int64)
+        order = torch.argsort(idx, stable=True)
+        inv = ((order // n) * npad + order % n).to(torch.int32)
+        offs = torch.zeros(table_rows + 1, dtype=torch.int64)
+        offs[1:] = torch.cumsum(torch.bincount(idx, minlength=table_rows), 0)
+        hit = _RELPOS_INV[key] = (inv.to(index.device), offs.to(torch.int32).to(index.device))
+    return hit
+
+
 class _WindowAttention(torch.autograd.Function):
     """One fused MFMA kernel per direction (csrc/kernels/winattn.h): scores, bias, shift mask, softmax and P@V never leave
     the CU; backward recomputes the scores from the saved log-sum-exp.  The relative-position bias is gathered from the
@@ -1507,7 +1588,9 @@ class _WindowAttention(torch.autograd.Function):
         b_, n, _ = qkv.shape
         dqkv = torch.empty_like(qkv)
         need_table = ctx.needs_input_grad[1]
-        dbias = torch.empty_like(bias_pad) if need_table else None
+        chunks = L.icl_window_attn_bwd_chunks(b_, n, heads, nw, dh) if need_table else 0
+        # one d(bias) slab per slice of windows (plain stores), summed in a fixed order below: no float atomics
+        dbias = torch.empty((chunks,) + tuple(bias_pad.shape), dtype=torch.float32, device=qkv.device) if need_table else None
         flops = 14.0 * b_ * heads * n * n * dh
         with _timed("window_attn_bwd_kernel", flops, 4.0 * (2 * qkv.numel() + 2 * out.numel()), qkv):
             _lib.check(L.icl_window_attn_bwd(_ptr(qkv), _ptr(bias_pad), _ptr(regions), _ptr(out), _ptr(lse), _ptr(gout), _ptr(dqkv),
@@ -1515,8 +1598,9 @@ class _WindowAttention(torch.autograd.Function):
         dtable = None
         if need_table:
             dtable = torch.empty((trows, heads), dtype=torch.float32, device=qkv.device)
-            _lib.check(L.icl_relpos_bias_bwd(_ptr(dbias), _ptr(index), _ptr(dtable), trows, n, heads, index.shape[0], _stream(qkv)),
-                       "relpos_bias_bwd")
+            inv, offs = _relpos_inverse(index, n, trows)
+            _lib.check(L.icl_relpos_bias_bwd_sum(_ptr(dbias), chunks, _ptr(inv), _ptr(offs), _ptr(dtable), trows, n, heads, _stream(qkv)),
+                       "relpos_bias_bwd_sum")
         return dqkv, dtable, None, None, None, None
 
 

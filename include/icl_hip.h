@@ -62,6 +62,15 @@ int icl_conv3d_split_weights_multi(const void* const* wp, void* const* wsplit, c
                                    void* stream);
 int icl_conv3d_fwd_presplit(const float* x, const void* wsplit, const float* bias, float* y, int n, int cin, int cout, int d, int h, int w,
                             int64_t x_bstride, int64_t y_bstride, void* stream);
+/* Convolution + the InstanceNorm statistics of its output from the epilogue's registers (reference: Conv3d -> InstanceNorm3d,
+ * /root/reference/code/networks/utils.py:104-105, :107-108) — the stand-alone statistics pass of icl_norm_fwd re-reads the whole output.
+ * icl_conv3d_fwd_stats_slots: the number of (count, mean, M2) summaries per (sample, channel) the launch will write (= its workgroup
+ * count), or 0 when the shape cannot produce them (not on the split-product kernel, or a workgroup's tile list would span two samples):
+ * the caller then runs icl_conv3d_fwd_presplit + icl_norm_fwd.  stats: n * cout * slots * 3 floats, every element written.
+ * icl_conv3d_fwd_presplit_stats returns 1 — nothing launched — under the same conditions as icl_conv3d_fwd_presplit. */
+int icl_conv3d_fwd_stats_slots(int n, int cin, int cout, int d, int h, int w);
+int icl_conv3d_fwd_presplit_stats(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int n, int cin, int cout,
+                                  int d, int h, int w, int64_t x_bstride, int64_t y_bstride, void* stream);
 int icl_conv3d_fwd(const float* x, const float* wp, const float* bias, float* y, void* ws, int n, int cin, int cout, int d, int h,
                    int w, int ks, int64_t x_bstride, int64_t y_bstride, void* stream);
 /* gw[cout][cin][taps] = sum over batch and voxels; ws >= icl_conv3d_wgrad_ws_bytes(n,cin,cout,ks) bytes (one packed
@@ -84,6 +93,11 @@ int icl_norm_bwd(const float* gy, const float* x, const float* mean, const float
 /* Same, with a residual branch: y = act(norm(x) + res) and, backward, gres = act'(.) * gy next to gx.  This is the tail of
  * MONAI 1.0.1 UnetResBlock.forward ("out = norm2(conv2(.)); out += residual; out = lrelu(out)") used by every encoder/decoder
  * block of SwinUNETR (networks/swinunetr_icl.py:123-223).  res / gres may be NULL (then identical to icl_norm_fwd/_bwd). */
+/* icl_norm_res_fwd with batch statistics taken from `part` — nslots (count, mean, M2) summaries per (sample, channel) row, layout
+ * part[(row * nslots + slot) * 3], as icl_conv3d_fwd_presplit_stats writes them — instead of a statistics pass over x. */
+int icl_norm_fwd_given_stats(const float* x, const float* res, float* y, float* mean, float* rstd, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, int n, int c, int64_t s, int mode, int act, float eps,
+                             float momentum, const float* part, int nslots, void* stream);
 int icl_norm_res_fwd(const float* x, const float* res, float* y, float* mean, float* rstd, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, int n, int c, int64_t s, int mode, int use_batch_stats,
                      int act, float eps, float momentum, void* ws, void* stream);
@@ -273,19 +287,25 @@ int icl_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* gbias, 
  * regions int32 [nW, n] or NULL: region id of every token of the rolled volume; query/key pairs with different ids get -100
  *      (the dense attn_mask of compute_mask, :979-1016, is exactly -100 * (id_i != id_j))
  * out [B_, n, heads*head_dim];  lse [B_, heads, n] = log-sum-exp of every score row (saved for backward).
- * Backward: dqkv (layout of qkv) and, if dbias != NULL, dbias [heads, n, npad] summed over all B_ windows (zeroed by the callee). */
+ * Backward: dqkv (layout of qkv) and, if dbias != NULL, dbias [chunks, heads, n, npad]: one slab per slice of the B_ windows
+ * (icl_window_attn_bwd_chunks), to be summed by icl_relpos_bias_bwd_sum. */
 int64_t icl_window_attn_bias_elems(int n, int heads);
 /* bias[h][i][j] = table[index[i*idx_stride + j]][h] (j < n), -1e30 (n <= j < npad): the gather of :733-737 into the padded layout;
  * index = the int64 relative_position_index buffer [idx_stride, idx_stride] (343 x 343), table [table_rows, heads].
- * Backward scatters dbias into dtable (zeroed by the callee). */
+ * Backward: icl_relpos_bias_bwd_sum below. */
 int icl_relpos_bias_fwd(const float* table, const int64_t* index, float* bias, int n, int heads, int idx_stride, void* stream);
-int icl_relpos_bias_bwd(const float* dbias, const int64_t* index, float* dtable, int64_t table_rows, int n, int heads, int idx_stride,
-                        void* stream);
 int icl_window_attn_fwd(const float* qkv, const float* bias, const int32_t* regions, float* out, float* lse, int b_, int n, int heads,
                         int nw, int head_dim, float scale, void* stream);
 int icl_window_attn_bwd(const float* qkv, const float* bias, const int32_t* regions, const float* out, const float* lse,
                         const float* dout, float* dqkv, float* dbias, int b_, int n, int heads, int nw, int head_dim, float scale,
                         void* stream);
+/* d(bias) of icl_window_attn_bwd arrives as icl_window_attn_bwd_chunks(...) slabs [chunk][heads][n][npad] (one per slice of windows,
+ * plain stores, every used element written: no zero fill).  icl_relpos_bias_bwd_sum adds them into the table gradient in a FIXED order —
+ * inv: the padded positions i * npad + j of index[:n, :n] sorted by table row (stable), offs[t] .. offs[t + 1] the entries of row t —
+ * so the gradient of relative_position_bias_table (swinunetr_icl.py:733-737) is bit-reproducible run to run. */
+int icl_window_attn_bwd_chunks(int b_, int n, int heads, int nw, int head_dim);
+int icl_relpos_bias_bwd_sum(const float* dbias, int chunks, const int32_t* inv, const int32_t* offs, float* dtable, int64_t table_rows, int n,
+                            int heads, void* stream);
 
 /* ---- on-device training augmentation: RandomRotFlip -> RandomCrop -> ToTensor of the 3-D trainers
  * (dataloaders/brats2019.py:80-147,177-189; composed at train_inherent_consistent_unet_3D_BraTS.py:66-73) as one gather over

@@ -119,8 +119,9 @@ def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root, monkeyp
         assert rel_err(model.final.weight.detach().cpu(), g["post_sgd.final.weight"]) < 1e-5
         # the first convolution's gradient is the deepest of the model (2e-2 band above); times lr = 0.01 on O(0.3) weights
         assert rel_err(model.conv1.conv1[0].weight.detach().cpu(), g["post_sgd.conv1.conv1.0.weight"]) < 1e-4
-        samples[conv_split] = {k: grads[k].detach()[::432, ::432].cpu().numpy() if k == big else grads[k].detach().cpu().numpy()
-                               for k in (big, "final.weight", "center.conv2.0.weight")}
+        # (the same subsamples the golden holds)
+        samples[conv_split] = {big: grads[big].detach()[::432, ::432].cpu().numpy(), "final.weight": grads["final.weight"].detach().cpu().numpy(),
+                               "center.conv2.0.weight": grads["center.conv2.0.weight"].detach()[::16, ::16].cpu().numpy()}
         del model, grads
         torch.cuda.empty_cache()
     # the accuracy statement proper: split products against the exact-fp32 kernels, same inputs, same everything else

@@ -1001,6 +1001,37 @@ def test_unet_icl_steps_are_bit_reproducible(dev):
     assert not differ, differ[:10]
 
 
+def test_swinunetr_icl_steps_are_bit_reproducible(dev):
+    """SwinUNETR-ICL too (round 4): the gradient of relative_position_bias_table — summed over all windows of a head — was the last
+    place that added floats atomically (winattn.h); it is now per-slice slabs written with plain stores and summed in a fixed order
+    (relpos_bias_gather_sum_kernel).  Two runs of two steps from the same state end in bit-identical weights and momentum buffers."""
+    from icl_amd import ops
+    from icl_amd.networks.swinunetr_icl import SwinUNETR_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    vol = synthetic_volume((2, 1, 96, 96, 96), 93).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 94, 2).to(dev)
+    runs = []
+    for _ in range(2):
+        ops.StepRNG.tensor = None
+        torch.manual_seed(20241003)
+        model = SwinUNETR_icl(img_size=(96, 96, 96), in_channels=1, out_channels=2, feature_size=48, device=dev)
+        fill_like_reference_init(list(model.named_parameters()))
+        model.train()
+        tr = ICLTrainer(model, ICLConfig(num_classes=2, labeled_bs=1, max_iterations=10))
+        losses = [tr.step(vol, lab)["loss"].clone() for _ in range(2)]
+        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        for k, p in model.named_parameters():
+            if p in tr.optimizer.state:
+                state["momentum " + k] = tr.optimizer.state[p]["momentum_buffer"].clone()
+        runs.append((losses, state))
+        del tr, model
+        torch.cuda.empty_cache()
+    (la, sa), (lb, sb) = runs
+    assert all(torch.equal(x, y) for x, y in zip(la, lb)), (la, lb)
+    differ = [k for k in sa if not torch.equal(sa[k], sb[k])]
+    assert not differ, differ[:10]
+
+
 def _split_operands(kind, cin, cout, r, seed):
     """Operand classes for the split-product accuracy tests: N(0,1); all-positive (post-ReLU activations x |weights|: the dropped
     product terms of a truncation split would add up coherently here); magnitudes mixed over 1e-15 .. 1e15 per channel (the split

@@ -102,6 +102,51 @@ def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w, variant)
     assert e1 <= 3.0 * e0 + 2e-7 * float(ref.abs().max()), (e1, e0)
 
 
+@pytest.mark.parametrize("n,cin,cout,d,h,w", [
+    (2, 16, 16, 8, 8, 16),      # one cout block: the loader-wave kernel; two samples, one XCD share each... (16 tiles: 2 per XCD)
+    (1, 32, 40, 5, 9, 20),      # three cout blocks (ragged), partial tiles in z / y / x: values outside the volume must not be counted
+    (2, 16, 32, 4, 8, 24),      # rows of 24 voxels: the flat tile, two cout blocks
+    (3, 16, 16, 12, 8, 16),     # 3 samples x 3 tiles on eight XCD shares of 2 tiles: a workgroup would span two samples -> refused
+])
+def test_conv3d_hands_instance_norm_its_statistics(monkeypatch, n, cin, cout, d, h, w):
+    """conv_bf16x3.h bf3_stats_*: the forward kernels write one (count, mean, M2) summary per (sample, channel, workgroup) from the
+    epilogue's registers; icl_norm_fwd_given_stats merges them instead of re-reading the output.  Reference: Conv3d -> InstanceNorm3d ->
+    ReLU (networks/utils.py:104-106)."""
+    import ctypes
+    monkeypatch.delenv("ICL_CONV_SPLIT_V", raising=False)
+    monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
+    monkeypatch.setenv("ICL_CONV_SPLIT", "1")
+    L = _lib.lib()
+    x = _rand((n, cin, d, h, w), 21) + 0.5                      # a non-zero mean: the summaries must carry it
+    wt = _rand((cout, cin, 3, 3, 3), 22) * 0.2
+    b = _rand((cout,), 23)
+    wp = ops.pack_weights(wt, 0)
+    wsplit = torch.empty(L.icl_conv3d_split_ws_bytes(cin, cout) // 4, dtype=torch.float32)
+    arr, iarr = ctypes.c_void_p * 1, ctypes.c_int32 * 1
+    _lib.check(L.icl_conv3d_split_weights_multi(arr(wp.data_ptr()), arr(wsplit.data_ptr()), iarr(cin), iarr(cout), 1, None), "split")
+    s = d * h * w
+    y = torch.empty((n, cout, d, h, w))
+    stats = ops.conv3d_forward_raw(x, wp, b, n, cin, cout, d, h, w, 3, cin * s, y, cout * s, wsplit=wsplit, want_stats=True)
+    ref = F.conv3d(x.double(), wt.double(), b.double(), padding=1)
+    assert float((y.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    if n == 3:
+        assert stats is None and L.icl_conv3d_fwd_stats_slots(n, cin, cout, d, h, w) == 0
+        return
+    assert stats is not None and stats.shape[0] == n * cout and stats.shape[2] == 3
+    cnt = stats[:, :, 0].double().sum(1)
+    assert torch.equal(cnt, torch.full_like(cnt, float(s)))     # every voxel counted once, nothing outside the volume
+    mean = (stats[:, :, 0].double() * stats[:, :, 1].double()).sum(1) / s
+    yd = y.double().reshape(n * cout, s)
+    assert torch.allclose(mean, yd.mean(1), rtol=0, atol=1e-6)
+    m2 = (stats[:, :, 2].double() + stats[:, :, 0].double() * (stats[:, :, 1].double() - mean[:, None]) ** 2).sum(1)
+    assert torch.allclose(m2 / s, yd.var(1, unbiased=False), rtol=1e-5, atol=1e-8)
+    # the normalisation from the summaries == the normalisation with its own statistics pass == torch
+    out = ops._NormAct.apply(y, None, None, None, None, 0, True, 1, 1e-5, 0.0, stats)
+    own = ops.instance_norm_relu(y)
+    want = F.relu(F.instance_norm(ref.float()))
+    assert float((out - own).abs().max()) < 2e-6 and float((out - want).abs().max()) < 2e-5
+
+
 def test_conv3d_forced_big_tile(monkeypatch):
     monkeypatch.setenv("ICL_CONV_FORCE_TILE", "48")
     _conv_check(1, 16, 16, 6, 8, 16, 3)
