@@ -60,6 +60,11 @@ __device__ __forceinline__ uint4 icl_buffer_load_u32x4(icl_rsrc_t r, unsigned by
   const u32x4v v = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ uint4 icl_buffer_load_u32x4(icl_rsrc_t r, unsigned byte_off, unsigned uniform_off) {
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  const u32x4v v = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, (int)uniform_off, 0));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 // ... with a wave-uniform byte offset on top (the instruction's scalar offset operand: no VALU add per load).  An out-of-range
 // lane offset (>= the descriptor's extent) returns 0 whatever the scalar part is.
 __device__ __forceinline__ float icl_buffer_load_f32(icl_rsrc_t r, unsigned byte_off, unsigned uniform_off) {

@@ -287,6 +287,13 @@ static inline uint4 icl_buffer_load_u32x4(icl_rsrc_t r, unsigned byte_off) {
   if ((uint64_t)byte_off + 16 <= r.bytes) memcpy(&v, r.p + byte_off, 16);
   return v;
 }
+static inline uint4 icl_buffer_load_u32x4(icl_rsrc_t r, unsigned byte_off, unsigned uniform_off) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if ((uint64_t)byte_off + 16 > r.bytes) return v;
+  if ((uint64_t)byte_off + uniform_off + 16 > r.bytes) { fprintf(stderr, "hipemu: buffer load past the descriptor through the scalar offset\n"); abort(); }
+  memcpy(&v, r.p + byte_off + uniform_off, 16);
+  return v;
+}
 // LDS-DMA (device_env_hip.h): each lane's 16 bytes land at lds_wave_base + 16 lane.  A lane outside the extent aborts: the kernels
 // must point such lanes at their zero block (the product does not rely on the hardware's range-check result for LDS-DMA).
 static inline void icl_buffer_load_lds_b128(icl_rsrc_t r, void* lds_wave_base, unsigned byte_off, unsigned uniform_off) {
