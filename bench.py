@@ -119,7 +119,7 @@ def self_launch(args, argv) -> int:
     the launcher's."""
     import socket
     import subprocess
-    if not args.launcher_selftest:
+    if not args.launcher_selftest and os.environ.get("ICL_BENCH_SHARE_GPU") != "1":
         have = torch.cuda.device_count()
         if have < args.gpus:
             print(f"bench.py --gpus {args.gpus}: this node shows {have} HIP device(s); one rank per GPU is the only supported "
@@ -200,6 +200,13 @@ def main():
         raise SystemExit(launcher_selftest(args, world, rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the product path has no CPU fallback")
+    # ICL_BENCH_SHARE_GPU=1 (with ICL_BENCH_BACKEND=gloo): every rank on device 0 — a REHEARSAL of the multi-rank code path (calibration,
+    # three-graph capture, eager collectives between the replays, MAX-over-ranks timing, the plan on the JSON line) on a one-GPU box; RCCL
+    # refuses two ranks on one device, gloo stages through the host: the numbers of such a run mean nothing and the line says so
+    share = os.environ.get("ICL_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("ICL_BENCH_BACKEND", "nccl")
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -217,8 +224,10 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        else:
+        elif backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     torch.manual_seed(1337 + rank)
     nc = args.num_classes
@@ -461,6 +470,8 @@ def main():
             "config": {"workload": f"{'SwinUNETR' if args.model == 'swinunetr_icl' else '3D U-Net'} ICL BraTS-shape synthetic 96x96x96, num_classes={nc}, "
                                    f"batch=2 per GPU (1 labeled + 1 unlabeled), full ICL step incl. SGD",
                        "global_batch": 2 * world, "parallelism": f"dp{world}",
+                       **({"rehearsal": "every rank on ONE device over gloo (ICL_BENCH_SHARE_GPU=1): exercises the multi-rank code path, "
+                                        "the timing is meaningless"} if share else {}),
                        **({"rccl_ranks": torch.distributed.get_world_size(), "collective_backend": torch.distributed.get_backend(),
                            "ddp_plan": {"rates": ddp.rates, "matrices": ddp.last_plan}}
                           if use_ddp else {}),

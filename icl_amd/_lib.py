@@ -49,6 +49,7 @@ _SIGNATURES = {
     "icl_rstd_from_var": (c_int, [P, P, I, F, P]),
     "icl_maxpool2_fwd": (c_int, [P, P, P, L, I, I, I, I, P]),
     "icl_maxpool2_bwd": (c_int, [P, P, P, L, I, I, I, I, P]),
+    "icl_maxpool2_bwd_add": (c_int, [P, P, P, P, I, I, I, I, I, I, L, P]),
     "icl_trilinear_fwd": (c_int, [P, P, I, I, I, I, I, I, I, I, L, I, P]),
     "icl_trilinear_bwd_ws_bytes": (c_int64, [I, I, I, I, I, I, I, I]),
     "icl_trilinear_bwd": (c_int, [P, P, P, I, I, I, I, I, I, I, I, L, I, P]),

@@ -57,6 +57,37 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
   }
 }
 
+// gx = add + scatter(gy): the gradient of a tensor that feeds BOTH a max-pool and a skip connection (conv1 .. conv4 of the 3D U-Net,
+// /root/reference/code/networks/unet_3D_icl.py:100-116: `maxpool(conv)` and `up_concat(conv, .)`) in one pass — autograd would run the
+// pooling backward (a full write of gx) and then add the skip gradient (two full reads, one write).  `add` is the skip gradient:
+// [N][C] planes of the pooled-from extent, batches add_bstride apart (a channel slice of the concat gradient).
+__global__ __launch_bounds__(256) void maxpool2_bwd_add_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ idx,
+                                                               const float* __restrict__ add, float* __restrict__ gx, long NC, int C, int Do,
+                                                               int Ho, int Wo, int pd, long add_bstride) {
+  const long total = NC * Do * Ho * Wo;
+  const int H = Ho * 2, W = Wo * 2;
+  const long plane = (long)Do * pd * H * W;
+  const int nk = 4 * pd;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(o % Wo);
+    long t = o / Wo;
+    const int oy = (int)(t % Ho);
+    t /= Ho;
+    const int oz = (int)(t % Do);
+    const long nc = t / Do;
+    const long in_plane = ((long)(oz * pd) * H + oy * 2) * (long)W + ox * 2;
+    float* p = gx + nc * plane + in_plane;
+    const float* a = add + (nc / C) * add_bstride + (nc % C) * plane + in_plane;
+    const float g = gy[o];
+    const int bi = idx[o];
+    for (int k = 0; k < nk; k += 2) {
+      const long off = ((k >> 2) * H + ((k >> 1) & 1)) * (long)W;
+      const float2 s = *reinterpret_cast<const float2*>(a + off);
+      *reinterpret_cast<float2*>(p + off) = make_float2(s.x + (bi == k ? g : 0.f), s.y + (bi == k + 1 ? g : 0.f));
+    }
+  }
+}
+
 // ---- linear interpolation taps along one axis, ATen's area_pixel_compute_source_index:
 //   align_corners=False: src = rscale*(dst+0.5)-0.5 clamped at 0, rscale = in/out
 //   align_corners=True : src = rscale*dst,                         rscale = (in-1)/(out-1)  (0 when out == 1)

@@ -147,6 +147,20 @@ __global__ __launch_bounds__(256) void relpos_bias_gather_kernel(const float* __
 // wave per (t, h); `inv` lists the padded positions i * npad + j sorted by t (stable), `offs[t] .. offs[t + 1]` its entries; lane l
 // takes entries l, l + 64, .. and adds the slices of an entry in order, then the xor-shuffle tree.  No atomics: the bias-table
 // gradient is bit-reproducible run to run.  grid (ceil(table_rows / 4), heads), block 256.
+// dbias[0][i] += dbias[1][i] + .. + dbias[chunks - 1][i], slices added in order (coalesced 16-byte accesses): the gather below then
+// reads ONE slab — its accesses are scattered (the positions of a table row lie all over the [n, npad] matrix), and scattered over
+// 16 slabs they cost 112 us per layer at stage 1 instead of ~10.  slab % 4 == 0.
+__global__ __launch_bounds__(256) void relpos_bias_slab_sum_kernel(float* __restrict__ dbias, long slab, int chunks) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < slab; i += (long)gridDim.x * blockDim.x * 4) {
+    float4 a = *reinterpret_cast<const float4*>(dbias + i);
+    for (int c = 1; c < chunks; ++c) {
+      const float4 b = *reinterpret_cast<const float4*>(dbias + c * slab + i);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    *reinterpret_cast<float4*>(dbias + i) = a;
+  }
+}
+
 __global__ __launch_bounds__(256) void relpos_bias_gather_sum_kernel(const float* __restrict__ dbias, const int* __restrict__ inv,
                                                                      const int* __restrict__ offs, float* __restrict__ dtable, int table_rows,
                                                                      int n, int npad, int heads, int chunks) {

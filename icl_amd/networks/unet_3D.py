@@ -45,11 +45,13 @@ class UNet3DBackbone(nn.Module):
         """One stream: returns (logits, [center, up4, up3]) — unet_3D_icl.py:100-117.  ``heads`` (the ICL model's aligner calls) is
         invoked on the three deep maps as soon as they exist and its result returned as a third value."""
         from .. import ops
-        c1 = self.conv1(x)
-        c2 = self.conv2(ops.max_pool3d_2(c1))
-        c3 = self.conv3(ops.max_pool3d_2(c2))
-        c4 = self.conv4(ops.max_pool3d_2(c3))
-        center = self.dropout1(self.center(ops.max_pool3d_2(c4)))
+        # every encoder output feeds its level's skip connection AND the next level's pooling: ops.skip_and_pool returns both so that
+        # the backward adds the two gradients inside the pooling backward's pass
+        c1, p1 = ops.skip_and_pool(self.conv1(x))
+        c2, p2 = ops.skip_and_pool(self.conv2(p1))
+        c3, p3 = ops.skip_and_pool(self.conv3(p2))
+        c4, p4 = ops.skip_and_pool(self.conv4(p3))
+        center = self.dropout1(self.center(p4))
         up4 = self.up_concat4(c4, center)
         up3 = self.up_concat3(c3, up4)
         extra = heads([center, up4, up3]) if heads is not None else None

@@ -735,6 +735,49 @@ class _MaxPool2(torch.autograd.Function):
         return gx, None
 
 
+class _SkipAndPool(torch.autograd.Function):
+    """(x, maxpool2(x)) for a tensor that feeds a skip connection AND the pooling of the next level: the backward adds the two
+    gradients inside the pooling backward's pass (icl_maxpool2_bwd_add) instead of a pooling backward plus an autograd `add` over the
+    full-resolution tensor.  The skip gradient may be a channel slice of a concat gradient (batch-strided view, _UpCat.backward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require(x)
+        L = _lib.lib()
+        x = x.contiguous()
+        n, c, d, h, w = x.shape
+        assert d % 2 == 0 and h % 2 == 0 and w % 2 == 0, "max-pool kernels need even extents"
+        y = torch.empty((n, c, d // 2, h // 2, w // 2), dtype=torch.float32, device=x.device)
+        idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+        _lib.check(L.icl_maxpool2_fwd(_ptr(x), _ptr(y), _ptr(idx), n * c, d // 2, h // 2, w // 2, 2, _stream(x)), "maxpool2_fwd")
+        ctx.save_for_backward(idx)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, gskip, gy):
+        (idx,) = ctx.saved_tensors
+        L = _lib.lib()
+        n, c, d, h, w = idx.shape
+        if gy is None:
+            return gskip
+        gy = gy.contiguous()
+        gx = torch.empty((n, c, d * 2, h * 2, w * 2), dtype=torch.float32, device=gy.device)
+        plane = 8 * d * h * w
+        ok = (gskip is not None and gskip.dtype == torch.float32 and tuple(gskip.shape) == tuple(gx.shape)
+              and gskip.stride()[1:] == (plane, 4 * h * w, 2 * w, 1) and gskip.stride(0) % 2 == 0 and gskip.data_ptr() % 8 == 0)
+        if ok:
+            _lib.check(L.icl_maxpool2_bwd_add(_ptr(gy), _ptr(idx), _vp(gskip.data_ptr()), _ptr(gx), n, c, d, h, w, 2, gskip.stride(0),
+                                              _stream(gy)), "maxpool2_bwd_add")
+            return gx
+        _lib.check(L.icl_maxpool2_bwd(_ptr(gy), _ptr(idx), _ptr(gx), n * c, d, h, w, 2, _stream(gy)), "maxpool2_bwd")
+        return gx if gskip is None else gx + gskip
+
+
+def skip_and_pool(x: torch.Tensor):
+    """Returns (x, MaxPool3d(2)(x)); use the FIRST output for the skip connection so that the backward can fuse the two gradients."""
+    return _SkipAndPool.apply(x)
+
+
 def max_pool3d_2(x: torch.Tensor) -> torch.Tensor:
     return _MaxPool2.apply(x, 2)
 

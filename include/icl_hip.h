@@ -110,6 +110,11 @@ int icl_rstd_from_var(const float* var, float* rstd, int c, float eps, void* str
  * D = 1 volume); idx = uint8 argmax within the pool_depth x 2 x 2 window. */
 int icl_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int64_t nc, int dout, int hout, int wout, int pool_depth, void* stream);
 int icl_maxpool2_bwd(const float* gy, const uint8_t* idx, float* gx, int64_t nc, int dout, int hout, int wout, int pool_depth, void* stream);
+/* gx = add + maxpool2 backward of gy: the gradient of a tensor that feeds both a max-pool and a skip connection
+ * (/root/reference/code/networks/unet_3D_icl.py:100-116) in one pass.  add: [n][c] planes of the un-pooled extent, batches add_bstride
+ * elements apart (a channel slice of the concat gradient). */
+int icl_maxpool2_bwd_add(const float* gy, const uint8_t* idx, const float* add, float* gx, int n, int c, int dout, int hout, int wout,
+                         int pool_depth, int64_t add_bstride, void* stream);
 
 /* ---- trilinear / bilinear (D = 1) resize (networks/utils.py:264; networks/unet_icl.py:84-85; utils/losses.py:245,263,281,292).
  * align_corners=0: source scale in/out (what ATen uses for size= and for scale_factor=2); 1: (in-1)/(out-1). */
@@ -302,9 +307,10 @@ int icl_window_attn_bwd(const float* qkv, const float* bias, const int32_t* regi
 /* d(bias) of icl_window_attn_bwd arrives as icl_window_attn_bwd_chunks(...) slabs [chunk][heads][n][npad] (one per slice of windows,
  * plain stores, every used element written: no zero fill).  icl_relpos_bias_bwd_sum adds them into the table gradient in a FIXED order —
  * inv: the padded positions i * npad + j of index[:n, :n] sorted by table row (stable), offs[t] .. offs[t + 1] the entries of row t —
- * so the gradient of relative_position_bias_table (swinunetr_icl.py:733-737) is bit-reproducible run to run. */
+ * so the gradient of relative_position_bias_table (swinunetr_icl.py:733-737) is bit-reproducible run to run.  dbias is used as scratch
+ * (the slabs are first added, in order, into slab 0). */
 int icl_window_attn_bwd_chunks(int b_, int n, int heads, int nw, int head_dim);
-int icl_relpos_bias_bwd_sum(const float* dbias, int chunks, const int32_t* inv, const int32_t* offs, float* dtable, int64_t table_rows, int n,
+int icl_relpos_bias_bwd_sum(float* dbias, int chunks, const int32_t* inv, const int32_t* offs, float* dtable, int64_t table_rows, int n,
                             int heads, void* stream);
 
 /* ---- on-device training augmentation: RandomRotFlip -> RandomCrop -> ToTensor of the 3-D trainers

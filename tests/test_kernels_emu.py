@@ -147,6 +147,26 @@ def test_conv3d_hands_instance_norm_its_statistics(monkeypatch, n, cin, cout, d,
     assert float((out - own).abs().max()) < 2e-6 and float((out - want).abs().max()) < 2e-5
 
 
+def test_skip_and_pool_adds_the_two_gradients_in_one_pass():
+    """ops.skip_and_pool (maxpool2_bwd_add_kernel): the gradient of an encoder output = its skip gradient (a batch-strided channel slice
+    of the concat gradient, as _UpCat.backward hands it over) + the pooling backward; reference: autograd on x -> (x, max_pool3d(x))."""
+    torch.manual_seed(0)
+    x = _rand((2, 3, 4, 6, 8), 31, True)
+    skip, y = ops.skip_and_pool(x)
+    gsk = _rand((2, 5, 4, 6, 8), 32)[:, :3]          # non-contiguous over the batch
+    gy = _rand(tuple(y.shape), 33)
+    torch.autograd.backward([skip, y], [gsk, gy])
+    xr = x.detach().clone().requires_grad_()
+    yr = F.max_pool3d(xr, 2)
+    torch.autograd.backward([xr * 1.0, yr], [gsk, gy])
+    assert torch.equal(y, yr) and torch.equal(x.grad, xr.grad)
+    # only one of the two consumers has a gradient
+    x2 = _rand((1, 2, 2, 4, 4), 34, True)
+    s2, y2 = ops.skip_and_pool(x2)
+    y2.sum().backward()
+    assert torch.equal(x2.grad, torch.autograd.grad(F.max_pool3d(x2, 2).sum(), x2)[0])
+
+
 def test_conv3d_forced_big_tile(monkeypatch):
     monkeypatch.setenv("ICL_CONV_FORCE_TILE", "48")
     _conv_check(1, 16, 16, 6, 8, 16, 3)
