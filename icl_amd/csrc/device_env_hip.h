@@ -81,6 +81,17 @@ __device__ __forceinline__ void icl_buffer_load_lds_b128(icl_rsrc_t r, void* lds
 }
 // every vector-memory operation of this wave (loads, stores, LDS-DMA) has completed
 #define ICL_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// ... all but the n youngest (n a literal): loads, stores and LDS-DMA of a wave retire in issue order
+#define ICL_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// Workgroup barrier that leaves vector-memory operations (LDS-DMA of a later stage, register loads) IN FLIGHT: __syncthreads() makes
+// hipcc wait vmcnt(0) while an LDS-DMA is outstanding (cdna_hip_programming.md "Pipelining across barriers").  The wave's own LDS
+// operations are complete before it arrives (lgkmcnt(0)); LDS-DMA data must have been waited for with ICL_WAIT_VMCNT by its issuer.
+#define ICL_BARRIER_KEEP_VMEM()                          \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();                        \
+    asm volatile("" ::: "memory");                       \
+  } while (0)
 
 // v_alignbit_b32: bits [sh, sh + 32) of the 64-bit value {hi, lo}
 __device__ __forceinline__ unsigned icl_alignbit(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }

@@ -301,6 +301,8 @@ static inline void icl_buffer_load_lds_b128(icl_rsrc_t r, void* lds_wave_base, u
   memcpy((unsigned char*)lds_wave_base + 16 * hipemu_lane(), r.p + byte_off + uniform_off, 16);
 }
 #define ICL_WAIT_VMEM() ((void)0)
+#define ICL_WAIT_VMCNT(n) ((void)0)
+#define ICL_BARRIER_KEEP_VMEM() __syncthreads()
 static inline float icl_fast_exp(float x) { return expf(x); }
 static inline float4 icl_nt_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static inline void icl_nt_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -11,6 +11,7 @@
 #include "kernels/conv_bf16x3.h"
 #include "probe_kernels/conv_planes.h"
 #include "kernels/conv_bf16x3_ws.h"
+#include "probe_kernels/conv_bf16x3_wsr.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -70,6 +71,21 @@ void launch_ws(const float* x, const uint4* ws, const float* bias, float* y, icl
     const size_t lds = icl::Bf3T<8>::lds_bytes(NBT, NBT == 1 ? 3 : 1);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_bf16x3_fwd_ws_kernel<NBT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL((icl::conv3d_bf16x3_fwd_ws_kernel<NBT, false>), dim3(gx, gy), dim3(768), lds, 0, x, ws, bias, y, g);
+  }
+}
+// cfg 4: conv3d_bf16x3_fwd_wsr_kernel — loader waves + NCBLK cout blocks per workgroup, weight planes through a three-slot DMA ring
+template <int NBT>
+void launch_wsr(const float* x, const uint4* ws, const float* bias, float* y, icl::Bf3Geom g, bool flat) {
+  if constexpr (NBT >= 2) {
+    const int gy = (g.CoutP + 16 * NBT - 1) / (16 * NBT);
+    const int gx = g.ntiles < 256 ? (g.ntiles + 7) / 8 * 8 : 256;
+    if (flat) {
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_bf16x3_fwd_wsr_kernel<NBT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      hipLaunchKernelGGL((icl::conv3d_bf16x3_fwd_wsr_kernel<NBT, true>), dim3(gx, gy), dim3(768), icl::Bf3F24::lds_bytes(1, 3), 0, x, ws, bias, y, g);
+    } else {
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_bf16x3_fwd_wsr_kernel<NBT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      hipLaunchKernelGGL((icl::conv3d_bf16x3_fwd_wsr_kernel<NBT, false>), dim3(gx, gy), dim3(768), icl::Bf3T<8>::lds_bytes(1, 3), 0, x, ws, bias, y, g);
+    }
   }
 }
 // cfg 0: <NBT, 8, 8, single> one workgroup per CU; 1: <1, 4, 4, single> two workgroups per CU; 2: <NBT, 4, 8, double-buffered>
@@ -141,7 +157,8 @@ int main(int argc, char** argv) {
   auto go_ws = [&]() { if (nbt == 1) launch_ws<1>(dx, dws, db, dy1, g, flat); else if (nbt == 2) launch_ws<2>(dx, dws, db, dy1, g, flat); else launch_ws<3>(dx, dws, db, dy1, g, flat); };
   // cfg 10 + f: the shipped kernel with Bf3Geom::flags = f (1 y-slowest tile order, 2 non-temporal output stores)
   auto go_flags = [&]() { icl::Bf3Geom gf = g; gf.flags = cfg - 10; if (nbt == 1) launch_old<1>(dx, dws, db, dy1, gf, flat); else if (nbt == 2) launch_old<2>(dx, dws, db, dy1, gf, flat); else launch_old<3>(dx, dws, db, dy1, gf, flat); };
-  auto go_new = [&]() { if (cfg >= 10) { go_flags(); return; } if (cfg == 3) { go_ws(); return; } if (nbt == 1) launch_new<1>(dpl, dws, db, dy1, p, flat, cfg); else if (nbt == 2) launch_new<2>(dpl, dws, db, dy1, p, flat, cfg); else launch_new<3>(dpl, dws, db, dy1, p, flat, cfg); };
+  auto go_wsr = [&]() { if (nbt == 2) launch_wsr<2>(dx, dws, db, dy1, g, flat); else if (nbt == 3) launch_wsr<3>(dx, dws, db, dy1, g, flat); };
+  auto go_new = [&]() { if (cfg >= 10) { go_flags(); return; } if (cfg == 4) { go_wsr(); return; } if (cfg == 3) { go_ws(); return; } if (nbt == 1) launch_new<1>(dpl, dws, db, dy1, p, flat, cfg); else if (nbt == 2) launch_new<2>(dpl, dws, db, dy1, p, flat, cfg); else launch_new<3>(dpl, dws, db, dy1, p, flat, cfg); };
   split(); go_old(); go_new();
   CK(hipDeviceSynchronize());
   CK(hipGetLastError());
@@ -183,7 +200,7 @@ int main(int argc, char** argv) {
   const double fl = 2.0 * 27 * cin * cout * N * S;
   printf("  shipped <%d,8,60>: median %.1f us (min %.1f) %.1f TF | planes + LDS-DMA: median %.1f us (min %.1f) %.1f TF = %.3fx | stand-alone split kernel %.1f us\n",
          nbt, med(t_old), mn(t_old), fl / med(t_old) * 1e-6, med(t_new), mn(t_new), fl / med(t_new) * 1e-6, med(t_old) / med(t_new), med(t_split));
-  if (cfg >= 10) return ndiff ? 1 : 0;
+  if (cfg >= 10 || cfg == 4) return ndiff ? 1 : 0;
   if (cfg == 3) {
     long long st[144];
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(icl::g_ws_stamps), sizeof(st)));
