@@ -369,6 +369,7 @@ class _Conv3d(torch.autograd.Function):
         y = _Conv3d._forward(ctx, x, weight, bias, zero_bias_grad, want_stats)
         if not want_stats:
             return y
+        ctx.set_materialize_grads(False)      # (no zero tensor — a fill launch per call — for the non-differentiable statistics output)
         stats = ctx.stats if getattr(ctx, "stats", None) is not None else torch.empty(0, dtype=torch.float32, device=x.device)
         ctx.stats = None
         ctx.mark_non_differentiable(stats)
@@ -426,6 +427,8 @@ class _Conv3d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, gstats=None):
+        if gy is None:
+            return None, None, None, None, None
         x, weight = ctx.saved_tensors
         L = _lib.lib()
         gy = gy.contiguous()
@@ -1005,6 +1008,7 @@ class _DropPathAdd(torch.autograd.Function):
         _lib.check(L.icl_drop_path_add(_ptr(x), _ptr(res), _ptr(y), x.numel(), group, seed, p, _ptr(seed_dev), _stream(x)), "drop_path_add")
         ctx.cfg = (p, seed, group)
         ctx.seed_dev = seed_dev
+        ctx.same = same
         return y
 
     @staticmethod
@@ -1012,6 +1016,14 @@ class _DropPathAdd(torch.autograd.Function):
         L = _lib.lib()
         p, seed, group = ctx.cfg
         gx = None
+        if ctx.same and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # x + drop_path(x) (the doubling of Class_Decoder, unet_3D_icl.py:264,266): both gradients belong to the same tensor —
+            # gy + mask * gy in the forward kernel's one pass, handed back once, instead of a mask kernel plus an autograd add
+            gy = gy.contiguous()
+            gx = torch.empty_like(gy)
+            _lib.check(L.icl_drop_path_add(_ptr(gy), _ptr(gy), _ptr(gx), gy.numel(), group, seed, p, _ptr(ctx.seed_dev), _stream(gy)),
+                       "drop_path_add_bwd")
+            return gx, None, None, None, None
         if ctx.needs_input_grad[0]:
             gy = gy.contiguous()
             gx = torch.empty_like(gy)
