@@ -138,7 +138,8 @@ class GradientReducer:
         else:
             t_ag = timed(lambda: dist.all_gather(list(buf.chunk(self.world)), mine.clone()))
         t_ar = timed(lambda: dist.all_reduce(buf))
-        self.rates = {"allgather_gbps": round(4.0 * n / t_ag / 1e9, 1), "allreduce_gbps": round(4.0 * n / t_ar / 1e9, 1), "measured": True,
+        # (a loaded host under gloo can be slower than 0.05 GB/s: keep the digits, a rate of 0.0 would divide by zero in exchange_plan)
+        self.rates = {"allgather_gbps": max(round(4.0 * n / t_ag / 1e9, 4), 1e-4), "allreduce_gbps": max(round(4.0 * n / t_ar / 1e9, 4), 1e-4), "measured": True,
                       "allgather_ms_764MB": round(t_ag * 1e3, 3), "allreduce_ms_764MB": round(t_ar * 1e3, 3)}
         del buf
         # thresholds for the 13,824^2 matrices (they are 97 % of the model) from the priced alternatives

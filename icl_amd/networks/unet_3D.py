@@ -12,6 +12,14 @@ import torch.nn as nn
 from .layers import Conv3d, Dropout3, UnetConv3, UnetUp3_CT, _Identity
 
 
+def _open_update_gate(grad):
+    from .. import ops
+    opt = ops.FactoredGrads.fused_optimizer
+    if opt is not None and hasattr(opt, "flush_deferred"):
+        opt.flush_deferred(gate=True)
+    return None
+
+
 class UNet3DBackbone(nn.Module):
     """Everything ``unet_3D`` and ``unet_3D_icl`` share (unet_3D_icl.py:28-68): 5 encoder stages,
     4 decoder stages, 1x1x1 classifier, two Dropout(0.3)."""
@@ -54,6 +62,10 @@ class UNet3DBackbone(nn.Module):
         center = self.dropout1(self.center(p4))
         up4 = self.up_concat4(c4, center)
         up3 = self.up_concat3(c3, up4)
+        if heads is not None and up3.requires_grad:
+            # backward: once up3's gradient is complete the aligners and the 48^3 / 96^3 decoder stages are done and the small deep levels
+            # follow — the point from which an optimiser with gated update placement streams its big matrices (FusedSGD.flush_deferred)
+            up3.register_hook(_open_update_gate)
         extra = heads([center, up4, up3]) if heads is not None else None
         up2 = self.up_concat2(c2, up3)
         up1 = self.dropout2(self.up_concat1(c1, up2))

@@ -27,6 +27,17 @@ class FusedSGD(torch.optim.Optimizer):
         self.lr_dev = None   # optional device scalar read by the kernels instead of group['lr'] (hipGraph replay)
         self._groups = None  # id(parameter) -> its group (update_in_backward)
         self._updated_in_backward = set()   # ids of the parameters whose update of this step already ran inside backward
+        # Where the update of a big once-used matrix runs on a single rank (update_in_backward):
+        #   "fused"  inside its backward, in the pass that computes the input gradient (one read of the matrix, 20 B/weight and step)
+        #   "gated"  the backward only computes the input gradient (4 B/weight); the update (16 B/weight) is queued on an update stream
+        #            that starts when the model opens the gate (flush_deferred() from a gradient hook where the chip-filling part of
+        #            the backward ends) and is joined in step(): 24 B/weight and step, but the HBM stream runs next to the small
+        #            deep-level kernels instead of next to the 96^3 / 48^3 convolutions (tools/critical_path.py)
+        #   "free"   like "gated" without the gate: the update stream only waits for the input-gradient kernel of its matrix
+        self.update_placement = os.environ.get("ICL_UPDATE_PLACEMENT", "fused")
+        self._deferred = []          # (parameter, g, x, event after the input-gradient kernel)
+        self._update_stream = None
+        self._update_stream_used = False
 
     def zero_grad(self, set_to_none: bool = True):
         for group in self.param_groups:
@@ -35,6 +46,9 @@ class FusedSGD(torch.optim.Optimizer):
                     p._icl_factors = None
         # a step that was skipped or failed after its backward pass must not make the next one raise "updated twice"
         self._updated_in_backward.clear()
+        if self._deferred or self._update_stream_used:
+            raise RuntimeError("FusedSGD.zero_grad(): updates queued by the previous backward pass were never applied; call step() "
+                               "after every backward pass when update_placement is 'gated' or 'free'")
         super().zero_grad(set_to_none=set_to_none)
 
     def _step_factored(self, L, p, factors, lr, mom, wd):
@@ -138,6 +152,17 @@ class FusedSGD(torch.optim.Optimizer):
         (icl_linear_dgrad_sgd).  ``step()`` then skips the parameter: it has neither a dense nor a factored gradient."""
         from . import ops
         L = _lib.lib()
+        g, x = g.contiguous(), x.contiguous()
+        if self.update_placement != "fused" and p.is_cuda:
+            gx = ops.linear_dgrad_raw(g, p)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._deferred.append((p, g, x, ev))
+            torch.autograd.graph.increment_version(p)
+            self._updated_in_backward.add(id(p))
+            if self.update_placement == "free":
+                self.flush_deferred(gate=False)
+            return gx
         group = self._group_of()[id(p)]
         lr, mom, wd = float(group["lr"]), float(group["momentum"]), float(group["weight_decay"])
         n, k = p.shape
@@ -148,7 +173,6 @@ class FusedSGD(torch.optim.Optimizer):
             st["momentum_buffer"] = torch.empty_like(p)
             first = 1
         m = st["momentum_buffer"]
-        g, x = g.contiguous(), x.contiguous()
         gx = torch.empty((rows, k), dtype=torch.float32, device=g.device)
         ws = ops._ws(L.icl_linear_ws_bytes(rows, k, n, 3), g)
         stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream) if p.is_cuda else None
@@ -164,12 +188,43 @@ class FusedSGD(torch.optim.Optimizer):
         return gx
 
     @torch.no_grad()
+    def flush_deferred(self, gate: bool = True):
+        """Queue the updates that ``update_in_backward`` deferred on the update stream.  ``gate``: the stream also waits for everything
+        queued so far on the CURRENT stream (the caller is a gradient hook at the point of the backward pass from which on the HBM is
+        idle); every update waits for the input-gradient kernel that read its matrix.  step() joins the stream."""
+        if not self._deferred:
+            return
+        L = _lib.lib()
+        dev = self._deferred[0][0].device
+        if self._update_stream is None:
+            # lowest priority: where the hardware honours it, the workgroups of the update fill the slots the step's own kernels leave
+            prio = int(os.environ.get("ICL_UPDATE_STREAM_PRIORITY", "0"))
+            self._update_stream = torch.cuda.Stream(device=dev, priority=prio)
+        s = self._update_stream
+        if gate:
+            s.wait_stream(torch.cuda.current_stream(dev))
+        for p, g, x, ev in self._deferred:
+            s.wait_event(ev)
+        with torch.cuda.stream(s):
+            for p, g, x, ev in self._deferred:
+                group = self._group_of()[id(p)]
+                self._step_factored(L, p, [(g, x)], float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]))
+                g.record_stream(s)
+                x.record_stream(s)
+        self._deferred = []
+        self._update_stream_used = True
+
+    @torch.no_grad()
     def step(self, closure=None):
         L = _lib.lib()
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self.flush_deferred(gate=True)      # a model without a gate hook: the updates start here
+        if self._update_stream_used:
+            torch.cuda.current_stream(self._update_stream.device).wait_stream(self._update_stream)
+            self._update_stream_used = False
         for group in self.param_groups:
             lr, mom, wd = float(group["lr"]), float(group["momentum"]), float(group["weight_decay"])
             small = {0: [], 1: []}
