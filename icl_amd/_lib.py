@@ -54,6 +54,7 @@ _SIGNATURES = {
     "icl_trilinear_bwd_ws_bytes": (c_int64, [I, I, I, I, I, I, I, I]),
     "icl_trilinear_bwd": (c_int, [P, P, P, I, I, I, I, I, I, I, I, L, I, P]),
     "icl_copy_rows": (c_int, [P, P, L, L, L, L, P]),
+    "icl_concat2": (c_int, [P, L, P, L, P, P]),
     "icl_dwconv3_fwd": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "icl_dwconv3_wgrad_ws_bytes": (c_int64, [I, I, I, I, I]),
     "icl_dwconv3_wgrad": (c_int, [P, P, P, P, I, I, I, I, I, P]),

@@ -138,6 +138,8 @@ __device__ __forceinline__ void icl_nt_store4(float* p, float4 v) {
 #define ICL_LAUNCH(kern, grid, block, lds, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), (lds), (stream), __VA_ARGS__)
 #define ICL_MEMSET_ASYNC(ptr, val, bytes, stream) ((void)hipMemsetAsync((ptr), (val), (bytes), (stream)))
+// address of a __device__ variable (0 on success)
+#define ICL_SYMBOL_ADDRESS(pp, sym) ((int)hipGetSymbolAddress((pp), HIP_SYMBOL(sym)))
 #define ICL_LAST_LAUNCH_ERROR() ((int)hipGetLastError())
 #define ICL_ERROR_STRING(e) hipGetErrorString((hipError_t)(e))
 // dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel (160 KiB per CU on gfx950).  Done once per

@@ -474,6 +474,18 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
   }
 }
 
+// out = [a ; b] (na + nb floats, multiples of 4); a null half is written as zeros: the gradient of a batch split of which only one part was
+// used (x[:k], x[k:] in the ICL forward) in one launch instead of a zero fill, a copy and a concatenation.
+__global__ __launch_bounds__(256) void concat2_kernel(const float* __restrict__ a, long na, const float* __restrict__ b, long nb,
+                                                      float* __restrict__ out) {
+  const long nq = (na + nb) >> 2, aq = na >> 2;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+    const float* src = q < aq ? a : b;
+    const long i = q < aq ? q : q - aq;
+    reinterpret_cast<float4*>(out)[q] = src ? reinterpret_cast<const float4*>(src)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // ---- depth-to-space / space-to-depth for ConvTranspose3d(kernel 2, stride 2) written as a GEMM (MONAI UnetrUpBlock.transp_conv):
 // the GEMM produces tokens yt[b][(z,y,x)][co*8 + i*4 + j*2 + k]; the volume is out[b][co][2z+i][2y+j][2x+k].
 // One workgroup moves one token row (b, z, y, all x): it reads W contiguous token vectors (cout*8 floats each) into LDS and

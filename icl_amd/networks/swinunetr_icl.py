@@ -41,7 +41,7 @@ class SwinUNETR_icl(SwinUNETRBackbone):  # noqa: N801 — reference class name
             # the aligners need only dec3..dec1: they run on a second stream next to the 48^3 / 96^3 decoder stages
             with ops.SideStream(feats) as side:
                 (maps_lab, qs_lab), (maps_con, _) = self.sspa.forward_labeled_pair(feats, bl)
-                maps_unlab, _ = self.uscl([t[bl:] for t in feats], qs_lab, "unlabeled")
+                maps_unlab, _ = self.uscl([ops.split_batch(t, bl)[1] for t in feats], qs_lab, "unlabeled")
             return side, maps_lab, maps_unlab, maps_con
 
         logits, _, (side, maps_lab, maps_unlab, maps_con) = self.run_backbone(torch.cat([x_lab, x_unlab], 0), heads)

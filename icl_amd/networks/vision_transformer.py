@@ -58,7 +58,7 @@ class SwinUnet(nn.Module):
         bl = x_lab.shape[0]
         out, feats = self.swin_unet.run(torch.cat([self._rgb(x_lab), self._rgb(x_unlab)], 0))
         (maps_lab, qs_lab), (maps_con, _) = self.sspa.forward_labeled_pair(feats, bl)
-        maps_unlab, _ = self.uscl([f[bl:] for f in feats], qs_lab, "unlabeled")
+        maps_unlab, _ = self.uscl([ops.split_batch(f, bl)[1] for f in feats], qs_lab, "unlabeled")
         out_lab, out_unlab = ops.split_batch(out, bl)
         return out_lab, out_unlab, maps_lab, maps_unlab, maps_con
 

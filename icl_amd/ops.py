@@ -7,6 +7,7 @@ Each function cites the reference operator it replaces (paths relative to /root/
 from __future__ import annotations
 
 import ctypes
+import math
 import os
 from typing import Optional, Sequence
 
@@ -1532,6 +1533,16 @@ class _SplitBatch(torch.autograd.Function):
         if ga is None and gb is None:
             return None, None
         ref = ga if ga is not None else gb
+        na, nb = ctx.k * math.prod(ctx.tail), (ctx.n - ctx.k) * math.prod(ctx.tail)
+        ok = ref.dtype == torch.float32 and na % 4 == 0 and nb % 4 == 0 and (ref.is_cuda or _lib.host_pointers_ok())
+        if ok:
+            # one launch, whichever halves exist (a missing half is written as zeros)
+            ga = ga.contiguous() if ga is not None else None
+            gb = gb.contiguous() if gb is not None else None
+            out = torch.empty((ctx.n,) + ctx.tail, dtype=torch.float32, device=ref.device)
+            if all(t is None or t.data_ptr() % 16 == 0 for t in (ga, gb)):
+                _lib.check(_lib.lib().icl_concat2(_ptr(ga), na if ga is not None else na, _ptr(gb), nb, _ptr(out), _stream(ref)), "concat2")
+                return out, None
         if ga is None:
             ga = ref.new_zeros((ctx.k,) + ctx.tail)
         if gb is None:

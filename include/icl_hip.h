@@ -129,6 +129,11 @@ int icl_trilinear_bwd(const float* gy, float* gx, void* ws, int n, int c, int di
 int icl_copy_rows(const float* src, float* dst, int64_t rows, int64_t row_elems, int64_t src_stride, int64_t dst_stride,
                   void* stream);
 
+/* ---- out = [a ; b] of na + nb floats (multiples of 4, 16-byte aligned); a NULL half is written as zeros.  The gradient of the batch
+ * split of the ICL forward (train_inherent_consistent_unet_3D_BraTS.py:103-104 slices outputs[:labeled_bs] / [labeled_bs:]; the unlabeled
+ * half of the features alone feeds uscl, unet_3D_icl.py:124-131) in one launch. */
+int icl_concat2(const float* a, int64_t na, const float* b, int64_t nb, float* out, void* stream);
+
 /* ---- depthwise Conv3d k=3 pad=1 groups=C, no bias (networks/unet_3D_icl.py:320-323).
  * w is [C][27]; flip=1 applies the transposed stencil (input gradient). gw [C][27] is overwritten (per-chunk partial sums in `ws`,
  * icl_dwconv3_wgrad_ws_bytes, added in a fixed order). */

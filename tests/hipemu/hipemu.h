@@ -328,6 +328,8 @@ static inline float atomicAdd(float* p, float v) {
 }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 // v_mfma_f32_16x16x4_f32: D(16x16) = A(16x4) * B(4x16) + C, exact fmaf chain over k = 0..3
 static inline f32x4 icl_mfma_16x16x4(float a, float b, f32x4 c) {
@@ -407,6 +409,7 @@ static inline f32x16 icl_mfma_32x32x2(float a, float b, f32x16 c) {
 #define ICL_LAUNCH(kern, grid, block, lds, stream, ...) \
   hipemu::launch((grid), (block), (lds), [=]() { kern(__VA_ARGS__); })
 #define ICL_MEMSET_ASYNC(ptr, val, bytes, stream) ((void)memset((ptr), (val), (bytes)))
+#define ICL_SYMBOL_ADDRESS(pp, sym) (*(pp) = (void*)(sym), 0)
 #define ICL_LAST_LAUNCH_ERROR() 0
 #define ICL_ERROR_STRING(e) "hipemu"
 #define ICL_SET_MAX_DYN_LDS(kern, bytes) ((void)0)

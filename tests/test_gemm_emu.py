@@ -72,6 +72,43 @@ def test_gemm_split_k_batched_and_batch_sum():
     assert rel_err(total, (a @ b).sum(0)) < 2e-5
 
 
+def test_last_arriving_workgroup_sums_the_partials_bitwise_like_the_second_launch(monkeypatch):
+    """Split products (weight-streaming slices, split-K, the batch sum, the fused input gradient + update) add their partials in the
+    workgroup that draws a region's last ticket; ICL_TICKETS=0 runs gemm_reduce_slabs_kernel as a second launch instead.  Same order,
+    same operations: the results must agree bit for bit, several times in a row (the tickets must be left at zero)."""
+    L = _lib.lib()
+
+    def run_all():
+        outs = []
+        for rows, i, o, act in [(16, 1024, 1024, 0), (8, 1088, 1040, 1), (24, 1024, 1056, 0), (4, 1728, 1728, 0)]:
+            x, w, b = _rand((rows, i), 1), _rand((o, i), 2) * 0.05, _rand((o,), 3)
+            outs.append(ops.linear_forward_raw(x, w, b, act))
+            outs.append(ops.linear_dgrad_raw(_rand((rows, o), 4), w))
+        outs.append(ops.linear_forward_raw(_rand((40, 1536), 5), _rand((48, 1536), 6) * 0.05, _rand((48,), 7), 1))      # split-K, GELU
+        bsz, m, n, k = 2, 48, 64, 640
+        a, b = _rand((bsz, m, k), 8), _rand((bsz, k, n), 9)
+        outs.append(ops.gemm(a, b, m, n, k, k, n, True, False, batch=bsz, a_bstride=m * k, b_bstride=k * n))
+        total = torch.empty(m, n)
+        ops.gemm(a, b, m, n, k, k, n, True, False, out=total, ldc=n, batch=bsz, a_bstride=m * k, b_bstride=k * n, c_bstride=0)
+        outs.append(total)
+        rows, i, o = 12, 1088, 1040
+        g, x = _rand((rows, o), 11), _rand((rows, i), 12)
+        w, mo = _rand((o, i), 13) * 0.05, _rand((o, i), 14) * 0.01
+        gx = torch.empty(rows, i)
+        ws = torch.empty(max(1, L.icl_linear_ws_bytes(rows, i, o, 3) // 4))
+        assert L.icl_linear_dgrad_sgd(g.data_ptr(), x.data_ptr(), w.data_ptr(), mo.data_ptr(), gx.data_ptr(), ws.data_ptr(), rows, i, o,
+                                      0.01, 0.9, 1e-4, 0, None, None) == 0, _lib.last_error()
+        outs += [gx, w, mo]
+        return outs
+
+    monkeypatch.setenv("ICL_TICKETS", "0")
+    two_launches = run_all()
+    monkeypatch.setenv("ICL_TICKETS", "1")
+    for _ in range(3):
+        for got, want in zip(run_all(), two_launches):
+            assert torch.equal(got, want)
+
+
 def test_linear_autograd_matches_torch():
     x = _rand((2, 6, 40), 10).requires_grad_()
     w = (_rand((24, 40), 11) * 0.2).requires_grad_()

@@ -1,6 +1,7 @@
 """GPU parity tests (run with -m gpu on the MI355X box): HIP kernels through the C ABI vs the CPU oracle /
 the golden vectors captured from the reference.  Tolerances: 1e-3 relative on logits, 1e-4 on Dice
 (BASELINE.json north_star); kernel-level checks are much tighter (fp32 reassociation only)."""
+import ctypes
 import os
 
 import numpy as np
@@ -967,6 +968,48 @@ def test_update_inside_backward_equals_update_in_optimizer_step(dev):
         assert rel_err(a[2][k].cpu(), b[2][k].cpu()) < 1e-4, k
     for k in a[3]:
         assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-4 * float(b[3][k].abs().max()) + 1e-7, k
+
+
+@pytest.mark.gpu
+def test_last_arriving_workgroup_sums_the_partials_bitwise_like_the_second_launch(dev, monkeypatch):
+    """Split products add their partials in the workgroup that draws a region's last ticket (csrc/kernels/common.h ticket_is_last: the
+    partials cross XCDs, device-scope release / acquire around an integer counter); ICL_TICKETS=0 runs gemm_reduce_slabs_kernel as a second
+    launch.  Same order, same operations — bit for bit, on the shapes of the ICL step (13,824^2 / 1,728^2 / 216^2 token-axis matrices,
+    split-K products, the batch sum, the fused input gradient + update), and repeatedly: the tickets must be left at zero."""
+    from icl_amd import _lib, ops
+    L = _lib.lib()
+
+    def run_all():
+        outs = []
+        for rows, i, o, act in [(4, 13824, 13824, 0), (16, 13824, 13824, 1), (4, 1728, 1728, 0), (32, 1728, 1728, 1), (8, 216, 216, 0),
+                                (24, 1024, 1056, 0), (40, 1536, 48, 1), (64, 4096, 96, 0)]:
+            x, w, b = _rand((rows, i), 1).to(dev), (_rand((o, i), 2) * 0.05).to(dev), _rand((o,), 3).to(dev)
+            outs.append(ops.linear_forward_raw(x, w, b, act))
+            outs.append(ops.linear_dgrad_raw(_rand((rows, o), 4).to(dev), w))
+        bsz, m, n, k = 4, 48, 64, 2560
+        a, b = _rand((bsz, m, k), 8).to(dev), _rand((bsz, k, n), 9).to(dev)
+        outs.append(ops.gemm(a, b, m, n, k, k, n, True, False, batch=bsz, a_bstride=m * k, b_bstride=k * n))
+        total = torch.empty(m, n, device=dev)
+        ops.gemm(a, b, m, n, k, k, n, True, False, out=total, ldc=n, batch=bsz, a_bstride=m * k, b_bstride=k * n, c_bstride=0)
+        outs.append(total)
+        rows, i, o = 4, 13824, 13824
+        g, x = _rand((rows, o), 11).to(dev), _rand((rows, i), 12).to(dev)
+        w, mo = (_rand((o, i), 13) * 0.05).to(dev), (_rand((o, i), 14) * 0.01).to(dev)
+        gx = torch.empty(rows, i, device=dev)
+        ws = torch.empty(max(1, L.icl_linear_ws_bytes(rows, i, o, 3) // 4), device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert L.icl_linear_dgrad_sgd(g.data_ptr(), x.data_ptr(), w.data_ptr(), mo.data_ptr(), gx.data_ptr(), ws.data_ptr(), rows, i, o,
+                                      0.01, 0.9, 1e-4, 0, None, st) == 0, _lib.last_error()
+        outs += [gx, w, mo]
+        torch.cuda.synchronize()
+        return outs
+
+    monkeypatch.setenv("ICL_TICKETS", "0")
+    two_launches = run_all()
+    monkeypatch.setenv("ICL_TICKETS", "1")
+    for _ in range(5):
+        for j, (got, want) in enumerate(zip(run_all(), two_launches)):
+            assert torch.equal(got, want), j
 
 
 @pytest.mark.gpu

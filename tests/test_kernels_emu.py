@@ -580,15 +580,24 @@ def test_factored_sgd_on_split_products(rows, n, k, first):
     assert e_split <= 4.0 * e_fp32 + 1e-7 * float(m_ref.abs().max()), (e_split, e_fp32)
 
 
-def test_layernorm_gelu():
-    x = (_rand((3, 5, 37), 61) * 2 + 0.3).requires_grad_()
-    w = (1 + 0.1 * _rand((37,), 62)).requires_grad_()
-    b = (0.1 * _rand((37,), 63)).requires_grad_()
-    gy = _rand((3, 5, 37), 64)
+@pytest.mark.parametrize("shape", [
+    (3, 5, 37),        # one chunk, ragged columns of one lane column
+    (2, 70, 64),       # 140 rows: five chunks of 32, the last one ragged; rows in flight past the chunk end
+    (1, 33, 128),      # two columns per lane
+    (1, 9, 200),       # four columns per lane, two rows in flight
+    (1, 6, 300), (1, 5, 768),      # one row in flight (Swin widths)
+    (2, 3, 1100),      # one workgroup per row (norm3's long rows): separate parameter-gradient pass
+])
+def test_layernorm_gelu(shape):
+    c = shape[-1]
+    x = (_rand(shape, 61) * 2 + 0.3).requires_grad_()
+    w = (1 + 0.1 * _rand((c,), 62)).requires_grad_()
+    b = (0.1 * _rand((c,), 63)).requires_grad_()
+    gy = _rand(shape, 64)
     y = ops.gelu(ops.layer_norm(x, w, b))
     y.backward(gy)
     xr, wr, br = (t.detach().clone().requires_grad_() for t in (x, w, b))
-    yr = F.gelu(F.layer_norm(xr, (37,), wr, br, 1e-5))
+    yr = F.gelu(F.layer_norm(xr, (c,), wr, br, 1e-5))
     yr.backward(gy)
     assert rel_err(y.detach(), yr.detach()) < 1e-5
     assert rel_err(x.grad, xr.grad) < 1e-4 and rel_err(w.grad, wr.grad) < 1e-4 and rel_err(b.grad, br.grad) < 1e-4
