@@ -117,6 +117,48 @@ class SideStream:
         self.pending = []
 
 
+
+class WgradLane:
+    """Weight gradients of the deep levels on a second stream.  From `up3` down (24^3, 12^3, 6^3) a layer's input-gradient and weight-gradient
+    launches occupy 54-144 workgroups each on a chip of 256 CUs, and nothing else runs in that part of the backward pass (the aligner
+    branches are done: tools/critical_path.py).  The weight gradient is a leaf of the graph — only the optimiser reads it — so inside
+    ICLTrainer's step (``open``) `_Conv3d.backward` launches it on a lane ordered after the producer of dY and goes on with the input
+    gradient on its own stream; ``join()`` (ICLTrainer, after backward) orders the step's stream after the lane.  Captured steps: the lane
+    is a parallel branch of the hipGraph.  ``ICL_WGRAD_LANE=0`` keeps everything in line."""
+    enabled = os.environ.get("ICL_WGRAD_LANE", "1") != "0"
+    max_voxels = int(os.environ.get("ICL_WGRAD_LANE_MAX_VOXELS", str(24 ** 3)))
+    open = False
+    _stream = None
+    _used = False
+
+    @classmethod
+    def wants(cls, x: torch.Tensor, voxels: int) -> bool:
+        return cls.enabled and cls.open and x.is_cuda and voxels <= cls.max_voxels
+
+    @classmethod
+    def fork_point(cls, like: torch.Tensor):
+        """Order the lane after everything queued so far on the current stream (call where dY is complete, BEFORE the input gradient
+        is queued, so that the two gradients of the layer run side by side)."""
+        dev = like.device
+        if cls._stream is None or cls._stream.device != dev:
+            # an aligner lane if there is one (idle in this part of the backward pass, and known to run beside the step's stream)
+            cls._stream = SideStream._streams.get((dev.index, 1)) or torch.cuda.Stream(device=dev)
+        cls._stream.wait_stream(torch.cuda.current_stream(dev))
+        cls._used = True
+
+    @classmethod
+    def on_lane(cls, *tensors):
+        for t in tensors:
+            if t is not None:
+                t.record_stream(cls._stream)
+        return torch.cuda.stream(cls._stream)
+
+    @classmethod
+    def join(cls):
+        if cls._used:
+            torch.cuda.current_stream(cls._stream.device).wait_stream(cls._stream)
+            cls._used = False
+
 class KernelTimer:
     """HIP-event timing of individual kernel launches on the stream they are launched on (bench.py roofline).
     Usage: ``with KernelTimer() as kt: step()``; ``kt.summary()`` -> {name: (launches, ms_total, flops, bytes)}."""
@@ -437,6 +479,10 @@ class _Conv3d(torch.autograd.Function):
         cout, ks = weight.shape[0], weight.shape[2]
         s = d * h * w
         gx = gw = gb = None
+        lane = (ks == 3 and WgradLane.wants(x, s) and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not getattr(ctx, "cin1", False)
+                and not (cin * 27 <= FIRST_CONV_PLANES_MAX_K))
+        if lane:
+            WgradLane.fork_point(gy)
         if ctx.needs_input_grad[0]:
             if ctx.pointwise_gemm:
                 # gx[b] [Cin,S] = W^T gy[b]: A = W read transposed (k-strided), B = gy[b] [Cout,S] (k-strided)
@@ -486,10 +532,18 @@ class _Conv3d(torch.autograd.Function):
                     _lib.check(L.icl_conv1x1_wgrad(_ptr(planes), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin * 27, cout, s,
                                                    cin * 27 * s, cout * s, _stream(x)), "conv1x1_wgrad")
             else:
-                ws = _ws(L.icl_conv3d_wgrad_ws_bytes(n, cin, cout, ks), x)
-                with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):
-                    _lib.check(L.icl_conv3d_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin, cout, d, h, w, ks,
-                                                  cin * s, cout * s, _stream(x)), "conv3d_wgrad")
+                def wgrad():
+                    ws = _ws(L.icl_conv3d_wgrad_ws_bytes(n, cin, cout, ks), x)
+                    with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):
+                        _lib.check(L.icl_conv3d_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin, cout, d, h, w, ks,
+                                                      cin * s, cout * s, _stream(x)), "conv3d_wgrad")
+                if lane:
+                    # deep level: beside the input gradient instead of behind it (the lane was forked where dY was complete, before
+                    # the input gradient above was queued on this stream)
+                    with WgradLane.on_lane(x, gy, gw, gb_arg):
+                        wgrad()
+                else:
+                    wgrad()
         return gx, gw, gb, None, None
 
 

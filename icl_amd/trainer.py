@@ -106,8 +106,11 @@ class ICLTrainer:
                 loss, parts = self.compute_loss(outputs, label_batch)
                 if boundary is not None:
                     boundary()
+                ops.WgradLane.open = True
                 loss.backward()
+                ops.WgradLane.join()
         finally:
+            ops.WgradLane.open = False
             ops.FactoredGrads.fused_optimizer = None
             ops.FactoredGrads.uses = None
             BatchNormAct.flush_counters()     # all num_batches_tracked increments of the step in one launch
