@@ -6,6 +6,9 @@
 #   tools/gpu_run.sh stats NAME [bench args]        rocprofv3 --kernel-trace --stats of a graph-replayed bench -> gpurun_out/NAME_kernel_stats.csv,
 #                                                   launches and kernel ms per step, the ATen / runtime kernels that are left
 #   tools/gpu_run.sh critical-path                  tools/critical_path.py (stamp kernels inside the replayed graph)
+#   tools/gpu_run.sh timeline                       kernel trace of the replayed step -> per-queue timeline (tools/timeline.py) -> gpurun_out/timeline.txt
+#   tools/gpu_run.sh pmc                            PMC counters (two SQ passes, tools/pmc_conv.sh) and HBM traffic (tools/pmc_hbm.sh) of the convolution
+#                                                   kernels on the layer shapes of the step, batch 2 -> gpurun_out/pmc_conv_raw.txt
 #   tools/gpu_run.sh probe SRC.hip ARGS...          build a stand-alone probe of tools/probe/ and run it
 # Several tasks in one call: separate them with "--".
 cd "$(dirname "$0")/.." || exit 1
@@ -42,6 +45,20 @@ for n, name in sorted(left, reverse=True)[:12]:
 PY
         ;;
     critical-path) python tools/critical_path.py 2>&1 | tail -24 ;;
+    timeline)
+        ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$O/tl_prof" -o b --output-format csv -- python3 "$R/bench.py" \
+            --no-cpu-baseline --no-exact-compare --launch graph --steps 8 --warmup 2 > /dev/null 2>&1 )
+        T=$(find "$O/tl_prof" -name "*kernel_trace.csv" | head -1)
+        python3 tools/timeline.py "$T" 3 0.25 > "$O/timeline.txt" 2>&1
+        rm -f "$T"; head -60 "$O/timeline.txt" ;;
+    pmc)
+        for spec in "f16 16 16 96 fwd" "f48 48 16 96 fwd" "f32 32 32 48 fwd" "f4848 48 48 96 fwd" "w16 16 16 96 wgrad" "w32 32 32 48 wgrad"; do
+          set -- $spec; tag=$1; shift
+          bash tools/pmc_conv.sh "$tag" -- "$1" "$2" "$3" "$4" 5 2
+          bash tools/pmc_hbm.sh "$tag" conv "$1" "$2" "$3" "$4" 5 2
+        done
+        python3 tools/pmc_summary.py "$O"/pmc_*_1 "$O"/pmc_*_2 "$O"/hbm_*_f "$O"/hbm_*_w > "$O/pmc_conv_raw.txt" 2>&1
+        cut -c1-400 "$O/pmc_conv_raw.txt" ;;
     probe) local src=$1; shift
         hipcc --offload-arch=gfx950 -O3 -std=c++17 -I icl_amd/csrc -I tools/probe "tools/probe/$src" -o "/tmp/${src%.hip}" && "/tmp/${src%.hip}" "$@" ;;
     *) echo "unknown task $t"; return 1 ;;
