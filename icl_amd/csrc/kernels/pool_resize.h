@@ -383,12 +383,20 @@ __global__ __launch_bounds__(256) void resize_bwd_axis_t4_kernel(const float* __
     lin_range(i, rscale, Lo, align, lo, hi);
     const float4* p = reinterpret_cast<const float4*>(src + (long)b * src_bstride + ((long)row * Lo) * inner4 * 4) + t4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int o = lo; o <= hi; ++o) {
-      const float w = lin_w(o, i, rscale, Li, align);
-      if (w != 0.f) {
-        const float4 v = p[(long)o * inner4];
-        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    // eight taps' loads in flight, added in tap order (a 96 -> 6 axis gathers up to 32 taps per output: one dependent load per tap made the
+    // few-workgroup launches of the deep maps' loss gradients 20-30 us latency chains at the head of the aligner lanes' backward)
+    for (int o = lo; o <= hi; o += 8) {
+      float4 v[8];
+      float w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int oo = o + u <= hi ? o + u : hi;
+        w[u] = o + u <= hi ? lin_w(oo, i, rscale, Li, align) : 0.f;
+        v[u] = p[(long)oo * inner4];
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (w[u] != 0.f) { acc.x += w[u] * v[u].x; acc.y += w[u] * v[u].y; acc.z += w[u] * v[u].z; acc.w += w[u] * v[u].w; }
     }
     reinterpret_cast<float4*>(dst)[e] = acc;
   }

@@ -60,6 +60,80 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int c = lane; c < C; c += stride) o[c] = rs * ((gamma ? gr[c] * gamma[c] : gr[c]) - s1 - (xr[c] - m) * rs * s2);
 }
 
+// Long rows (one workgroup per row: norm3's 13,824 tokens, 4-32 rows) with the row held in REGISTERS: thread t owns columns t, t + 256, ...
+// (the assignment and the summation order of layernorm_fwd/bwd_kernel<true>, so the results are bit-identical), all K = ceil(C / 256) loads of
+// a thread are issued before the first is used.  The plain kernels walk the row three times with one dependent 4-byte load per iteration: 70 us
+// for a 55 KB row; these take the latency of one round of loads plus the two block reductions.  C <= 256 K.
+template <int K>
+__global__ __launch_bounds__(256) void layernorm_fwd_longrow_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float* __restrict__ y,
+                                                                    float* __restrict__ mean, float* __restrict__ rstd, int C, float eps) {
+  __shared__ float red[4];
+  const int t = threadIdx.x;
+  const long r = blockIdx.x;
+  const float* xr = x + r * C;
+  float v[K], ga[K], be[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int c = t + 256 * k;
+    v[k] = c < C ? xr[c] : 0.f;
+    ga[k] = (gamma && c < C) ? gamma[c] : 1.f;
+    be[k] = (beta && c < C) ? beta[c] : 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (t + 256 * k < C) s += v[k];
+  const float m = block_sum<256>(s, red) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (t + 256 * k < C) { const float d = v[k] - m; q += d * d; }
+  const float rs = 1.0f / sqrtf(block_sum<256>(q, red) / (float)C + eps);
+  float* yr = y + r * C;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int c = t + 256 * k;
+    if (c < C) yr[c] = gamma ? (v[k] - m) * rs * ga[k] + be[k] : (v[k] - m) * rs;
+  }
+  if (t == 0) { mean[r] = m; rstd[r] = rs; }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void layernorm_bwd_longrow_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, float* __restrict__ gx, int C) {
+  __shared__ float red[4];
+  const int t = threadIdx.x;
+  const long r = blockIdx.x;
+  const float* xr = x + r * C;
+  const float* gr = gy + r * C;
+  const float m = mean[r], rs = rstd[r];
+  float g[K], xh[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int c = t + 256 * k;
+    const float gv = c < C ? gr[c] : 0.f;
+    g[k] = (gamma && c < C) ? gv * gamma[c] : gv;
+    xh[k] = c < C ? xr[c] : 0.f;
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (t + 256 * k < C) {
+      s1 += g[k];
+      s2 += g[k] * (xh[k] - m) * rs;
+    }
+  s1 = block_sum<256>(s1, red) / (float)C;
+  s2 = block_sum<256>(s2, red) / (float)C;
+  float* o = gx + r * C;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int c = t + 256 * k;
+    if (c < C) o[c] = rs * (g[k] - s1 - (xh[k] - m) * rs * s2);
+  }
+}
+
 // Partial sums of dgamma[c] = sum_rows gy*xhat and dbeta[c] = sum_rows gy: row chunk j (blockIdx.y) writes part_g[j][c] and
 // part_b[j][c]; colsum_multi_kernel adds the chunks in a fixed order (no float atomics: the step is bit-reproducible).  A workgroup
 // covers `cols` = min(C,256) columns x (256/cols) row lanes so that short rows still read full 256-byte lines; grid (ceil(C/cols), chunks).
@@ -162,26 +236,31 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
 }
 
 // one workgroup per (b,h,c): softmax statistics and out = P @ V
-template <int D>
-__global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const float* __restrict__ logits, const float* __restrict__ kv,
+// NT threads per row: 256, or 1024 for long token axes (24^3: 13,824 tokens per row and only B h nc = 8-16 rows — with 256 threads a row is a
+// 54-iteration latency chain per thread)
+template <int D, int NT>
+__global__ __launch_bounds__(NT) void attn_softmax_pv_kernel(const float* __restrict__ logits, const float* __restrict__ kv,
                                                               float* __restrict__ out, float* __restrict__ stats, int B, int H, int nc, int N) {
-  __shared__ float red[4 * (D + 1)];
+  constexpr int NW = NT / 64;
+  __shared__ float red[NW * (D + 1)];
   const int row = blockIdx.x;  // (b*H + h)*nc + c
   const int bh = row / nc;
   const int b = bh / H, h = bh % H;
   const float* l = logits + (((long)b * nc + row % nc) * H + h) * N;
   float m = -3.0e38f;
-  for (int n = threadIdx.x; n < N; n += 256) m = fmaxf(m, l[n]);
+  for (int n = threadIdx.x; n < N; n += NT) m = fmaxf(m, l[n]);
   m = wave_max(m);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) red[wid] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
   __syncthreads();
   float s = 0.f, o[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) o[d] = 0.f;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  for (int n = threadIdx.x; n < N; n += NT) {
     const float p = expf(l[n] - m);
     s += p;
     const float* vp = kv + (((long)b * N + n) * 2 + 1) * H * D + h * D;
@@ -199,7 +278,9 @@ __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const float* __res
   __syncthreads();
   if (threadIdx.x < D + 1) {
     const int i = threadIdx.x;
-    const float v = red[i] + red[(D + 1) + i] + red[2 * (D + 1) + i] + red[3 * (D + 1) + i];
+    float v = red[i];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += red[w * (D + 1) + i];
     red[i] = v;
   }
   __syncthreads();
@@ -250,12 +331,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
 }
 
 // one workgroup per (b,h,c): dQ[c] = scale * sum_n dlogit[c][n] * K[n]
-template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ kv, const float* __restrict__ logits, const float* __restrict__ stats,
+template <int D, int NT>
+__global__ __launch_bounds__(NT) void attn_bwd_q_kernel(const float* __restrict__ kv, const float* __restrict__ logits, const float* __restrict__ stats,
                                                          const float* __restrict__ out, const float* __restrict__ gout,
                                                          const float* __restrict__ glog, float* __restrict__ gq, int B, int H, int nc,
                                                          int N, float scale) {
-  __shared__ float red[4 * D];
+  constexpr int NW = NT / 64;
+  __shared__ float red[NW * D];
   __shared__ float go[D];
   __shared__ float delta_s;
   const int row = blockIdx.x;
@@ -274,7 +356,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   float acc[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) acc[d] = 0.f;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  for (int n = threadIdx.x; n < N; n += NT) {
     const long base = ((long)b * N + n) * 2 * H * D + h * D;
     const float p = expf(logits[lrow + n] - m) / tot;
     float dp = 0.f;
@@ -293,7 +375,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   __syncthreads();
   if (threadIdx.x < D) {
     const int d = threadIdx.x;
-    gq[(long)row * D + d] = scale * (red[d] + red[D + d] + red[2 * D + d] + red[3 * D + d]);
+    float v = red[d];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += red[w * D + d];
+    gq[(long)row * D + d] = scale * v;
   }
 }
 

