@@ -17,14 +17,8 @@ namespace icl {
 constexpr int kNormChunk = 8192;  // elements per workgroup
 constexpr int kNormThreads = 256;
 
-// part[(r*nchunks + ch)*3 + {0,1,2}] = (count, mean, M2) of x[r, ch*chunk : (ch+1)*chunk]
-__global__ __launch_bounds__(kNormThreads) void rowstats_partial_kernel(
-    const float* __restrict__ x, float* __restrict__ part, long S, int nchunks) {
-  const int ch = blockIdx.x;
-  const long r = blockIdx.y;
-  const long lo = (long)ch * kNormChunk;
-  const long hi = (lo + kNormChunk < S) ? lo + kNormChunk : S;
-  const float* xr = x + r * S;
+// (count, mean, M2) of xr[lo, hi) by the whole workgroup; the result is valid in thread 0
+__device__ __forceinline__ void row_chunk_summary(const float* __restrict__ xr, long lo, long hi, long S, float& tn, float& tm, float& tq) {
   // shifted sums per thread (shift = first element seen) -> (n, mean, M2)
   float n = 0.f, shift = 0.f, s1 = 0.f, s2 = 0.f;
   if ((S & 3) == 0) {   // 16 bytes per lane (chunk bounds are multiples of 4)
@@ -66,9 +60,23 @@ __global__ __launch_bounds__(kNormThreads) void rowstats_partial_kernel(
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) { red[wid * 3] = n; red[wid * 3 + 1] = mean; red[wid * 3 + 2] = m2; }
   __syncthreads();
+  tn = tm = tq = 0.f;
   if (threadIdx.x == 0) {
-    float tn = red[0], tm = red[1], tq = red[2];
+    tn = red[0]; tm = red[1]; tq = red[2];
     for (int w = 1; w < kNormThreads / 64; ++w) welford_merge(tn, tm, tq, red[w * 3], red[w * 3 + 1], red[w * 3 + 2]);
+  }
+}
+
+// part[(r*nchunks + ch)*3 + {0,1,2}] = (count, mean, M2) of x[r, ch*chunk : (ch+1)*chunk]
+__global__ __launch_bounds__(kNormThreads) void rowstats_partial_kernel(
+    const float* __restrict__ x, float* __restrict__ part, long S, int nchunks) {
+  const int ch = blockIdx.x;
+  const long r = blockIdx.y;
+  const long lo = (long)ch * kNormChunk;
+  const long hi = (lo + kNormChunk < S) ? lo + kNormChunk : S;
+  float tn, tm, tq;
+  row_chunk_summary(x + r * S, lo, hi, S, tn, tm, tq);
+  if (threadIdx.x == 0) {
     float* p = part + (r * nchunks + ch) * 3;
     p[0] = tn; p[1] = tm; p[2] = tq;
   }
@@ -117,12 +125,23 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mean,
     float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     long S, int C, int batch_mode, int act, const float* __restrict__ res, const float* __restrict__ part, int R, int nchunks,
-    float eps, float* running_mean, float* running_var, float momentum) {
+    float eps, float* running_mean, float* running_var, float momentum, int inline_stats) {
   const long r = blockIdx.y;
   const int c = (int)(r % C);
   const int g = batch_mode ? c : (int)r;
   float m, rs;
-  if (part) {
+  if (part == nullptr && inline_stats) {
+    // instance statistics of a row that is ONE chunk: summarised here (the arithmetic of rowstats_partial_kernel, and merging a single
+    // summary is exact), no statistics launch in front of this one
+    __shared__ float bcs[2];
+    float tn, tm, tq;
+    row_chunk_summary(x + r * S, 0, S, S, tn, tm, tq);
+    if (threadIdx.x == 0) { bcs[0] = tm; bcs[1] = tq / tn; }
+    __syncthreads();
+    m = bcs[0];
+    rs = 1.0f / sqrtf(bcs[1] + eps);
+    if (threadIdx.x == 0) { mean[g] = m; rstd[g] = rs; }
+  } else if (part) {
     float var, n;
     norm_group_stats(part, g, R, C, nchunks, batch_mode, m, var, n);
     rs = 1.0f / sqrtf(var + eps);
@@ -169,21 +188,10 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_fwd_kernel(
 }
 
 // Backward partial sums per (row, chunk): p1 = sum h, p2 = sum h*xhat, h = gy * [y > 0 if act].
-__global__ __launch_bounds__(kNormThreads) void norm_act_bwd_partial_kernel(
-    const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
-    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ part, long S, int C, int nchunks, int batch_mode, int act, const float* __restrict__ res) {
-  const long r = blockIdx.y;
-  const int c = (int)(r % C);
-  const int g = batch_mode ? c : (int)r;
-  const float m = mean[g], rs = rstd[g];
-  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-  const long lo = (long)blockIdx.x * kNormChunk;
-  const long hi = (lo + kNormChunk < S) ? lo + kNormChunk : S;
-  const float* xr = x + r * S;
-  const float* gr = gy + r * S;
-  const float* rr = res ? res + r * S : nullptr;
-  float p1 = 0.f, p2 = 0.f;
+// (sum h, sum h*xhat) over [lo, hi) of one row by the whole workgroup, valid in every thread
+__device__ __forceinline__ void norm_bwd_chunk_sums(const float* __restrict__ xr, const float* __restrict__ gr, const float* __restrict__ rr, long lo,
+                                                    long hi, long S, float m, float rs, float ga, float be, int act, float& p1, float& p2) {
+  p1 = 0.f; p2 = 0.f;
   if ((S & 3) == 0) {   // 16 bytes per lane
     const float4* x4 = reinterpret_cast<const float4*>(xr);
     const float4* g4 = reinterpret_cast<const float4*>(gr);
@@ -214,6 +222,20 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_partial_kernel(
   __shared__ float red[kNormThreads / 64];
   p1 = block_sum<kNormThreads>(p1, red);
   p2 = block_sum<kNormThreads>(p2, red);
+}
+
+__global__ __launch_bounds__(kNormThreads) void norm_act_bwd_partial_kernel(
+    const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ part, long S, int C, int nchunks, int batch_mode, int act, const float* __restrict__ res) {
+  const long r = blockIdx.y;
+  const int c = (int)(r % C);
+  const int g = batch_mode ? c : (int)r;
+  const long lo = (long)blockIdx.x * kNormChunk;
+  const long hi = (lo + kNormChunk < S) ? lo + kNormChunk : S;
+  float p1, p2;
+  norm_bwd_chunk_sums(x + r * S, gy + r * S, res ? res + r * S : nullptr, lo, hi, S, mean[g], rstd[g], gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f,
+                      act, p1, p2);
   if (threadIdx.x == 0) {
     float* p = part + (r * nchunks + blockIdx.x) * 2;
     p[0] = p1; p[1] = p2;
@@ -234,7 +256,14 @@ __global__ __launch_bounds__(kNormThreads) void norm_act_bwd_apply_kernel(
   const int c = (int)(r % C);
   const int g = batch_mode ? c : (int)r;
   __shared__ float bc[2];
-  if (threadIdx.x < 64) {
+  if (part == nullptr) {
+    // instance statistics, the row is ONE chunk: its two sums computed here (norm_act_bwd_partial_kernel's arithmetic; with one chunk
+    // the group sum below is that chunk's value), no partial-sum launch in front of this one
+    float p1, p2;
+    norm_bwd_chunk_sums(x + r * S, gy + r * S, res ? res + r * S : nullptr, 0, S, S, mean[g], rstd[g], gamma ? gamma[c] : 1.f,
+                        beta ? beta[c] : 0.f, act, p1, p2);
+    if (threadIdx.x == 0) { bc[0] = p1; bc[1] = p2; }
+  } else if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const int step = batch_mode ? C : R;
     const int nrows = (R - g + step - 1) / step;
