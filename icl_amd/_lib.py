@@ -98,6 +98,8 @@ _SIGNATURES = {
     "icl_gelu_bwd": (c_int, [P, P, P, L, P]),
     "icl_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, F, P]),
     "icl_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "icl_attn_bwd_ws_bytes": (c_int64, [I, I, I, I, I]),
+    "icl_attn_bwd_ws": (c_int, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
     "icl_crop_rotflip": (c_int, [P, P, P, I, P, P, I, I, I, P]),
     "icl_sgd_step": (c_int, [P, P, P, L, F, F, F, I, P, P]),
     "icl_sgd_step_factored": (c_int, [P, P, P, P, I, I, I, F, F, F, I, P, P]),

@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
 }
 
 // one workgroup per (b,h,c): softmax statistics and out = P @ V
-// NT threads per row: 256, or 1024 for long token axes (24^3: 13,824 tokens per row and only B h nc = 8-16 rows — with 256 threads a row is a
-// 54-iteration latency chain per thread)
+// NT threads per row.  (Round 4: 1,024 threads per row for the 13,824-token rows of the 24^3 level — 8-16 rows per launch — measured SLOWER in the
+// step's kernel statistics: softmax.V 41 us against 27, dQ 89 against 51-82; the launches use 256.)
 template <int D, int NT>
 __global__ __launch_bounds__(NT) void attn_softmax_pv_kernel(const float* __restrict__ logits, const float* __restrict__ kv,
                                                               float* __restrict__ out, float* __restrict__ stats, int B, int H, int nc, int N) {
@@ -290,12 +290,18 @@ __global__ __launch_bounds__(NT) void attn_softmax_pv_kernel(const float* __rest
 }
 
 // dlogit[c][n] = ga[c][n] + p*(dO[c].V[n] - out[c].dO[c]);   thread per (b,h,n): dK[n], dV[n] (no reduction needed)
+// dK, dV per token (one thread per token, 256 tokens per workgroup) and — `pq` given — the workgroup's share of dQ: pq[blockIdx.x][bh][c][d] =
+// sum over its tokens of g[c][n] k[n][d] (attn_dq_reduce_kernel adds the workgroups' shares in order and scales).  With the token axis of the
+// 24^3 level (13,824 tokens, 8-16 (sample, head, class) rows) the row-per-workgroup dQ kernel below is an 89 us latency chain on the query chain
+// of the backward pass; here the products ride on the pass that has g and the token's K / V row in registers already.
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ logits,
                                                           const float* __restrict__ stats, const float* __restrict__ out,
                                                           const float* __restrict__ gout, const float* __restrict__ glog,
-                                                          float* __restrict__ gkv, int B, int H, int nc, int N, float scale) {
+                                                          float* __restrict__ gkv, int B, int H, int nc, int N, float scale,
+                                                          float* __restrict__ pq) {
   __shared__ float qs[kAttnMaxNc * D], gos[kAttnMaxNc * D], dl[kAttnMaxNc], ms[kAttnMaxNc * 2];
+  __shared__ float dqw[4][D];
   const int bh = blockIdx.y;
   const int b = bh / H, h = bh % H;
   for (int i = threadIdx.x; i < nc * D; i += 256) {
@@ -311,23 +317,60 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
   }
   __syncthreads();
   const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  const long base = ((long)b * N + n) * 2 * H * D + h * D;
-  float v[D], dk[D], dv[D];
+  const bool live = n < N;
+  if (!live && pq == nullptr) return;
+  const long base = ((long)b * N + (live ? n : N - 1)) * 2 * H * D + h * D;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float v[D], k[D], dk[D], dv[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) { v[d] = kv[base + (long)H * D + d]; dk[d] = 0.f; dv[d] = 0.f; }
+  for (int d = 0; d < D; ++d) {
+    v[d] = kv[base + (long)H * D + d];
+    k[d] = pq ? kv[base + d] : 0.f;
+    dk[d] = 0.f; dv[d] = 0.f;
+  }
   for (int c = 0; c < nc; ++c) {
-    const long li = (((long)b * nc + c) * H + h) * N + n;
+    const long li = (((long)b * nc + c) * H + h) * N + (live ? n : N - 1);
     const float p = expf(logits[li] - ms[c * 2]) / ms[c * 2 + 1];
     float dp = 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) dp += gos[c * D + d] * v[d];
-    const float g = (glog ? glog[li] : 0.f) + p * (dp - dl[c]);
+    const float g = live ? (glog ? glog[li] : 0.f) + p * (dp - dl[c]) : 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) { dk[d] += scale * g * qs[c * D + d]; dv[d] += p * gos[c * D + d]; }
+    if (pq) {
+      // the workgroup's sum of g k[d] for class c: wave sums, then the four waves in order
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const float w = wave_sum(g * k[d]);
+        if (lane == 0) dqw[wid][d] = w;
+      }
+      __syncthreads();
+      if (threadIdx.x < D)
+        pq[(((long)blockIdx.x * gridDim.y + bh) * nc + c) * D + threadIdx.x] =
+            ((dqw[0][threadIdx.x] + dqw[1][threadIdx.x]) + dqw[2][threadIdx.x]) + dqw[3][threadIdx.x];
+      __syncthreads();
+    }
   }
+  if (!live) return;
 #pragma unroll
   for (int d = 0; d < D; ++d) { gkv[base + d] = dk[d]; gkv[base + (long)H * D + d] = dv[d]; }
+}
+
+// gq[row][d] = scale * sum over the token chunks x (in order) of pq[x][row][d]; rows = B H nc, one thread per (row, d)
+__global__ __launch_bounds__(256) void attn_dq_reduce_kernel(const float* __restrict__ pq, float* __restrict__ gq, int chunks, int rd, float scale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rd) return;
+  float s = 0.f;
+  int x = 0;
+  for (; x + 8 <= chunks; x += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = pq[(long)(x + u) * rd + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; x < chunks; ++x) s += pq[(long)x * rd + i];
+  gq[i] = scale * s;
 }
 
 // one workgroup per (b,h,c): dQ[c] = scale * sum_n dlogit[c][n] * K[n]

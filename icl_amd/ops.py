@@ -1761,8 +1761,11 @@ class _ProtoAttention(torch.autograd.Function):
         glog = glog.contiguous() if glog is not None else None
         gq = torch.empty_like(qh)
         gkv = torch.empty_like(kv)
-        _lib.check(L.icl_attn_bwd(_ptr(qh), _ptr(kv), _ptr(logits), _ptr(stats), _ptr(out), _ptr(gout), _ptr(glog), _ptr(gq), _ptr(gkv),
-                                  B, h, nc, N, d, ctx.scale, _stream(qh)), "attn_bwd")
+        # dQ from the shares the dK / dV pass writes per 256-token chunk (long token axes: the row-per-workgroup dQ kernel is a latency
+        # chain on the backward's query chain); short axes keep the two-kernel form (one launch fewer than shares + sum... the same count)
+        ws = _ws(L.icl_attn_bwd_ws_bytes(B, h, nc, N, d), qh) if (N >= 1024 and os.environ.get("ICL_ATTN_DQ_SHARES", "1") != "0") else None
+        _lib.check(L.icl_attn_bwd_ws(_ptr(qh), _ptr(kv), _ptr(logits), _ptr(stats), _ptr(out), _ptr(gout), _ptr(glog), _ptr(gq), _ptr(gkv),
+                                     _ptr(ws), B, h, nc, N, d, ctx.scale, _stream(qh)), "attn_bwd")
         return gq, gkv, None, None
 
 

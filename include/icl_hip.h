@@ -196,6 +196,11 @@ int icl_attn_fwd(const float* q, const float* kv, float* logits, float* out, flo
                  float scale, void* stream);
 int icl_attn_bwd(const float* q, const float* kv, const float* logits, const float* stats, const float* out, const float* gout,
                  const float* glog, float* gq, float* gkv, int b, int h, int nc, int n, int d, float scale, void* stream);
+/* the same with a workspace (icl_attn_bwd_ws_bytes): dQ is summed from per-token-chunk shares written by the dK / dV pass instead of a second
+ * walk over K and V by one workgroup per (sample, head, class) row; ws == NULL is icl_attn_bwd */
+int64_t icl_attn_bwd_ws_bytes(int b, int h, int nc, int n, int d);
+int icl_attn_bwd_ws(const float* q, const float* kv, const float* logits, const float* stats, const float* out, const float* gout,
+                    const float* glog, float* gq, float* gkv, void* ws, int b, int h, int nc, int n, int d, float scale, void* stream);
 
 /* out_i[c] = sum_r g_i[r * cols_i + c] for `count` small row-major matrices, one launch per 48 of them: the bias gradients of the
  * aligner / Swin Linear layers (unet_3D_icl.py:244-315) collected over a backward pass. */

@@ -36,7 +36,8 @@ task() {
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 import collections
-steps = collections.Counter(int(r['Calls']) for r in rows if int(r['Calls']) >= 10).most_common(1)[0][0]      # once-per-step kernels: the most common call count
+cnt = collections.Counter(int(r['Calls']) for r in rows if int(r['Calls']) >= 10)
+steps = min(k for k, v in cnt.items() if v >= 3)      # the call count of the once-per-step kernels: the smallest count several kernels share
 print('launches/step', round(sum(int(r['Calls']) for r in rows) / steps, 1), 'kernel ms/step', round(sum(float(r['TotalDurationNs']) for r in rows) / steps / 1e6, 3))
 left = [(int(r['Calls']) / steps, r['Name']) for r in rows if 'at::' in r['Name'] or 'rocclr' in r['Name']]
 print('ATen / runtime launches per step:', round(sum(n for n, _ in left), 1))
