@@ -20,7 +20,7 @@ from icl_amd.utils.hashfill import synthetic_labels, synthetic_volume  # noqa: E
 S = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", "libstamp.so"))
 S.probe_stamp.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 dev = torch.device("cuda", 0)
-slots = torch.zeros(256, dtype=torch.int64, device=dev)
+slots = torch.zeros(512, dtype=torch.int64, device=dev)
 names = []
 
 
@@ -90,6 +90,13 @@ if os.environ.get("CP_ALIGNER_DETAIL", "0") != "0":
         for i, cd in enumerate(getattr(model, head).class_decoders):
             cd.mlp2.register_full_backward_hook(lambda m, gi, go, t=f"B {head} level {i}: mlp2 backward done": mark(t))
             cd.attn.register_full_backward_hook(lambda m, gi, go, t=f"B {head} level {i}: attention backward done": mark(t))
+    if os.environ.get("CP_ALIGNER_DETAIL", "0") == "2":
+        # the links of sspa's query chain (the serial tail of the backward's forked phase)
+        for i, cd in enumerate(model.sspa.class_decoders):
+            for name, mod in (("query_convs", model.sspa.query_convs[i]), ("mlp", cd.mlp), ("norm2", cd.norm2), ("attn.proj", cd.attn.proj),
+                              ("attn.fc_q", cd.attn.fc_q), ("attn.fc_kv", cd.attn.fc_kv), ("norm1_query", cd.norm1_query), ("norm1", cd.norm1),
+                              ("norm_layers", model.sspa.norm_layers[i])):
+                mod.register_full_backward_hook(lambda m, gi, go, t=f"B   sspa level {i}: {name} backward done": mark(t))
 _loss = tr.compute_loss
 
 
@@ -131,3 +138,4 @@ v = slots.cpu().tolist()
 base = v[names.index("forward start")]
 for t, n in sorted((v[i], n) for i, n in enumerate(names)):
     print(f"{(t - base) / 100.0:9.1f} us  {n}")
+

@@ -45,12 +45,13 @@ for n, name in sorted(left, reverse=True)[:12]:
     print(f'  {n:6.1f}  {name[:120]}')
 PY
         ;;
-    critical-path) python tools/critical_path.py 2>&1 | tail -24 ;;
+    critical-path) python tools/critical_path.py 2>&1 | tail -${TAIL:-24} ;;
     timeline)
         ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$O/tl_prof" -o b --output-format csv -- python3 "$R/bench.py" \
             --no-cpu-baseline --no-exact-compare --launch graph --steps 8 --warmup 2 > /dev/null 2>&1 )
         T=$(find "$O/tl_prof" -name "*kernel_trace.csv" | head -1)
         python3 tools/timeline.py "$T" 3 0.25 > "$O/timeline.txt" 2>&1
+        python3 tools/queue_tail.py "$T" 70 > "$O/queue_tails.txt" 2>&1      # the tails of the backward chains, per hardware queue
         rm -f "$T"; head -60 "$O/timeline.txt" ;;
     pmc)
         for spec in "f16 16 16 96 fwd" "f48 48 16 96 fwd" "f32 32 32 48 fwd" "f4848 48 48 96 fwd" "w16 16 16 96 wgrad" "w32 32 32 48 wgrad"; do
