@@ -134,6 +134,89 @@ __global__ __launch_bounds__(256) void layernorm_bwd_longrow_kernel(const float*
   }
 }
 
+// Input gradient AND the row-chunk partials of dgamma / dbeta in one pass over gy and x (rows of fewer than 1024 columns, one wave per row): one
+// launch instead of two on the backward chains of the aligner heads, where every dependent launch costs 10-15 us (profiles/r4_timeline.md).
+// Workgroup j owns rows [j rpb, (j + 1) rpb); its four waves walk them RU rows at a time (RU independent rows in flight per wave), every lane
+// keeps the running sums of its CPL columns, and the four waves' sums are folded through LDS in wave order into part_g[j][c], part_b[j][c] — the
+// layout layernorm_wgrad_kernel writes, summed by colsum_multi_kernel in chunk order as before (no float atomics).  grid = chunks, C <= 64 CPL.
+template <int CPL, int RU>
+__global__ __launch_bounds__(256) void layernorm_bwd_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, float* __restrict__ gx,
+                                                                  float* __restrict__ part_g, float* __restrict__ part_b, long rows, int C,
+                                                                  long rpb) {
+  __shared__ float fold[2][3][64 * CPL];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * rpb;
+  const long r1 = r0 + rpb < rows ? r0 + rpb : rows;
+  float a[CPL], b[CPL], gam[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    a[k] = b[k] = 0.f;
+    gam[k] = lane + 64 * k < C ? gamma[lane + 64 * k] : 0.f;
+  }
+  for (long rb = r0 + wid * RU; rb < r1; rb += 4 * RU) {
+    float gv[RU][CPL], xh[RU][CPL], rs[RU], s1[RU], s2[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const long r = rb + u < r1 ? rb + u : r1 - 1;            // a row past the chunk re-reads the last one; it is neither stored nor summed
+      const float m = mean[r];
+      rs[u] = rstd[r];
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        const int c = lane + 64 * k;
+        gv[u][k] = c < C ? gy[r * C + c] : 0.f;
+        xh[u][k] = c < C ? x[r * C + c] - m : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      s1[u] = s2[u] = 0.f;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        xh[u][k] *= rs[u];
+        const float g = gv[u][k] * gam[k];
+        s1[u] += g;
+        s2[u] += g * xh[u][k];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      s1[u] = wave_sum(s1[u]) / (float)C;
+      s2[u] = wave_sum(s2[u]) / (float)C;
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (rb + u >= r1) break;
+      float* o = gx + (rb + u) * C;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) o[c] = rs[u] * (gv[u][k] * gam[k] - s1[u] - xh[u][k] * s2[u]);
+        a[k] += gv[u][k] * xh[u][k];
+        b[k] += gv[u][k];
+      }
+    }
+  }
+  if (wid > 0) {
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      fold[0][wid - 1][lane + 64 * k] = a[k];
+      fold[1][wid - 1][lane + 64 * k] = b[k];
+    }
+  }
+  __syncthreads();
+  if (wid == 0) {
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      if (c >= C) continue;
+      part_g[(long)blockIdx.x * C + c] = ((a[k] + fold[0][0][c]) + fold[0][1][c]) + fold[0][2][c];
+      part_b[(long)blockIdx.x * C + c] = ((b[k] + fold[1][0][c]) + fold[1][1][c]) + fold[1][2][c];
+    }
+  }
+}
+
 // Partial sums of dgamma[c] = sum_rows gy*xhat and dbeta[c] = sum_rows gy: row chunk j (blockIdx.y) writes part_g[j][c] and
 // part_b[j][c]; colsum_multi_kernel adds the chunks in a fixed order (no float atomics: the step is bit-reproducible).  A workgroup
 // covers `cols` = min(C,256) columns x (256/cols) row lanes so that short rows still read full 256-byte lines; grid (ceil(C/cols), chunks).
