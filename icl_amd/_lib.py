@@ -78,6 +78,7 @@ _SIGNATURES = {
     "icl_linear_ws_bytes": (c_int64, [L, I, I, I]),
     "icl_linear_fwd": (c_int, [P, P, P, P, P, L, I, I, I, P]),
     "icl_linear_dgrad": (c_int, [P, P, P, P, L, I, I, P]),
+    "icl_linear_bwd_small": (c_int, [P, P, P, P, P, P, L, I, I, P]),
     "icl_linear_wgrad_small": (c_int, [P, P, P, P, L, I, I, P]),
     "icl_linear_dgrad_sgd": (c_int, [P, P, P, P, P, P, L, I, I, F, F, F, I, P, P]),
     "icl_gemm_ws_bytes": (c_int64, [L, I, I, I]),

@@ -82,10 +82,34 @@ __device__ __forceinline__ void reduce_slabs_rect(const float* slab, float* out,
 template <int MT, bool NN, int P>
 __global__ __launch_bounds__(512) void linear_stream_kernel(const float* __restrict__ xs, const float* __restrict__ w, float* __restrict__ slab,
                                                             int M, int K, int O, int slice_len, int upw, const float* __restrict__ bias,
-                                                            int act, float* __restrict__ y, unsigned* __restrict__ tickets) {
+                                                            int act, float* __restrict__ y, unsigned* __restrict__ tickets,
+                                                            const float* __restrict__ wg_x, float* __restrict__ wg_dw, int wg_blocks) {
   ICL_DYN_LDS(float, lds);
   float* xl = lds;                                        // [16 MT][slice_len], quad q of row m stored at quad q ^ (m & 15)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, u = lane & 15, lg = lane >> 4;
+  if (NN && wg_dw != nullptr && (int)blockIdx.x >= (int)gridDim.x - wg_blocks) {
+    // The last `wg_blocks` workgroup columns of an input-gradient launch compute the layer's WEIGHT gradient dw[o][k] = sum_r xs[r][o] wg_x[r][k]
+    // (xs = dY [M][O], wg_x = the layer input [M][K]): the arithmetic of linear_wgrad_outer_kernel, in the same launch — one dependent
+    // launch fewer per small Linear layer on the aligner heads' backward chains (profiles/r4_timeline.md).
+    if (blockIdx.y != 0) return;
+    const int wb = (int)blockIdx.x - ((int)gridDim.x - wg_blocks);
+    const int iq = K >> 2;
+    const long total = (long)O * iq;
+    for (long e = (long)wb * 512 + tid; e < total; e += (long)wg_blocks * 512) {
+      const int o = (int)(e / iq), i = (int)(e % iq) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < M; ++r) {
+        const float g = xs[(long)r * O + o];
+        const float4 xv = *reinterpret_cast<const float4*>(wg_x + (long)r * K + i);
+        acc.x = fmaf(g, xv.x, acc.x);
+        acc.y = fmaf(g, xv.y, acc.y);
+        acc.z = fmaf(g, xv.z, acc.z);
+        acc.w = fmaf(g, xv.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(wg_dw + (long)o * K + i) = acc;
+    }
+    return;
+  }
   float* wl = lds + 16 * MT * slice_len + wid * 1024;     // this wave's 16 x 64 weight tile
   const int cdim = NN ? O : K;                            // contraction axis (columns of xs)
   const int c0 = blockIdx.y * slice_len;

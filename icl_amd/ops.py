@@ -1139,6 +1139,7 @@ def drop_path(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Te
 # --------------------------------------------------------------------------------------
 
 LINEAR_WGRAD_MIN_ROWS = 2048
+LINEAR_BWD_ONE_LAUNCH = os.environ.get("ICL_LINEAR_BWD_ONE_LAUNCH", "1") != "0"
 
 
 def linear_forward_raw(x2: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0) -> torch.Tensor:
@@ -1278,12 +1279,27 @@ class _Linear(torch.autograd.Function):
         o, i = weight.shape
         gx = gw = gb = None
         g2 = gy.reshape(-1, o).contiguous()
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if need_b and ctx.bias_param is not None and DeferredBiasGrads.defer(ctx.bias_param, g2):
+            need_b = False      # reduced with all the other bias gradients of the step (DeferredBiasGrads.flush)
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and g2.shape[0] <= 32 and LINEAR_BWD_ONE_LAUNCH:
+            # few rows (the aligner's query-side layers): input gradient and weight gradient in ONE launch — these layers sit on the
+            # backward chains the step waits for, where a dependent launch costs 10-15 us (profiles/r4_timeline.md)
+            _require(g2, weight, x2)
+            L = _lib.lib()
+            rows = g2.shape[0]
+            gx2 = torch.empty((rows, i), dtype=torch.float32, device=g2.device)
+            gw2 = torch.empty((o, i), dtype=torch.float32, device=g2.device)
+            need = L.icl_linear_ws_bytes(rows, i, o, 1)
+            ws = _ws(need, g2) if need else None
+            rc = L.icl_linear_bwd_small(_ptr(g2), _ptr(weight), _ptr(x2), _ptr(gx2), _ptr(gw2), _ptr(ws), rows, i, o, _stream(g2))
+            if rc == 0:
+                return gx2.view(ctx.x_shape), gw2, (g2.sum(0) if need_b else None), None
+            if rc != 1:      # 1: shapes that do not take that path
+                _lib.check(rc, "linear_bwd_small")
         if ctx.needs_input_grad[0]:
             gx = linear_dgrad_raw(g2, weight).view(ctx.x_shape)
-        need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or need_b:
-            if need_b and ctx.bias_param is not None and DeferredBiasGrads.defer(ctx.bias_param, g2):
-                need_b = False      # reduced with all the other bias gradients of the step (DeferredBiasGrads.flush)
             if ctx.needs_input_grad[1]:
                 gw, gb = _tall_atb(g2, x2, need_b)
             elif need_b:

@@ -261,6 +261,10 @@ int64_t icl_linear_ws_bytes(int64_t rows, int in, int out, int kind);
 int icl_linear_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, int64_t rows, int in, int out, int act,
                    void* stream);
 int icl_linear_dgrad(const float* gy, const float* w, float* gx, void* ws, int64_t rows, int in, int out, void* stream);
+/* gx = gy W AND dW = gy^T x of a Linear layer that sees <= 32 rows (the aligner's query-side layers, unet_3D_icl.py:283-315) in one launch;
+ * returns 1 (nothing launched) when the shapes do not take the weight-streaming path: call icl_linear_dgrad + icl_linear_wgrad_small then */
+int icl_linear_bwd_small(const float* gy, const float* w, const float* x, float* gx, float* dw, void* ws, int64_t rows, int in, int out,
+                         void* stream);
 int icl_linear_wgrad_small(const float* gy, const float* x, float* dw, void* ws, int64_t rows, int in, int out, void* stream);
 /* Backward + optimiser step of a big skinny Linear in ONE pass over its weight (single rank, the weight used once per step):
  * gx[rows, in] = gy[rows, out] W_old, then W / momentum are updated from the factors of dW = gy^T x with the SGD rule of

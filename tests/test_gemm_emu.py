@@ -109,6 +109,23 @@ def test_last_arriving_workgroup_sums_the_partials_bitwise_like_the_second_launc
             assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("rows,i,o", [(4, 64, 256), (8, 256, 1024), (16, 1024, 1024), (24, 1056, 1024), (32, 128, 64), (2, 132, 192)])
+def test_small_linear_backward_in_one_launch_equals_the_two_launches(rows, i, o):
+    """icl_linear_bwd_small: the weight-streaming input-gradient launch with extra workgroup columns for the outer-product weight gradient —
+    bit for bit the results of icl_linear_dgrad and icl_linear_wgrad_small (one slice and several, one and two row tiles)."""
+    L = _lib.lib()
+    g, x, w = _rand((rows, o), 21), _rand((rows, i), 22), _rand((o, i), 23) * 0.05
+    gx_ref = ops.linear_dgrad_raw(g, w)
+    gw_ref = ops._tall_atb(g, x, False)[0]
+    gx, gw = torch.empty(rows, i), torch.empty(o, i)
+    need = L.icl_linear_ws_bytes(rows, i, o, 1)
+    ws = torch.empty(max(1, need // 4))
+    rc = L.icl_linear_bwd_small(g.data_ptr(), w.data_ptr(), x.data_ptr(), gx.data_ptr(), gw.data_ptr(), ws.data_ptr() if need else None,
+                                rows, i, o, None)
+    assert rc == 0, (rc, _lib.last_error())
+    assert torch.equal(gx, gx_ref) and torch.equal(gw, gw_ref)
+
+
 def test_linear_autograd_matches_torch():
     x = _rand((2, 6, 40), 10).requires_grad_()
     w = (_rand((24, 40), 11) * 0.2).requires_grad_()
