@@ -51,6 +51,13 @@ class BatchNorm3d(BatchNormAct):
         super().__init__(c, 1, device)
 
 
+def _open_tail_gate(grad):
+    opt = ops.FactoredGrads.fused_optimizer
+    if opt is not None and getattr(opt, "update_placement", "") == "tail":
+        opt.flush_deferred(gate=True)
+    return None
+
+
 class DropPath(nn.Module):
     """Per-sample stochastic depth (MONAI DropPath semantics)."""
 
@@ -236,6 +243,10 @@ class InherentConsistent(nn.Module):
         for i in range(len(self.depth)):
             tok = self._tokens(i, feats[i])
             q_out, attn = self.class_decoders[i].attend(nxt, tok)
+            if i == len(self.depth) - 1 and attn.requires_grad:
+                # backward: when the logits' gradient of the LAST level arrives, that level's map chain (the two big weight streams) is done
+                # and what remains of this aligner is the serial query chain — the gate of FusedSGD's "tail" update placement
+                attn.register_hook(_open_tail_gate)
             # the map chain of this level (token-axis MLP + separable convolutions) does not feed the next level: its own lane
             with ops.SideStream([attn], lane=(1 + i) if ops.SideStream.lane_mask & 1 else 99) as lane:
                 attn = self.class_decoders[i].refine(attn)

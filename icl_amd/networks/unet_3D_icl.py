@@ -10,6 +10,8 @@ tests build small instances of the same class.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import ops
@@ -27,6 +29,10 @@ class unet_3D_icl(UNet3DBackbone):  # noqa: N801 — reference class name
                   num_classes=n_classes, num_heads=tuple(icl_heads), device=device)
         self.sspa = InherentConsistent(**kw)
         self.uscl = InherentConsistent(**kw)
+        # FusedSGD update_placement "tail" (optim.py): the SGD streams of sspa's two 13,824^2 matrices run beside sspa's serial query chain
+        # (the last millisecond of the backward's forked phase) instead of inside the map chain in front of it
+        for p in self.sspa.class_decoders[-1].mlp2.parameters():
+            p._icl_tail_update = True
 
     def forward(self, x_lab, x_unlab=None, inference=None):
         if inference:

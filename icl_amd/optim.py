@@ -29,12 +29,16 @@ class FusedSGD(torch.optim.Optimizer):
         self._updated_in_backward = set()   # ids of the parameters whose update of this step already ran inside backward
         # Where the update of a big once-used matrix runs on a single rank (update_in_backward):
         #   "fused"  inside its backward, in the pass that computes the input gradient (one read of the matrix, 20 B/weight and step)
+        #            — what "tail" (the default) does for every matrix the model has not marked
         #   "gated"  the backward only computes the input gradient (4 B/weight); the update (16 B/weight) is queued on an update stream
         #            that starts when the model opens the gate (flush_deferred() from a gradient hook where the chip-filling part of
         #            the backward ends) and is joined in step(): 24 B/weight and step, but the HBM stream runs next to the small
         #            deep-level kernels instead of next to the 96^3 / 48^3 convolutions (tools/critical_path.py)
         #   "free"   like "gated" without the gate: the update stream only waits for the input-gradient kernel of its matrix
-        self.update_placement = os.environ.get("ICL_UPDATE_PLACEMENT", "fused")
+        #   "tail"   "gated" for the matrices the model marks (`_icl_tail_update`: the own-query aligner's 24^3 level), with the gate where
+        #            that level's map chain is done and only the serial query chain is left (~1 ms of small dependent launches that leave
+        #            the chip idle): their update streams run beside that chain; every other matrix stays fused
+        self.update_placement = os.environ.get("ICL_UPDATE_PLACEMENT", "tail")
         self._deferred = []          # (parameter, g, x, event after the input-gradient kernel)
         self._update_stream = None
         self._update_stream_used = False
@@ -153,7 +157,7 @@ class FusedSGD(torch.optim.Optimizer):
         from . import ops
         L = _lib.lib()
         g, x = g.contiguous(), x.contiguous()
-        if self.update_placement != "fused" and p.is_cuda:
+        if self.update_placement != "fused" and p.is_cuda and (self.update_placement != "tail" or getattr(p, "_icl_tail_update", False)):
             gx = ops.linear_dgrad_raw(g, p)
             ev = torch.cuda.Event()
             ev.record()

@@ -958,7 +958,10 @@ def test_update_inside_backward_equals_update_in_optimizer_step(dev):
         with ops.KernelTimer() as kt:
             losses = [float(tr.step(vol, lab)["loss"]) for _ in range(3)]
         n = kt.summary().get("linear_dgrad_sgd_kernel", (0,))[0]
-        assert n == (12 if fuse else 0), n                       # four matrices x three steps, or none
+        # uscl's two matrices x three steps in the fused pass; sspa's two take the "tail" placement (FusedSGD.update_placement: input
+        # gradient in their backward, the update on a stream beside sspa's query chain) — or none at all
+        assert n == (6 if fuse else 0), n
+        assert tr.optimizer.update_placement == "tail"
         big = {k: p for k, p in model.named_parameters() if p.numel() >= 1 << 26}
         assert len(big) == 4
         out.append((losses, {k: p.detach().clone() for k, p in big.items()},
