@@ -579,7 +579,7 @@ def _conv3d_tiny_volume(x, weight, bias):
     dW through its tall/skinny paths)."""
     n, cin, d, h, w = x.shape
     cout = weight.shape[0]
-    y = linear(_Im2Col3.apply(x), weight.flatten(1), bias)            # [n*S, cout]
+    y = linear(_Im2Col3.apply(x), weight.flatten(1), bias, lane_wgrad=True)            # [n*S, cout]; dW beside the input gradient (WgradLane)
     return y.view(n, d * h * w, cout).permute(0, 2, 1).reshape(n, cout, d, h, w)
 
 
@@ -1261,10 +1261,11 @@ class _Linear(torch.autograd.Function):
     inputs (>= 2048 rows: the Swin token grids) use csrc/kernels/linear_wgrad.h, of short ones the k-strided tiled product."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, owner=None):
+    def forward(ctx, x, weight, bias, owner=None, lane_wgrad=False):
         weight = weight.contiguous()
         x2 = x.reshape(-1, weight.shape[1]).contiguous()
         ctx.save_for_backward(x2, weight)
+        ctx.lane_wgrad = bool(lane_wgrad)
         ctx.has_bias = bias is not None
         # the Parameter behind the bias (for DeferredBiasGrads: all small bias gradients of a step reduced in one launch): the
         # owner's, or the argument itself when the caller passed a Parameter without naming its module
@@ -1294,17 +1295,25 @@ class _Linear(torch.autograd.Function):
             ws = _ws(need, g2) if need else None
             rc = L.icl_linear_bwd_small(_ptr(g2), _ptr(weight), _ptr(x2), _ptr(gx2), _ptr(gw2), _ptr(ws), rows, i, o, _stream(g2))
             if rc == 0:
-                return gx2.view(ctx.x_shape), gw2, (g2.sum(0) if need_b else None), None
+                return gx2.view(ctx.x_shape), gw2, (g2.sum(0) if need_b else None), None, None
             if rc != 1:      # 1: shapes that do not take that path
                 _lib.check(rc, "linear_bwd_small")
+        # the product form of a 6^3 convolution (conv3d on tiny volumes): its weight gradient goes to the lane of the deep levels' weight gradients
+        lane = ctx.lane_wgrad and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not need_b and WgradLane.wants(g2, 0)
+        if lane:
+            WgradLane.fork_point(g2)
         if ctx.needs_input_grad[0]:
             gx = linear_dgrad_raw(g2, weight).view(ctx.x_shape)
         if ctx.needs_input_grad[1] or need_b:
             if ctx.needs_input_grad[1]:
-                gw, gb = _tall_atb(g2, x2, need_b)
+                if lane:
+                    with WgradLane.on_lane(g2, x2):
+                        gw, gb = _tall_atb(g2, x2, False)
+                else:
+                    gw, gb = _tall_atb(g2, x2, need_b)
             elif need_b:
                 gb = g2.sum(0)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 class _ConvTransposeGemm(torch.autograd.Function):
@@ -1411,7 +1420,7 @@ class _LinearFactored(torch.autograd.Function):
         return gx, None, gb, None
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], owner=None) -> torch.Tensor:
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], owner=None, lane_wgrad: bool = False) -> torch.Tensor:
     """F.linear.  ``owner``: the module whose ``.weight`` this is — lets the gradient stay factored (see FactoredGrads)."""
     if FactoredGrads.uses is not None:
         # every use of a weight in this step, whichever autograd path it takes below: the update-inside-backward of
@@ -1423,7 +1432,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
             and (x.numel() // x.shape[-1]) * FactoredGrads.world <= FactoredGrads.max_rows_gathered
             and weight.shape[1] % 4 == 0 and torch.is_grad_enabled()):
         return _LinearFactored.apply(x, weight, bias, owner)
-    return _Linear.apply(x, weight, bias, owner)
+    return _Linear.apply(x, weight, bias, owner, lane_wgrad)
 
 
 class _LayerNorm(torch.autograd.Function):
