@@ -1620,7 +1620,7 @@ class _SplitBatch(torch.autograd.Function):
             gb = gb.contiguous() if gb is not None else None
             out = torch.empty((ctx.n,) + ctx.tail, dtype=torch.float32, device=ref.device)
             if all(t is None or t.data_ptr() % 16 == 0 for t in (ga, gb)):
-                _lib.check(_lib.lib().icl_concat2(_ptr(ga), na if ga is not None else na, _ptr(gb), nb, _ptr(out), _stream(ref)), "concat2")
+                _lib.check(_lib.lib().icl_concat2(_ptr(ga), na, _ptr(gb), nb, _ptr(out), _stream(ref)), "concat2")
                 return out, None
         if ga is None:
             ga = ref.new_zeros((ctx.k,) + ctx.tail)

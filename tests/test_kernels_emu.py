@@ -147,6 +147,23 @@ def test_conv3d_hands_instance_norm_its_statistics(monkeypatch, n, cin, cout, d,
     assert float((out - own).abs().max()) < 2e-6 and float((out - want).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("use", ["both", "first", "second"])
+def test_split_batch_gradient_is_one_concatenation(use):
+    """x[:k], x[k:] through ops.split_batch: the gradient is one launch (icl_concat2), a half that received no gradient comes back as zeros."""
+    x = _rand((3, 2, 4, 2, 6), 91).requires_grad_()
+    a, b = ops.split_batch(x, 1)
+    assert torch.equal(a, x[:1]) and torch.equal(b, x[1:])
+    ga, gb = _rand(a.shape, 92), _rand(b.shape, 93)
+    loss = (a * ga).sum() * (use != "second") + (b * gb).sum() * (use != "first")
+    if use == "first":
+        loss = (a * ga).sum()
+    elif use == "second":
+        loss = (b * gb).sum()
+    loss.backward()
+    want = torch.cat([ga if use != "second" else torch.zeros_like(ga), gb if use != "first" else torch.zeros_like(gb)], 0)
+    assert torch.equal(x.grad, want)
+
+
 def test_skip_and_pool_adds_the_two_gradients_in_one_pass():
     """ops.skip_and_pool (maxpool2_bwd_add_kernel): the gradient of an encoder output = its skip gradient (a batch-strided channel slice
     of the concat gradient, as _UpCat.backward hands it over) + the pooling backward; reference: autograd on x -> (x, max_pool3d(x))."""
