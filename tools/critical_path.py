@@ -43,7 +43,9 @@ def run_backbone(self, x, heads=None):
     c1, p1 = ops.skip_and_pool(self.conv1(x))
     c2, p2 = ops.skip_and_pool(self.conv2(grad_mark(p1, "B gradient of pool1 ready (conv2..4 backward done)")))
     c3, p3 = ops.skip_and_pool(self.conv3(p2))
+    c3 = grad_mark(c3, "B skip gradient of c3 ready (up_concat3's convolutions and concat backward done)")
     c4, p4 = ops.skip_and_pool(self.conv4(p3))
+    c4 = grad_mark(c4, "B skip gradient of c4 ready (up_concat4 backward done)")
     p4 = grad_mark(p4, "B gradient of pool4 ready (center backward done)")
     mark("F encoder done")
     center = self.dropout1(self.center(p4))
@@ -54,6 +56,8 @@ def run_backbone(self, x, heads=None):
     up3.register_hook(U._open_update_gate)
     a_in = [grad_mark(center, "B aligner gradient of center ready"), grad_mark(up4, "B aligner gradient of up4 ready"),
             grad_mark(up3, "B aligner gradient of up3 ready")]
+    if os.environ.get("CP_DETACH_HEADS", "0") != "0":      # what would the step take if the deep backward did not wait for the aligners?
+        a_in = [t.detach() for t in a_in]
     extra = heads(a_in)
     up2 = self.up_concat2(c2, grad_mark(up3, "B decoder gradient of up3 ready (up2/up1/final backward done)"))
     up1 = self.dropout2(self.up_concat1(c1, up2))
