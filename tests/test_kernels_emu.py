@@ -76,6 +76,12 @@ def test_conv3d_wgrad_row_window_kernel(monkeypatch, mode, n, cin, cout, d, h, w
 ])
 @pytest.mark.parametrize("variant", ["default", "60", "24", "8", "0", "4"])
 def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w, variant):
+    # the superseded schedules (24, 8, 0, 4: still selectable with ICL_CONV_SPLIT_V for A/B runs) are checked on the shapes that reach every
+    # code path of theirs — one / two / three cout blocks, ragged chunks, flat tiles — not on every shape: the emulator needs a minute for the
+    # big ones and the CPU suite has to stay short
+    if variant in ("24", "8", "0", "4") and (n, cin, cout, d, h, w) not in ((1, 16, 16, 4, 8, 16), (2, 32, 20, 5, 9, 20), (1, 16, 48, 3, 4, 12),
+                                                                             (1, 48, 40, 2, 8, 16), (1, 16, 16, 3, 9, 24)):
+        pytest.skip("superseded schedule: covered on the smaller shapes")
     """conv_bf16x3.h: forward and input gradient with each fp32 operand split exactly into three bf16 terms (six bf16 MFMA terms per
     product, fp32 accumulation) — same tolerance as the fp32-MFMA kernels, and the two paths agree to fp32 rounding.  variant: the
     schedule of the forward kernel (8 = all weight planes of a chunk in LDS for one cout block, the default; 0 = one plane per dz
