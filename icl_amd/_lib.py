@@ -59,6 +59,8 @@ _SIGNATURES = {
     "icl_dwconv3_wgrad_ws_bytes": (c_int64, [I, I, I, I, I]),
     "icl_dwconv3_wgrad": (c_int, [P, P, P, P, I, I, I, I, I, P]),
     "icl_conv1x1_small": (c_int, [P, P, P, P, I, I, I, L, I, I, P]),
+    "icl_conv1x1_dropout": (c_int, [P, P, P, P, I, I, I, L, I, I, I, ctypes.c_uint32, F, P, P]),
+    "icl_conv1x1_wgrad_dropout": (c_int, [P, P, P, P, P, I, I, I, L, L, ctypes.c_uint32, F, P, P]),
     "icl_dropout": (c_int, [P, P, L, ctypes.c_uint32, F, P, P]),
     "icl_drop_path": (c_int, [P, P, L, L, ctypes.c_uint32, F, P, P]),
     "icl_drop_path_add": (c_int, [P, P, P, L, L, ctypes.c_uint32, F, P, P]),

@@ -90,8 +90,9 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 // grid (nsplit/4, ceil(O/48), ceil(I/48)), block 256; the (batch, voxel-group) range is split over nsplit waves.
 __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                             float* __restrict__ slabs, int N, long S, int O, int I, int nsplit,
-                                                            long g_bstride, long x_bstride) {
+                                                            long g_bstride, long x_bstride, DropSpec dr) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const unsigned dseed = dr.mode ? drop_seed(dr) : 0u;      // mode 1: x is a dropped tensor (contiguous [N, I, S]) whose mask is applied on load
   const int split = blockIdx.x * 4 + wid;
   const int o0 = blockIdx.y * kLwB, i0 = blockIdx.z * kLwB;
   const long gps = S / 16;                                 // groups of 16 voxels per sample
@@ -123,7 +124,10 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restr
       av[a] = make_float4(0.f, 0.f, 0.f, 0.f);
       bv[a] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (rv && ov[a]) av[a] = *reinterpret_cast<const float4*>(g + b * g_bstride + (long)(o0 + a * 16 + lr) * S + v);
-      if (rv && iv[a]) bv[a] = *reinterpret_cast<const float4*>(x + b * x_bstride + (long)(i0 + a * 16 + lr) * S + v);
+      if (rv && iv[a]) {
+        bv[a] = *reinterpret_cast<const float4*>(x + b * x_bstride + (long)(i0 + a * 16 + lr) * S + v);
+        if (dr.mode == 1) bv[a] = drop_apply4(bv[a], dseed, dr.thresh, dr.scale, (b * I + (i0 + a * 16 + lr)) * S + v);
+      }
     }
 #pragma unroll
     for (int a = 0; a < kLwT; ++a) {

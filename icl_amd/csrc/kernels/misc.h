@@ -97,6 +97,30 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_reduce_kernel(const float* 
   gw[e] = v;
 }
 
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+
+// The element-wise dropout mask of dropout_kernel (below) for kernels that apply it on the fly: keep(k) = hash(seed, k) >= thresh, k = the flat
+// index of the element in the dropped tensor.  mode 0: off; 1: the kernel's INPUT x is the dropped tensor (forward of dropout -> conv, and the
+// weight gradient's x operand); 2: its OUTPUT is (the input gradient: d(dropout) applied to what the convolution's backward produces).
+struct DropSpec {
+  unsigned seed, thresh;
+  float scale;
+  const unsigned* seed_dev;
+  int mode;
+};
+__device__ __forceinline__ unsigned drop_seed(const DropSpec& d) { return d.seed_dev ? mix32(d.seed ^ mix32(*d.seed_dev + 0x632BE5ABu)) : d.seed; }
+__device__ __forceinline__ float drop_apply(float v, unsigned seed, unsigned thresh, float scale, long k) {
+  const unsigned h = mix32((unsigned)k * 0x9E3779B1u + seed) ^ mix32((unsigned)(k >> 32) + seed * 0x85EBCA77u);
+  return h >= thresh ? v * scale : 0.f;
+}
+__device__ __forceinline__ float4 drop_apply4(float4 v, unsigned seed, unsigned thresh, float scale, long k) {
+  return make_float4(drop_apply(v.x, seed, thresh, scale, k), drop_apply(v.y, seed, thresh, scale, k + 1), drop_apply(v.z, seed, thresh, scale, k + 2),
+                     drop_apply(v.w, seed, thresh, scale, k + 3));
+}
+
 // ---- 1x1x1 convolution with a handful of channels on a small volume (the aligner's SeparableConv3d.pointwise h -> h and attn_convs1
 // h -> 1 on <= 4 x 24^3 maps, unet_3D_icl.py:196,327, and their input gradients): y[b][o][v] = bias[o] + sum_i w(o, i) * x[b][i][v],
 // w(o, i) = w[o * w_ostride + i * w_istride] (the input gradient is the same kernel with the strides swapped).  One thread per
@@ -133,9 +157,10 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restr
 template <int OB>
 __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y, int N, int CI, int CO,
-                                                             long S, int wos, int wis) {
+                                                             long S, int wos, int wis, DropSpec dr) {
   const long S4 = S >> 2, total = (long)N * S4;
   const int o0 = blockIdx.y * OB;
+  const unsigned dseed = dr.mode ? drop_seed(dr) : 0u;
   float wb[OB];
 #pragma unroll
   for (int o = 0; o < OB; ++o) wb[o] = (bias && o0 + o < CO) ? bias[o0 + o] : 0.f;
@@ -146,7 +171,8 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const float* __rest
     for (int o = 0; o < OB; ++o) acc[o] = make_float4(wb[o], wb[o], wb[o], wb[o]);
     const float* xp = x + b * CI * S + (v4 << 2);
     for (int i = 0; i < CI; ++i) {
-      const float4 xv = *reinterpret_cast<const float4*>(xp + (long)i * S);
+      float4 xv = *reinterpret_cast<const float4*>(xp + (long)i * S);
+      if (dr.mode == 1) xv = drop_apply4(xv, dseed, dr.thresh, dr.scale, (b * CI + i) * S + (v4 << 2));      // dropout -> conv: the mask on load
 #pragma unroll
       for (int o = 0; o < OB; ++o) {
         const float wv = o0 + o < CO ? w[(long)(o0 + o) * wos + (long)i * wis] : 0.f;
@@ -158,7 +184,10 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const float* __rest
     }
 #pragma unroll
     for (int o = 0; o < OB; ++o)
-      if (o0 + o < CO) *reinterpret_cast<float4*>(y + (b * CO + o0 + o) * S + (v4 << 2)) = acc[o];
+      if (o0 + o < CO) {
+        if (dr.mode == 2) acc[o] = drop_apply4(acc[o], dseed, dr.thresh, dr.scale, (b * CO + o0 + o) * S + (v4 << 2));      // input gradient: the mask on store
+        *reinterpret_cast<float4*>(y + (b * CO + o0 + o) * S + (v4 << 2)) = acc[o];
+      }
   }
 }
 
@@ -323,11 +352,6 @@ __global__ __launch_bounds__(256) void col2im3_kernel(const float* __restrict__ 
   }
 }
 
-__device__ __forceinline__ unsigned mix32(unsigned x) {
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  return x;
-}
-
 // y = keep ? x*scale : 0 with keep(i) = hash(seed, i) >= thresh; the same (seed) regenerates the mask in backward.
 // seed_dev (optional): a device-resident step counter HASHED into the seed, so replays of a captured hipGraph draw new masks
 // (mixing it in linearly would make the mask of step t the mask of step 0 shifted by t elements).
@@ -340,8 +364,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   if (seed_dev) seed = mix32(seed ^ mix32(*seed_dev + 0x632BE5ABu));
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long k = group > 1 ? i / group : i;
-    const unsigned h = mix32((unsigned)k * 0x9E3779B1u + seed) ^ mix32((unsigned)(k >> 32) + seed * 0x85EBCA77u);
-    const float v = h >= thresh ? x[i] * scale : 0.f;
+    const float v = drop_apply(x[i], seed, thresh, scale, k);
     y[i] = res ? res[i] + v : v;
   }
 }

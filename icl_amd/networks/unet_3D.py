@@ -68,10 +68,15 @@ class UNet3DBackbone(nn.Module):
             up3.register_hook(_open_update_gate)
         extra = heads([center, up4, up3]) if heads is not None else None
         up2 = self.up_concat2(c2, up3)
-        up1 = self.dropout2(self.up_concat1(c1, up2))
+        up1 = self.up_concat1(c1, up2)
+        if self.dropout2.training and self.dropout2.p > 0.0:
+            # final(dropout2(up1)) with the mask applied inside the 1x1x1 convolution's passes (ops.dropout_conv1x1)
+            logits = ops.dropout_conv1x1(up1, self.final.weight, self.final.bias, self.dropout2.p)
+        else:
+            logits = self.final(self.dropout2(up1))
         if heads is not None:
-            return self.final(up1), [center, up4, up3], extra
-        return self.final(up1), [center, up4, up3]
+            return logits, [center, up4, up3], extra
+        return logits, [center, up4, up3]
 
 
 class unet_3D(UNet3DBackbone):  # noqa: N801 — reference class name

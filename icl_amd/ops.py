@@ -1119,6 +1119,70 @@ def dropout(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Tens
     return _Dropout.apply(x, float(p), int(seed) & 0xFFFFFFFF, seed_dev)
 
 
+class _DropoutConv1x1(torch.autograd.Function):
+    """conv1x1(dropout(x)) with the mask applied on the fly: forward (mask on the convolution's input loads), input gradient (mask on its
+    stores) and weight gradient (mask on the x operand) each run as ONE pass — the dropped tensor never exists."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, p, seed, seed_dev):
+        _require(x, weight, bias)
+        L = _lib.lib()
+        x = x.contiguous()
+        n, cin = x.shape[0], x.shape[1]
+        cout = weight.shape[0]
+        s = x.numel() // (n * cin)
+        y = torch.empty((n, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        _lib.check(L.icl_conv1x1_dropout(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), n, cin, cout, s, cin, 1, 1, seed, p, _ptr(seed_dev),
+                                         _stream(x)), "conv1x1_dropout")
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (p, seed, bias is not None)
+        ctx.seed_dev = seed_dev
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        p, seed, has_bias = ctx.cfg
+        L = _lib.lib()
+        gy = gy.contiguous()
+        n, cin = x.shape[0], x.shape[1]
+        cout = weight.shape[0]
+        s = x.numel() // (n * cin)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(L.icl_conv1x1_dropout(_ptr(gy), _ptr(weight), None, _ptr(gx), n, cout, cin, s, 1, cin, 2, seed, p, _ptr(ctx.seed_dev),
+                                             _stream(x)), "conv1x1_dropout dgrad")
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty_like(weight)
+            gb = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+            ws = _ws(L.icl_conv1x1_wgrad_ws_bytes(n, s, cin, cout), x)
+            with _timed("conv1x1_wgrad_kernel", 2.0 * cin * cout * s * n, 4.0 * n * s * (cin + cout), x):
+                _lib.check(L.icl_conv1x1_wgrad_dropout(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(ws), n, cin, cout, s, cout * s, seed, p,
+                                                       _ptr(ctx.seed_dev), _stream(x)), "conv1x1_wgrad_dropout")
+        return gx, gw, gb, None, None, None
+
+
+def dropout_conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], p: float, seed: Optional[int] = None) -> torch.Tensor:
+    """``conv3d(dropout(x, p), weight, bias)`` for a 1x1x1 (or 1x1) convolution of <= 16 channels on a big volume — `final(dropout2(up1))` of
+    the backbones (unet_3D_icl.py:67-68,117) — without materialising the dropped tensor.  Same seed protocol and the same mask as
+    ``dropout`` (so the results are those of the two-op form, bit for bit); other shapes take the two-op form."""
+    n, cin = x.shape[0], x.shape[1]
+    s = x.numel() // max(n * cin, 1)
+    fusable = (x.is_cuda or _lib.host_pointers_ok()) and weight.shape[2:].numel() == 1 and cin <= 16 and weight.shape[0] <= 16 \
+        and s % 4 == 0 and n * s >= 65536 and torch.is_grad_enabled() and os.environ.get("ICL_DROPOUT_CONV_FUSED", "1") != "0"
+    if not fusable:
+        return conv3d(dropout(x, p, seed), weight, bias)
+    seed_dev = None
+    if seed is None:
+        if StepRNG.tensor is not None and StepRNG.tensor.device == x.device:
+            seed = StepRNG.next_seed()
+            seed_dev = StepRNG.tensor
+        else:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return _DropoutConv1x1.apply(x, weight, bias, float(p), int(seed) & 0xFFFFFFFF, seed_dev)
+
+
 def drop_path(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Tensor:
     """Per-sample stochastic depth (timm / MONAI DropPath): each sample of the batch keeps its branch with probability 1-p (scaled
     by 1/(1-p)) or drops it entirely — one kernel instead of empty + bernoulli_ + div + mul; same seeding scheme as ``dropout``."""

@@ -146,6 +146,13 @@ int icl_dwconv3_wgrad(const float* x, const float* gy, float* gw, void* ws, int 
  * y [n, cout, s], s % 4 == 0, bias may be NULL.  The input gradient is the same call with the strides swapped. */
 int icl_conv1x1_small(const float* x, const float* w, const float* bias, float* y, int n, int cin, int cout, int64_t s, int w_ostride,
                       int w_istride, void* stream);
+/* the same with nn.Dropout(p) folded in (the mask of icl_dropout, same seed protocol; unet_3D_icl.py:67-68,117: `final(dropout2(up1))`):
+ * mask_mode 1: the INPUT is the dropped tensor (forward); 2: the OUTPUT is (the pair's input gradient).  Returns 1 (nothing launched) for
+ * n * s < 65536: run icl_dropout and icl_conv1x1_small then.  icl_conv1x1_wgrad_dropout: the pair's weight gradient from the un-dropped x. */
+int icl_conv1x1_dropout(const float* x, const float* w, const float* bias, float* y, int n, int cin, int cout, int64_t s, int w_ostride,
+                        int w_istride, int mask_mode, uint32_t seed, float p, const uint32_t* seed_dev, void* stream);
+int icl_conv1x1_wgrad_dropout(const float* x, const float* gy, float* gw, float* gbias, void* ws, int n, int cin, int cout, int64_t s,
+                              int64_t gy_bstride, uint32_t seed, float p, const uint32_t* seed_dev, void* stream);
 
 /* ---- nn.Dropout(p) (networks/unet_3D_icl.py:67-68,110,116): y = keep ? x/(1-p) : 0 with a counter-based
  * mask keyed by (seed, element index); calling it again with the same seed on dY is the backward.  seed_dev (may be

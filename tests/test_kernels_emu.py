@@ -153,6 +153,26 @@ def test_conv3d_hands_instance_norm_its_statistics(monkeypatch, n, cin, cout, d,
     assert float((out - own).abs().max()) < 2e-6 and float((out - want).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("n,cin,cout,s3", [(2, 16, 2, (32, 32, 32)), (1, 12, 5, (8, 96, 96)), (1, 16, 16, (4, 128, 128))])
+def test_dropout_folded_into_the_1x1_convolution_equals_the_two_ops(n, cin, cout, s3):
+    """ops.dropout_conv1x1 (`final(dropout2(up1))`): the mask applied on the convolution's input loads (forward), on the input gradient's stores
+    and on the weight gradient's x operand — the results of dropout followed by the convolution, bit for bit, with the same seed."""
+    x = _rand((n, cin) + s3, 101, True)
+    w = (_rand((cout, cin, 1, 1, 1), 102) * 0.3).requires_grad_()
+    b = _rand((cout,), 103, True)
+    gy = _rand((n, cout) + s3, 104)
+    y = ops.dropout_conv1x1(x, w, b, 0.3, seed=1234)
+    assert y.grad_fn.__class__.__name__ == "_DropoutConv1x1Backward"
+    y.backward(gy)
+    xr, wr, br = (t.detach().clone().requires_grad_() for t in (x, w, b))
+    yr = ops.conv3d(ops.dropout(xr, 0.3, seed=1234), wr, br)
+    yr.backward(gy)
+    dropped = float((ops.dropout(xr.detach(), 0.3, seed=1234) == 0).float().mean())
+    assert 0.25 < dropped < 0.35
+    assert torch.equal(y.detach(), yr.detach()) and torch.equal(x.grad, xr.grad)
+    assert torch.equal(w.grad, wr.grad) and torch.equal(b.grad, br.grad)
+
+
 @pytest.mark.parametrize("use", ["both", "first", "second"])
 def test_split_batch_gradient_is_one_concatenation(use):
     """x[:k], x[k:] through ops.split_batch: the gradient is one launch (icl_concat2), a half that received no gradient comes back as zeros."""
