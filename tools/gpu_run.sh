@@ -22,10 +22,11 @@ task() {
   local t=$1; shift
   case $t in
     suite) python -m pytest tests -m gpu -q -x 2>&1 | tail -${TAIL:-6} ;;
-    bench) python bench.py --no-cpu-baseline --no-exact-compare "$@" 2>/dev/null | line "bench $*" ;;
+    bench) timeout 600 python bench.py --no-cpu-baseline --no-exact-compare "$@" 2>/dev/null | line "bench $*" ;;
     ab) local var=$1 a=$2 b=$3; shift 3
         for rep in 1 2; do for v in "$a" "$b"; do
-          env "$var=$v" python bench.py --no-cpu-baseline --no-exact-compare --steps 30 "$@" 2>/dev/null | line "$var=$v"
+          # (a runtime knob that makes the replay hang must not hold the box until gpurun's own limit)
+          env "$var=$v" timeout 300 python bench.py --no-cpu-baseline --no-exact-compare --steps 30 "$@" 2>/dev/null | line "$var=$v" || echo "$var=$v: no result (timeout or error)"
         done; done ;;
     stats) local name=$1; shift
         ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$O/${name}_prof" -o b --output-format csv -- python3 "$R/bench.py" \
