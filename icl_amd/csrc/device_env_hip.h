@@ -96,6 +96,10 @@ __device__ __forceinline__ void icl_buffer_load_lds_b128(icl_rsrc_t r, void* lds
 // v_alignbit_b32: bits [sh, sh + 32) of the 64-bit value {hi, lo}
 __device__ __forceinline__ unsigned icl_alignbit(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
+// v_med3_f32: the median of three (one instruction).  med3(t, 0, +inf) = max(t, 0); med3(t, 0, 0) = 0: a clamp whose upper bound
+// doubles as a per-lane "this position is padding" switch (kernels/conv_cl16.h)
+__device__ __forceinline__ float icl_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
 // v_exp_f32 based exp (2 instructions); the CPU emulation maps it to expf
 __device__ __forceinline__ float icl_fast_exp(float x) { return __expf(x); }
 

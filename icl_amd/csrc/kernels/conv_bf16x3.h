@@ -490,6 +490,15 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       for (int r = 0; r < ROUNDS; ++r) split_round(r);
     }
   }
+  // the bias of the lane's output channels, loaded once (inside the epilogue it is a global load per work item whose latency every wave
+  // waits out in front of its stores: conv_bf16x3_ws.h)
+  float bvs[NBT];
+#pragma unroll
+  for (int j = 0; j < NBT; ++j) {
+    const int co = n0 + j * 16 + lr;
+    bvs[j] = (bias && co < g.Cout) ? bias[co] : 0.f;
+    ICL_PIN1(bvs[j]);
+  }
   bool first_item = true;
   int item_no = -1;
   Origin nxt = {x, 0, 0, 0, 0, 0};
@@ -694,7 +703,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #pragma unroll
       for (int j = 0; j < NBT; ++j) {
         const int co = n0 + j * 16 + lr;
-        const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+        const float bv = bvs[j];
         float sv[16];
         bool sok[4] = {false, false, false, false};
 #pragma unroll

@@ -242,6 +242,16 @@ __global__ __launch_bounds__(768) void conv3d_bf16x3_fwd_ws_kernel(const float* 
     load_w(0, 0);
     if (WHOLE) store_w();
   }
+  // the bias of the lane's output channels, loaded ONCE: read inside the epilogue it is a global load whose latency nothing hides for
+  // the late wave of a SIMD (round 5, stamps of tools/probe/conv_cl16_probe.hip: its epilogue behind barrier B took 2.0 k of a 16 k-cycle
+  // item — the load, not the four stores)
+  float bvs[NBT];
+#pragma unroll
+  for (int j = 0; j < NBT; ++j) {
+    const int co = n0 + j * 16 + lr;
+    bvs[j] = (bias && co < g.Cout) ? bias[co] : 0.f;
+    ICL_PIN1(bvs[j]);
+  }
   bool first_item = true;
   int item_no = -1;
   (void)item_no;
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(768) void conv3d_bf16x3_fwd_ws_kernel(const float* 
 #pragma unroll
       for (int j = 0; j < NBT; ++j) {
         const int co = n0 + j * 16 + lr;
-        const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+        const float bv = bvs[j];
         float sv[16];
         bool sok[4] = {false, false, false, false};
 #pragma unroll

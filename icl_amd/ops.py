@@ -130,6 +130,35 @@ class WgradLane:
     open = False
     _stream = None
     _used = False
+    # forward uses of every weight whose gradient may take the lane, counted while the step is open (ICLTrainer resets it per step).
+    # The lane's only join is after loss.backward(), so a gradient computed there must reach the optimiser untouched: autograd has to
+    # ADOPT the returned tensor (weight.grad is None, one use per step, no hooks on the parameter).  Anything else — a weight applied
+    # twice, a .grad left from an earlier backward, parameter hooks — reads or adds to the gradient on the step's own stream during
+    # backward; ``adoptable`` is False then and the caller orders its stream after the lane before it returns the gradient.
+    uses = None
+
+    @classmethod
+    def begin_step(cls):
+        cls.uses = {}
+        cls.open = False
+
+    @classmethod
+    def note_use(cls, weight):
+        if cls.uses is not None and weight is not None:
+            cls.uses[id(weight)] = cls.uses.get(id(weight), 0) + 1
+
+    @classmethod
+    def adoptable(cls, weight) -> bool:
+        if cls.uses is None or cls.uses.get(id(weight), 0) != 1 or weight.grad is not None:
+            return False
+        if getattr(weight, "_backward_hooks", None) or getattr(weight, "_post_accumulate_grad_hooks", None):
+            return False
+        return True
+
+    @classmethod
+    def sync_to_current(cls, like: torch.Tensor):
+        """Order the current stream after everything queued on the lane (a gradient that is not simply adopted)."""
+        torch.cuda.current_stream(like.device).wait_stream(cls._stream)
 
     @classmethod
     def wants(cls, x: torch.Tensor, voxels: int) -> bool:
@@ -429,6 +458,8 @@ class _Conv3d(torch.autograd.Function):
         assert weight.shape[1] == cin and weight.shape[2] == weight.shape[3] == weight.shape[4]
         s = d * h * w
         ctx.save_for_backward(x, weight)
+        if ks == 3:
+            WgradLane.note_use(weight)
         ctx.has_bias = bias is not None
         small_ch = cin <= CONV1X1_SMALL_MAX_CHANNELS and cout <= CONV1X1_SMALL_MAX_CHANNELS and s % 4 == 0
         ctx.pointwise_gemm = ks == 1 and n * s >= CONV1X1_GEMM_MIN_VOXELS and not small_ch
@@ -542,6 +573,8 @@ class _Conv3d(torch.autograd.Function):
                     # the input gradient above was queued on this stream)
                     with WgradLane.on_lane(x, gy, gw, gb_arg):
                         wgrad()
+                    if not WgradLane.adoptable(weight):
+                        WgradLane.sync_to_current(gw)      # accumulated / hooked gradient: no race with the lane
                 else:
                     wgrad()
         return gx, gw, gb, None, None
@@ -1330,6 +1363,12 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, weight.shape[1]).contiguous()
         ctx.save_for_backward(x2, weight)
         ctx.lane_wgrad = bool(lane_wgrad)
+        # the gradient is returned for `weight` as passed (a view of the convolution weight in _conv3d_tiny_volume): adoption is
+        # decided on the Parameter behind it
+        ctx.lane_param = owner.weight if owner is not None and getattr(owner, "weight", None) is not None else (
+            weight._base if weight._base is not None else weight)
+        if lane_wgrad:
+            WgradLane.note_use(ctx.lane_param)
         ctx.has_bias = bias is not None
         # the Parameter behind the bias (for DeferredBiasGrads: all small bias gradients of a step reduced in one launch): the
         # owner's, or the argument itself when the caller passed a Parameter without naming its module
@@ -1373,6 +1412,8 @@ class _Linear(torch.autograd.Function):
                 if lane:
                     with WgradLane.on_lane(g2, x2):
                         gw, gb = _tall_atb(g2, x2, False)
+                    if not WgradLane.adoptable(ctx.lane_param):
+                        WgradLane.sync_to_current(gw)
                 else:
                     gw, gb = _tall_atb(g2, x2, need_b)
             elif need_b:

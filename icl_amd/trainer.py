@@ -95,6 +95,7 @@ class ICLTrainer:
         self.optimizer.zero_grad(set_to_none=True)
         BatchNormAct.defer_counters()
         ops.DeferredBiasGrads.begin()
+        ops.WgradLane.begin_step()      # per-weight use counts of the step (a lane gradient must be adopted, not accumulated)
         try:
             ops.FactoredGrads.world = self.ddp.world if (self.ddp is not None and self.ddp.active) else 1
             # without gradient exchange the factors of a layer are final when its backward runs: update there (FusedSGD.update_in_backward)
@@ -111,6 +112,7 @@ class ICLTrainer:
                 ops.WgradLane.join()
         finally:
             ops.WgradLane.open = False
+            ops.WgradLane.uses = None
             ops.FactoredGrads.fused_optimizer = None
             ops.FactoredGrads.uses = None
             BatchNormAct.flush_counters()     # all num_batches_tracked increments of the step in one launch

@@ -41,6 +41,7 @@ static inline unsigned icl_bf16_rn_bits(float f) {      // fp32 -> bf16 bits, ro
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 static inline unsigned icl_pack_bf16_rn(float lo, float hi) { return icl_bf16_rn_bits(lo) | (icl_bf16_rn_bits(hi) << 16); }
+static inline float icl_med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 static inline unsigned icl_alignbit(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)((((uint64_t)hi << 32) | lo) >> sh); }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }

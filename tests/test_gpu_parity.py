@@ -1221,3 +1221,39 @@ def test_split_bf16_weight_gradient(dev, monkeypatch, cin, cout, kind):
         errs[split] = float((d / scale.clamp_min(1e-300))[~tiny].max())
     assert errs["2"] < 2e-5 and errs["2"] <= 1.5 * errs["0"] + 2e-7, errs
 
+
+
+def test_wgrad_lane_gradient_of_a_weight_used_twice_is_ordered_before_its_accumulation(dev):
+    """ops.WgradLane launches dW on a second stream whose only join is after backward.  A weight applied twice in a
+    step has its second gradient ADDED to the first by autograd on the step's own stream — the lane must be ordered in front of that
+    add (WgradLane.adoptable is False -> sync_to_current).  Same gradient, bit for bit, as with the lane switched off."""
+    from icl_amd import ops
+    x = _rand((2, 16, 24, 24, 24), 901).to(dev)
+    w = (0.05 * _rand((16, 16, 3, 3, 3), 902)).to(dev).requires_grad_()
+    w1 = (0.05 * _rand((16, 16, 3, 3, 3), 903)).to(dev).requires_grad_()
+
+    def run(lane):
+        w.grad = w1.grad = None
+        old = ops.WgradLane.enabled
+        ops.WgradLane.begin_step()
+        try:
+            xin = x.clone().requires_grad_()
+            y = ops.conv3d(ops.conv3d(ops.conv3d(xin, w, None), w1, None), w, None)
+            seen = dict(twice=ops.WgradLane.adoptable(w), once=ops.WgradLane.adoptable(w1))
+            ops.WgradLane.enabled, ops.WgradLane.open = lane, True
+            y.square().sum().backward()
+            ops.WgradLane.join()
+        finally:
+            ops.WgradLane.open, ops.WgradLane.enabled, ops.WgradLane.uses = False, old, None
+        torch.cuda.synchronize()
+        return w.grad.clone(), w1.grad.clone(), seen
+
+    a, a1, _ = run(False)
+    b, b1, seen = run(True)
+    assert seen == dict(twice=False, once=True), seen
+    assert torch.equal(a, b) and torch.equal(a1, b1)
+    # a gradient left from an earlier backward is accumulated into, not replaced: not adoptable either
+    ops.WgradLane.begin_step()
+    ops.WgradLane.note_use(w1)
+    assert w1.grad is not None and not ops.WgradLane.adoptable(w1)
+    ops.WgradLane.uses = None
