@@ -29,7 +29,7 @@ __device__ long long g_ws_stamps[3 * 3 * 16];
 #define WS_STAMP(k) ((void)0)
 #endif
 
-template <int NBT, bool FLAT = false>
+template <int NBT, bool FLAT = false, bool LF = false>
 __global__ __launch_bounds__(768) void conv3d_bf16x3_fwd_ws_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
                                                                    const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {
   typedef typename std::conditional<FLAT, Bf3F24, Bf3T<8>>::type TC;
@@ -43,7 +43,12 @@ __global__ __launch_bounds__(768) void conv3d_bf16x3_fwd_ws_kernel(const float* 
   ICL_DYN_LDS(uint4, lds);
   uint4* Xs = lds;
   uint4* Ws = lds + TC::XS_U4;
-  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  // LF ("loaders first", round 5 experiment): the four loader waves are the workgroup's OLDEST waves (hardware wave ids 0..3) instead of its
+  // youngest — the SIMD's issue arbiter prefers the older wave at equal priority.  Roles are expressed through `wid` / `tid` as the code
+  // below has always used them: consumers 0..7 (threads 0..511), loaders 8..11 (threads 512..767).
+  const int htid = threadIdx.x;
+  const int tid = LF ? (htid < NL ? htid + NC : htid - NL) : htid;
+  const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   int wid = tid >> 6;
   ICL_WAVE_UNIFORM(wid);
   const int n0 = blockIdx.y * NB;
