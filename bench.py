@@ -95,6 +95,77 @@ def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
 HBM_TRAFFIC_FILE = "profiles/r4_hbm_traffic.json"
 
 
+def reference_loop_bench(nc: int, steps: int, warmup: int, dev, fused: bool):
+    """The loop body of the UNCHANGED reference trainer (/root/reference/code/train_inherent_consistent_unet_3D_BraTS.py:63-64,85-90,
+    103-133) — its statements, its names — through the `compat/` import root (`networks.net_factory_3d`, `utils.losses`), eager, with the
+    six `.item()` reads of its logging line; on the same HBM-resident synthetic batch as the headline.  ``fused``: the one-line optimiser
+    swap of INTEGRATION.md §2 (`icl_amd.optim.FusedSGD` instead of `optim.SGD`), everything else untouched."""
+    compat = os.path.join(os.path.dirname(os.path.abspath(__file__)), "compat")
+    sys.path.insert(0, compat)
+    try:
+        import torch.optim as optim
+        from torch.nn.modules.loss import CrossEntropyLoss
+        from networks.net_factory_3d import net_factory_3d
+        from utils import losses
+        from icl_amd.utils.hashfill import synthetic_labels, synthetic_volume
+        base_lr, max_iterations, labeled_bs, num_classes = 0.01, 30000, 1, nc
+        torch.manual_seed(1337)
+        model = net_factory_3d(net_type="unet_3D_icl", in_chns=1, class_num=num_classes)
+        model.train()
+        if fused:
+            from icl_amd.optim import FusedSGD
+            optimizer = FusedSGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001)
+        else:
+            optimizer = optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001)
+        ce_loss = CrossEntropyLoss()
+        dice_loss = losses.DiceLoss(num_classes)
+        aux_loss = losses.AuxLoss3D(num_classes)
+        pse_loss = losses.PseudoSoftLoss3D(num_classes)
+        volume_batch = synthetic_volume((2, 1, 96, 96, 96), 1337, device=dev)
+        label_batch = synthetic_labels((2, 96, 96, 96), 4242, num_classes, device=dev)
+        iter_num = 0
+        logged = None
+
+        def iteration():
+            nonlocal iter_num, logged
+            outputs = model(volume_batch[:labeled_bs], volume_batch[labeled_bs:])
+            outputs_soft = torch.softmax(outputs[0], dim=1)
+            loss_ce = ce_loss(outputs[0], label_batch[:labeled_bs])
+            loss_dice = dice_loss(outputs_soft, label_batch[:labeled_bs].unsqueeze(1))
+            loss_aux = aux_loss(outputs[2], label_batch[:labeled_bs])
+            loss_pse = pse_loss(outputs[3], outputs[1])
+            loss_aux_consis = losses.softmax_mse_loss(outputs[3], outputs[4])
+            loss = loss_dice + loss_ce + loss_aux + loss_pse + 10 * loss_aux_consis
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            lr_ = base_lr * (1.0 - iter_num / max_iterations) ** 0.9
+            for param_group in optimizer.param_groups:
+                param_group['lr'] = lr_
+            iter_num = iter_num + 1
+            logged = (iter_num, loss.item(), loss_ce.item(), loss_dice.item(), loss_aux.item(), loss_pse.item(), 10 * loss_aux_consis.item())
+
+        for _ in range(max(warmup, 2)):
+            iteration()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            iteration()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / steps
+        dense = sum(p.grad.numel() for p in model.parameters() if p.grad is not None)
+        out = {"ms_per_step": round(dt * 1e3, 3), "value": round(2.0 / dt, 3), "unit": "volumes/s",
+               "optimizer": "icl_amd.optim.FusedSGD (one-line swap; step scope opened from the model's forward hook)" if fused else "torch.optim.SGD",
+               "dense_gradient_elements": int(dense), "last_logged_loss": round(float(logged[1]), 6)}
+        del model, optimizer
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        sys.path.remove(compat)
+        for name in [m for m in list(sys.modules) if m.split(".")[0] in ("networks", "utils", "val_3D", "dataloaders")]:
+            del sys.modules[name]
+
+
 def hbm_traffic(kernel: str):
     """HBM bytes per launch of a kernel from the committed PMC run (FETCH_SIZE and WRITE_SIZE passes of rocprofv3 on one
     reference layer of that kernel, gfx950 correction applied) — counters cannot be collected from inside this process, so the
@@ -183,6 +254,10 @@ def main():
                     help="after the headline region, time the same K steps with every batch built on the device by the data feed "
                          "(TwoStreamBatchSampler indices -> OnDeviceAugment.batch: rot/flip/crop of 240x240x155 volumes resident in "
                          "HBM) and the feed alone; reported as `feed` (the headline `value` keeps its HBM-resident input)")
+    ap.add_argument("--loop", default="trainer", choices=["trainer", "reference"],
+                    help="reference: after the headline region also time the UNCHANGED reference loop body (compat/ import root, "
+                         "net_factory_3d, utils.losses, six .item() per iteration, eager) with torch.optim.SGD and with the one-line "
+                         "FusedSGD swap; reported as config.reference_loop beside the headline (3D U-Net ICL, one rank)")
     ap.add_argument("--force-ddp", action="store_true", help="with --gpus 1: run the data-parallel step on a one-rank RCCL group")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="exercise ONLY the multi-rank plumbing (self-launch, rendezvous, barrier-bracketed timing, MAX over ranks, "
@@ -350,6 +425,25 @@ def main():
                           "TwoStreamBatchSampler(2 labeled, 6 unlabeled, batch 2) -> OnDeviceAugment.batch (crop_rotflip_kernel)"}
         del store, aug
 
+    ref_loop = None
+    if args.loop == "reference" and rank == 0 and world == 1 and args.model == "unet_3D_icl" and nc == 2:
+        # ICLTrainer's own eager step on the same batch, for the comparison the two loops are judged against
+        trainer.use_graph = False
+        for _ in range(2):
+            trainer.step(vol, lab)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step(vol, lab)
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        trainer.use_graph = graphed
+        ref_loop = {"source": "train_inherent_consistent_unet_3D_BraTS.py:63-64,85-90,103-133 (loop body verbatim, compat/ import root, eager, "
+                              "six .item() reads per iteration), same HBM-resident synthetic batch",
+                    "torch_optim_sgd": reference_loop_bench(nc, args.steps, args.warmup, dev, fused=False),
+                    "fused_sgd_one_line_swap": reference_loop_bench(nc, args.steps, args.warmup, dev, fused=True),
+                    "icl_trainer_eager_ms_per_step": round(eager_ms, 3)}
+
     exact = None
     if rank == 0 and world == 1 and not args.no_exact_compare and os.environ.get("ICL_CONV_SPLIT", "1") != "0":
         # the same step with every convolution on the exact-fp32 MFMA kernels (ICL_CONV_SPLIT=0), for reference: a second model and
@@ -492,6 +586,7 @@ def main():
                                              "rounding floor of that sample (profiles/r4_mlp2_grad_sensitivity.txt)"}
                           if os.environ.get("ICL_CONV_SPLIT", "1") != "0" else {}),
                        **({"exact_fp32_mfma_convolutions": exact} if exact else {}),
+                       **({"reference_loop": ref_loop} if ref_loop else {}),
                        **({"feed": feed} if feed else {})},
             "roofline": roof,
         }

@@ -6,6 +6,8 @@ from __future__ import annotations
 
 import torch
 
+from ..optim import tag_model_parameters
+
 from .unet import UNet
 from .unet_icl import UNet_icl
 from .vision_transformer import SwinUnet, default_config
@@ -20,9 +22,9 @@ def _device():
 
 def net_factory(net_type="unet", in_chns=1, class_num=3):
     if net_type == "unet":
-        return UNet(in_chns=in_chns, class_num=class_num, device=_device())
+        return tag_model_parameters(UNet(in_chns=in_chns, class_num=class_num, device=_device()))
     if net_type == "icl_unet":
-        return UNet_icl(in_chns=in_chns, class_num=class_num, device=_device())
+        return tag_model_parameters(UNet_icl(in_chns=in_chns, class_num=class_num, device=_device()))
     if net_type in ("swinunet", "icl_swinunet"):     # net_factory.py:81-86: img_size [224, 224]
-        return SwinUnet(default_config(), img_size=224, num_classes=class_num, device=_device(), icl=net_type == "icl_swinunet")
+        return tag_model_parameters(SwinUnet(default_config(), img_size=224, num_classes=class_num, device=_device(), icl=net_type == "icl_swinunet"))
     return None

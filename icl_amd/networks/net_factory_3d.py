@@ -11,6 +11,7 @@ import argparse
 
 import torch
 
+from ..optim import tag_model_parameters
 from .swinunetr import SwinUNETR
 from .swinunetr_icl import SwinUNETR_icl
 from .unet_3D import unet_3D
@@ -37,12 +38,12 @@ def _device():
 
 def net_factory_3d(net_type="unet_3D", in_chns=1, class_num=2):
     if net_type == "unet_3D":
-        return unet_3D(n_classes=class_num, in_channels=in_chns, device=_device())
+        return tag_model_parameters(unet_3D(n_classes=class_num, in_channels=in_chns, device=_device()))
     if net_type == "unet_3D_icl":
-        return unet_3D_icl(n_classes=class_num, in_channels=in_chns, device=_device())
+        return tag_model_parameters(unet_3D_icl(n_classes=class_num, in_channels=in_chns, device=_device()))
     if net_type in ("swinunetr", "swinunetr_icl"):   # net_factory_3d.py:44-63: shapes come from the parser, not the arguments
         cls = SwinUNETR if net_type == "swinunetr" else SwinUNETR_icl
-        return cls(img_size=(args.roi_x, args.roi_y, args.roi_z), in_channels=args.in_channels, out_channels=args.num_classes,
+        return tag_model_parameters(cls(img_size=(args.roi_x, args.roi_y, args.roi_z), in_channels=args.in_channels, out_channels=args.num_classes,
                    feature_size=args.feature_size, drop_rate=0.0, attn_drop_rate=0.0, dropout_path_rate=args.dropout_path_rate,
-                   use_checkpoint=args.use_checkpoint, device=_device())
+                   use_checkpoint=args.use_checkpoint, device=_device()))
     return None

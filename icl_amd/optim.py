@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -19,11 +20,49 @@ SPLIT_MIN_ROWS = 192    # factor rows from which d = g^T x runs on split product
                         # but +2 small launches: a wash inside the step; 256 rows 1244 -> 1029 us, 512 rows 2158 -> 1770 us)
 
 
+def tag_model_parameters(model: torch.nn.Module) -> torch.nn.Module:
+    """Called by the model factories (networks/net_factory*.py): every parameter remembers the model it belongs to, so that an optimiser
+    built from ``model.parameters()`` alone — the one line of the reference trainers — can find the module to hook (FusedSGD step scope)."""
+    ref = weakref.ref(model)
+    for p in model.parameters():
+        p._icl_model = ref
+    return model
+
+
 class FusedSGD(torch.optim.Optimizer):
-    def __init__(self, params, lr=0.01, momentum=0.9, weight_decay=0.0):
+    """``step_scope`` (default on): when the parameters belong to ONE icl_amd model built by ``net_factory_3d`` / ``net_factory``, the
+    optimiser opens — from a forward pre-hook of that model, in training mode with gradients enabled — the step-scoped machinery that
+    ``ICLTrainer`` opens around its iteration, and closes it in ``step()``: packed convolution weights (``ops.PackedWeights``), factored
+    gradients of the token-axis matrices and their SGD step inside backward (``ops.FactoredGrads``), deferred bias gradients and
+    BatchNorm counters, weight gradients of the deep levels on a lane (``ops.WgradLane``).  The unchanged reference loop
+    (``outputs = model(..); ..; optimizer.zero_grad(); loss.backward(); optimizer.step()``,
+    /root/reference/code/train_inherent_consistent_unet_3D_BraTS.py:103-115) then runs the fast path with the one-line optimiser swap of
+    INTEGRATION.md §2.  Requirement it inherits from ``update_in_backward``: every ``loss.backward()`` of a training-mode forward is
+    followed by ``optimizer.step()`` (the big matrices are updated inside their backward pass); pass ``update_in_backward=False`` for
+    loops that accumulate gradients over several backward passes, ``step_scope=False`` to get a plain fused optimiser."""
+
+    def __init__(self, params, lr=0.01, momentum=0.9, weight_decay=0.0, step_scope: bool = True, update_in_backward: bool = True):
         if momentum <= 0:
             raise ValueError("FusedSGD implements the momentum form used by the ICL trainers")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self._scope_model = None
+        self._scope_open = False
+        self._scope_update_in_backward = bool(update_in_backward)
+        self._scope_packed = None
+        self._scope_hook = None
+        if step_scope:
+            models = {id(m): m for m in (getattr(p, "_icl_model", lambda: None)() for g in self.param_groups for p in g["params"])
+                      if m is not None}
+            if len(models) == 1:
+                (model,) = models.values()
+                self._scope_model = weakref.ref(model)
+                me = weakref.ref(self)
+
+                def pre_forward(module, args):
+                    opt = me()
+                    if opt is not None:
+                        opt._open_scope(module)
+                self._scope_hook = model.register_forward_pre_hook(pre_forward)
         self.lr_dev = None   # optional device scalar read by the kernels instead of group['lr'] (hipGraph replay)
         self._groups = None  # id(parameter) -> its group (update_in_backward)
         self._updated_in_backward = set()   # ids of the parameters whose update of this step already ran inside backward
@@ -52,8 +91,75 @@ class FusedSGD(torch.optim.Optimizer):
         self._updated_in_backward.clear()
         if self._deferred or self._update_stream_used:
             raise RuntimeError("FusedSGD.zero_grad(): updates queued by the previous backward pass were never applied; call step() "
-                               "after every backward pass when update_placement is 'gated' or 'free'")
+                               "after every backward pass when update_placement is 'tail' (the default), 'gated' or 'free' — or "
+                               "abandon_step() to discard what a failed iteration left behind")
         super().zero_grad(set_to_none=set_to_none)
+
+    def abandon_step(self):
+        """Discard what an iteration that will not reach ``step()`` left behind (an exception between backward and step, a skipped
+        step): queued updates of the update stream are dropped — the stream is joined first, so nothing of them is still running —,
+        the factors of factored gradients and the step scope are cleared.  Matrices whose update already ran inside their backward pass
+        (placement 'fused') keep it: that pass cannot be undone.  ICLTrainer calls this when its step raises."""
+        if self._update_stream is not None and self._update_stream_used:
+            torch.cuda.current_stream(self._update_stream.device).wait_stream(self._update_stream)
+        self._deferred = []
+        self._update_stream_used = False
+        self._updated_in_backward.clear()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if getattr(p, "_icl_factors", None) is not None:
+                    p._icl_factors = None
+        if self._scope_open:
+            self._close_scope(flush=False)
+
+    # ---- step scope (see the class docstring)
+    def _open_scope(self, module):
+        from . import ops
+        from .networks.layers import BatchNormAct
+        if not module.training or not torch.is_grad_enabled():
+            return
+        if self._scope_open:
+            self.abandon_step()          # a forward pass whose backward / step never came
+        if ops.PackedWeights.current is not None or ops.FactoredGrads.uses is not None:
+            return                       # somebody else (ICLTrainer) has a step open
+        if self._scope_packed is None:
+            self._scope_packed = ops.PackedWeights()
+        self._scope_open = True
+        self._scope_packed.begin_step()
+        BatchNormAct.defer_counters()
+        ops.DeferredBiasGrads.begin()
+        ops.WgradLane.begin_step()
+        ops.WgradLane.open = True        # (only backward functions consult it)
+        multi = False
+        try:
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        except Exception:                # noqa: BLE001
+            multi = False
+        self._scope_prev_factored = ops.FactoredGrads.enabled
+        if not multi:                    # data-parallel wrappers of an unchanged loop expect dense .grad tensors
+            ops.FactoredGrads.enabled = True
+            ops.FactoredGrads.world = 1
+            ops.FactoredGrads.fused_optimizer = self if self._scope_update_in_backward else None
+            ops.FactoredGrads.uses = {} if self._scope_update_in_backward else None
+
+    def _close_scope(self, flush: bool = True):
+        from . import ops
+        from .networks.layers import BatchNormAct
+        ops.WgradLane.join()
+        ops.WgradLane.open = False
+        ops.WgradLane.uses = None
+        ops.FactoredGrads.enabled = self._scope_prev_factored
+        ops.FactoredGrads.fused_optimizer = None
+        ops.FactoredGrads.uses = None
+        if flush:
+            BatchNormAct.flush_counters()
+            ops.DeferredBiasGrads.flush()
+        else:
+            BatchNormAct.deferred = None
+            ops.DeferredBiasGrads.pending = None
+        self._scope_packed.end_step()
+        self._scope_open = False
 
     def _step_factored(self, L, p, factors, lr, mom, wd):
         """dW = sum over entries of g^T x, applied without forming it (ops.FactoredGrads, csrc/kernels/optim.h)."""
@@ -225,6 +331,8 @@ class FusedSGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self._scope_open:
+            self._close_scope()                 # lane joined, deferred bias gradients assigned, packed weights released
         self.flush_deferred(gate=True)      # a model without a gate hook: the updates start here
         if self._update_stream_used:
             torch.cuda.current_stream(self._update_stream.device).wait_stream(self._update_stream)

@@ -43,7 +43,7 @@ class ICLTrainer:
     def __init__(self, model: torch.nn.Module, cfg: ICLConfig, ddp=None):
         self.model, self.cfg, self.ddp = model, cfg, ddp
         self.optimizer = FusedSGD(model.parameters(), lr=cfg.base_lr, momentum=cfg.momentum,
-                                  weight_decay=cfg.weight_decay)
+                                  weight_decay=cfg.weight_decay, step_scope=False)      # this class opens the step scope itself
         self.ce_loss = CrossEntropyLoss()
         self.dice_loss = L.DiceLoss(cfg.num_classes)
         if len(cfg.patch_size) == 3:
@@ -127,7 +127,13 @@ class ICLTrainer:
         ops.StepRNG.end_step()
 
     def _step_body(self, volume_batch, label_batch, boundary=None):
-        parts = self._forward_backward(volume_batch, label_batch, boundary)
+        try:
+            parts = self._forward_backward(volume_batch, label_batch, boundary)
+        except BaseException:
+            # an iteration that will not reach optimizer.step(): drop its queued updates, or every later zero_grad() raises
+            self.optimizer.abandon_step()
+            self.packed.end_step()
+            raise
         if self.ddp is not None:
             self.ddp.reduce_gradients()
         self._apply_update()

@@ -39,12 +39,17 @@ def _parity_mode(model):
             mod.drop_prob = 0.0
 
 
-def _reference_loop_body(model, volume_batch, label_batch, labeled_bs, num_classes, base_lr):
-    """The statements of the reference `train()` between building the optimiser and `optimizer.step()`, with its names."""
+def _reference_loop_body(model, volume_batch, label_batch, labeled_bs, num_classes, base_lr, fused_swap=False):
+    """The statements of the reference `train()` between building the optimiser and `optimizer.step()`, with its names.
+    ``fused_swap``: the ONE line INTEGRATION.md §2 changes — `icl_amd.optim.FusedSGD` for `optim.SGD`."""
     import torch.optim as optim
     from torch.nn.modules.loss import CrossEntropyLoss
     from utils import losses
-    optimizer = optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001)
+    if fused_swap:
+        from icl_amd.optim import FusedSGD
+        optimizer = FusedSGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001)
+    else:
+        optimizer = optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001)
     ce_loss = CrossEntropyLoss()
     dice_loss = losses.DiceLoss(num_classes)
     aux_loss = losses.AuxLoss3D(num_classes)
@@ -129,6 +134,45 @@ def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root, monkeyp
     assert rel_err(samples["1"][big], samples["0"][big]) < 3e-3
     assert rel_err(samples["1"]["final.weight"], samples["0"]["final.weight"]) < 1e-5
     assert rel_err(samples["1"]["center.conv2.0.weight"], samples["0"]["center.conv2.0.weight"]) < 1e-3
+
+
+def test_reference_loop_body_with_the_one_line_fused_sgd_swap(compat_root):
+    """The unchanged loop body with `FusedSGD(model.parameters(), ...)` in place of `optim.SGD(...)`: the optimiser finds the model behind
+    its parameters (the factory tags them), opens ICLTrainer's step scope from a forward pre-hook and closes it in `step()` — the
+    13,824^2 gradients stay factored and their matrices are updated inside backward.  Losses and EVERY parameter after the step equal the
+    golden (post-step norms 1e-4, two tensors elementwise); a second iteration runs (the scope re-opens cleanly); an evaluation-mode
+    forward leaves everything closed."""
+    from networks.net_factory_3d import net_factory_3d
+    from icl_amd import ops
+    g = load_golden("model_unet3d_icl_nc2.npz")
+    model = net_factory_3d(net_type="unet_3D_icl", in_chns=1, class_num=2)
+    fill_like_reference_init(list(model.named_parameters()))
+    _parity_mode(model)
+    dev = next(model.parameters()).device
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, 2).to(dev)
+    got, grads = _reference_loop_body(model, vol, lab, labeled_bs=1, num_classes=2, base_lr=0.01, fused_swap=True)
+    assert np.allclose(got, g["losses"], rtol=0, atol=1e-4), (got, g["losses"])
+    big = "sspa.class_decoders.2.mlp2.fc1.weight"
+    assert big not in grads and "uscl.class_decoders.2.mlp2.fc2.weight" not in grads      # factored: no 764 MB dense gradient was formed
+    assert "final.weight" in grads and "sspa.class_decoders.0.mlp2.fc1.weight" in grads   # small layers: dense as usual
+    names = [k for k, _ in model.named_parameters()]
+    post = np.array([float(p.detach().double().norm()) for _, p in model.named_parameters()])
+    off = [(names[i], post[i], g["post_sgd_norms"][i]) for i in range(len(names))
+           if abs(post[i] - g["post_sgd_norms"][i]) > 1e-4 * g["post_sgd_norms"][i]]
+    assert not off, off[:8]
+    assert rel_err(model.final.weight.detach().cpu(), g["post_sgd.final.weight"]) < 1e-5
+    assert rel_err(model.conv1.conv1[0].weight.detach().cpu(), g["post_sgd.conv1.conv1.0.weight"]) < 1e-4
+    # the scope is closed again: nothing of the step machinery leaks into code that runs after optimizer.step()
+    assert ops.PackedWeights.current is None and ops.FactoredGrads.uses is None and not ops.FactoredGrads.enabled
+    assert ops.WgradLane.uses is None and not ops.WgradLane.open and ops.DeferredBiasGrads.pending is None
+    with torch.no_grad():
+        model.eval()
+        model(vol[:1], inference=True)
+        model.train()
+    assert ops.PackedWeights.current is None and ops.FactoredGrads.uses is None
+    del grads
+    torch.cuda.empty_cache()
 
 
 def test_reference_loop_body_swinunetr_icl_through_compat_root(compat_root):

@@ -772,3 +772,73 @@ def test_conv1x1_big_volume_runs_as_batched_product(monkeypatch):
 def test_conv1x1_stream_kernel_final_conv_class(n, cin, cout):
     """The `final` convolution class (unet_3D_icl.py:65): <= 16 channels on >= 65536 voxels, forward and input gradient."""
     _conv_check(n, cin, cout, 32, 32, 64 // n, 1)
+
+
+@pytest.mark.timeout(1200)
+def test_fused_sgd_step_scope_equals_the_plain_loop_with_torch_sgd():
+    """The one-line optimiser swap of INTEGRATION.md §2 on the kernel emulation: the reference loop body
+    (`outputs = model(..); losses; optimizer.zero_grad(); loss.backward(); optimizer.step()`) on a small `unet_3D_icl` with
+    `FusedSGD(model.parameters(), ...)` — which finds the model through its tagged parameters and opens ICLTrainer's step scope (packed
+    weights, factored token-axis gradients, deferred bias gradients, lane bookkeeping) from a forward pre-hook — leaves every parameter
+    where `torch.optim.SGD` on dense gradients leaves it, over two iterations (momentum included); the scope is closed after `step()`,
+    an evaluation forward does not open it, and a forward whose step never comes is abandoned by the next one."""
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.optim import FusedSGD, tag_model_parameters
+    from icl_amd.utils import losses
+    from icl_amd.utils.hashfill import synthetic_labels
+    nc = 2
+    old_min = ops.FactoredGrads.min_elems
+    ops.FactoredGrads.min_elems = 64 * 64
+    try:
+        vol = synthetic_volume((2, 1, 16, 16, 16), 900)
+        lab = synthetic_labels((2, 16, 16, 16), 950, nc)
+
+        def run(fused):
+            torch.manual_seed(7)
+            model = tag_model_parameters(unet_3D_icl(feature_scale=16, n_classes=nc, in_channels=1, icl_in_resolutions=(1, 2, 4), icl_heads=(8, 4, 2)))
+            for m in model.modules():           # parity mode: no dropout / drop-path randomness between the two runs
+                if hasattr(m, "p") and m.__class__.__name__ == "Dropout3":
+                    m.p = 0.0
+                if hasattr(m, "drop_prob"):
+                    m.drop_prob = 0.0
+            opt = (FusedSGD if fused else torch.optim.SGD)(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-2)
+            ce = torch.nn.CrossEntropyLoss()
+            dice, aux, pse = losses.DiceLoss(nc), losses.AuxLoss3D(nc, (16, 16, 16)), losses.PseudoSoftLoss3D(nc, (16, 16, 16))
+            seen = []
+            for it in range(2):
+                outputs = model(vol[:1], vol[1:])
+                if fused:
+                    seen.append((ops.PackedWeights.current is not None, ops.FactoredGrads.enabled, ops.WgradLane.uses is not None))
+                loss = (dice(torch.softmax(outputs[0], 1), lab[:1].unsqueeze(1)) + ce(outputs[0], lab[:1]) + aux(outputs[2], lab[:1])
+                        + pse(outputs[3], outputs[1]) + 10 * losses.softmax_mse_loss(outputs[3], outputs[4]))
+                opt.zero_grad()
+                loss.backward()
+                if fused and it == 0:
+                    fac = [k for k, p in model.named_parameters() if getattr(p, "_icl_factors", None)]
+                    assert sum("mlp2" in k for k in fac) == 4, fac          # the token-axis gradients stayed factored
+                opt.step()
+                if fused:
+                    assert ops.PackedWeights.current is None and not ops.FactoredGrads.enabled and ops.FactoredGrads.uses is None
+                    assert ops.WgradLane.uses is None and not ops.WgradLane.open and ops.DeferredBiasGrads.pending is None
+            if fused:
+                assert seen == [(True, True, True)] * 2, seen
+                with torch.no_grad():
+                    model.eval()
+                    model(vol[:1], inference=True)
+                    model.train()
+                assert ops.PackedWeights.current is None
+                model(vol[:1], vol[1:])                   # opens the scope; no backward, no step
+                assert ops.PackedWeights.current is not None
+                model(vol[:1], vol[1:])                   # ... the next forward abandons it and opens a fresh one
+                assert ops.PackedWeights.current is not None
+                opt.abandon_step()
+                assert ops.PackedWeights.current is None and not ops.FactoredGrads.enabled
+            return {k: p.detach().clone() for k, p in model.named_parameters()}, float(loss)
+
+        a, la = run(False)
+        b, lb = run(True)
+        assert abs(la - lb) < 1e-5 * max(1.0, abs(la)), (la, lb)
+        bad = [k for k in a if not torch.allclose(a[k], b[k], rtol=2e-4, atol=2e-6)]
+        assert not bad, bad[:8]
+    finally:
+        ops.FactoredGrads.min_elems = old_min
