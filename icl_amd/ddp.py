@@ -90,10 +90,17 @@ class GradientReducer:
         # and `post_update()` all-gathers the updated rows in place (764 MB per 13,824^2 matrix over xGMI).  Which side wins depends
         # on the all-gather rate RCCL reaches on the node (2.2 ms per matrix at 300 GB/s per rank -> crossover ~600 rows; 1 TB/s ->
         # ~100; one 153 GB/s link -> ~1300): default 768, ICL_DDP_SHARD_ROWS to tune on hardware, 0 = never.
+        import os
+        # an explicit choice (constructor argument or ICL_DDP_SHARD_ROWS / ICL_DDP_DENSE_ROWS) wins over what calibrate() measures
+        self._explicit_shard = shard_min_rows is not None or "ICL_DDP_SHARD_ROWS" in os.environ
         if shard_min_rows is None:
-            import os
             shard_min_rows = int(os.environ.get("ICL_DDP_SHARD_ROWS", "768"))
         self.shard_min_rows = shard_min_rows
+        # gathered factor rows above which a layer forms its dense gradient instead (ops.FactoredGrads.max_rows_gathered is the switch
+        # the layers read; it is set from HERE for the duration of a step by ICLTrainer, not globally: ADVICE round 4)
+        from . import ops as _ops
+        self._explicit_dense = "ICL_DDP_DENSE_ROWS" in os.environ
+        self.max_rows_gathered = int(os.environ.get("ICL_DDP_DENSE_ROWS", str(_ops.FactoredGrads.max_rows_gathered)))
         self._sharded = []       # parameters whose update of this step is row-sharded
         self._names = {id(p): n for n, p in model.named_parameters()}
         self.rates = {"allgather_gbps": ASSUMED_ALLGATHER_GBPS, "allreduce_gbps": None, "measured": False}
@@ -150,13 +157,29 @@ class GradientReducer:
                 shard_from = rows
             if dense_from is None and mode == "dense":
                 dense_from = rows
-        self.shard_min_rows = shard_from if shard_from is not None else 0
-        from . import ops
-        if dense_from is not None:
-            ops.FactoredGrads.max_rows_gathered = dense_from - 1
+        # the thresholds live on THIS reducer (ICLTrainer hands max_rows_gathered to the layers per step); explicit settings win
+        if not self._explicit_shard:
+            self.shard_min_rows = shard_from if shard_from is not None else 0
+        if dense_from is not None and not self._explicit_dense:
+            self.max_rows_gathered = dense_from - 1
         self.rates["shard_min_rows"] = self.shard_min_rows
-        self.rates["max_rows_gathered"] = ops.FactoredGrads.max_rows_gathered
+        self.rates["max_rows_gathered"] = self.max_rows_gathered
+        self.rates["explicit"] = {"shard_min_rows": self._explicit_shard, "max_rows_gathered": self._explicit_dense}
         return self.rates
+
+    def state_dict(self):
+        """The exchange plan of this run: which matrices take the factored path, which updates are row-sharded.  Save it with the
+        checkpoint and ``load_state_dict`` it on resume — a re-measured crossover would otherwise put a resumed run on a different
+        arithmetic path (same mathematics, different summation order) than the run that wrote the checkpoint."""
+        return {"world": self.world, "shard_min_rows": self.shard_min_rows, "max_rows_gathered": self.max_rows_gathered,
+                "rates": dict(self.rates)}
+
+    def load_state_dict(self, sd):
+        if sd.get("world") != self.world:
+            raise RuntimeError(f"GradientReducer: the saved exchange plan is for {sd.get('world')} ranks, this group has {self.world}")
+        self.shard_min_rows, self.max_rows_gathered = int(sd["shard_min_rows"]), int(sd["max_rows_gathered"])
+        self._explicit_shard = self._explicit_dense = True       # a loaded plan is a choice: calibrate() must not replace it
+        self.rates = dict(sd.get("rates", self.rates))
 
     def broadcast_parameters(self, src: int = 0):
         for p in self.params:

@@ -98,6 +98,9 @@ class ICLTrainer:
         ops.WgradLane.begin_step()      # per-weight use counts of the step (a lane gradient must be adopted, not accumulated)
         try:
             ops.FactoredGrads.world = self.ddp.world if (self.ddp is not None and self.ddp.active) else 1
+            rows_default = ops.FactoredGrads.max_rows_gathered
+            if self.ddp is not None and self.ddp.active:
+                ops.FactoredGrads.max_rows_gathered = self.ddp.max_rows_gathered      # this reducer's crossover, for this step only
             # without gradient exchange the factors of a layer are final when its backward runs: update there (FusedSGD.update_in_backward)
             fuse = cfg.factored_mlp2_grads and cfg.update_in_backward and not (self.ddp is not None and self.ddp.active)
             ops.FactoredGrads.fused_optimizer = self.optimizer if fuse else None
@@ -111,6 +114,8 @@ class ICLTrainer:
                 loss.backward()
                 ops.WgradLane.join()
         finally:
+            if "rows_default" in locals():
+                ops.FactoredGrads.max_rows_gathered = rows_default
             ops.WgradLane.open = False
             ops.WgradLane.uses = None
             ops.FactoredGrads.fused_optimizer = None

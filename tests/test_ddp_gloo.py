@@ -1,4 +1,4 @@
-"""World-size 2 / 3 / 4 checks of the data-parallel gradient reducer on the gloo backend (CPU).
+"""World-size 2 / 3 / 4 / 8 checks of the data-parallel gradient reducer on the gloo backend (CPU).
 
 SURVEY.md §8e: W ranks == W independent reference steps with averaged gradients; parameters whose grad is None
 are skipped, never zero-filled (torch SGD skips them too, so weight decay must not touch them)."""
@@ -125,6 +125,40 @@ def _worker_factored(rank, world, port, tmp):
             assert torch.allclose(lin.weight.detach(), rw.detach(), rtol=1e-5, atol=1e-6), (shard_rows, nrows, step)
             assert torch.allclose(lin.bias.detach(), rb.detach(), rtol=1e-5, atol=1e-6)
             assert lin.weight._icl_shard is None      # consumed by the step: the decision never outlives its factors
+    if world == 8:
+        # the only world size the scaling target names, with the factor-row counts of config 5 (num_classes = 16: 128 rows per rank in
+        # `sspa`, 64 in `uscl` -> 1024 / 512 gathered rows) and the reducer's DEFAULT crossover (768 gathered rows): the 1024-row matrix
+        # is updated row-sharded when its row count divides by 8 (13,824 does) and whole when it does not; the 512-row one whole
+        for rows_rank, nrows, want_shard in ((128, 48, True), (128, 50, False), (64, 48, False)):
+            torch.manual_seed(3)
+            lin = Linear(64, nrows)
+            red = GradientReducer(lin, world)
+            assert red.shard_min_rows == 768
+            red.broadcast_parameters()
+            rw, rb = torch.nn.Parameter(lin.weight.detach().clone()), torch.nn.Parameter(lin.bias.detach().clone())
+            ref_opt = torch.optim.SGD([rw, rb], lr=0.1, momentum=0.9, weight_decay=1e-2)
+            opt = FusedSGD(lin.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+            torch.manual_seed(21)
+            data = torch.randn(world, rows_rank, 64)
+            for step in range(2):
+                opt.zero_grad()
+                with ops.FactoredGrads(True):
+                    lin(data[rank] + step).pow(2).mean().backward()
+                red.reduce_gradients()
+                assert lin.weight._icl_factors[0][0].shape[0] == rows_rank * world
+                assert (lin.weight._icl_shard is not None) == want_shard, (rows_rank, nrows)
+                opt.step()
+                red.post_update()
+                gw, gb = torch.zeros_like(rw), torch.zeros_like(rb)
+                for r in range(world):
+                    rw.grad = rb.grad = None
+                    torch.nn.functional.linear(data[r] + step, rw, rb).pow(2).mean().backward()
+                    gw += rw.grad / world
+                    gb += rb.grad / world
+                rw.grad, rb.grad = gw, gb
+                ref_opt.step()
+                assert torch.allclose(lin.weight.detach(), rw.detach(), rtol=1e-5, atol=1e-6), (rows_rank, nrows, step)
+                assert torch.allclose(lin.bias.detach(), rb.detach(), rtol=1e-5, atol=1e-6)
     # the shard decision flips between steps (sharded, sharded, whole, sharded, whole): the momentum rows the other ranks own are
     # exchanged before the buffer is used whole again, and a saved state holds the complete buffer on every rank
     torch.manual_seed(3)
@@ -168,7 +202,7 @@ def _worker_factored(rank, world, port, tmp):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_factored_gradient_exchange(tmp_path, world):
     from hipemu.build_emu import build_emu  # noqa: F401  (build once, before the workers race for it)
     build_emu()
@@ -185,12 +219,21 @@ def _worker_calibrate(rank, world, port, tmp):
     rates = red.calibrate(nbytes=1 << 20, iters=1)
     assert rates["measured"] and rates["allgather_gbps"] > 0 and rates["allreduce_gbps"] > 0
     everyone = [None] * world
-    dist.all_gather_object(everyone, (rates, red.shard_min_rows, ops.FactoredGrads.max_rows_gathered))
+    dist.all_gather_object(everyone, (rates, red.shard_min_rows, red.max_rows_gathered))
     assert all(e == everyone[0] for e in everyone)        # MAX-reduced times: every rank derives the same thresholds
     # the thresholds are the crossovers of the priced alternatives at the measured rates
     if red.shard_min_rows:
         assert exchange_plan(red.shard_min_rows, 13824 * 13824, world, rates["allgather_gbps"], rates["allreduce_gbps"])[0] == "shard"
-    ops.FactoredGrads.max_rows_gathered = before
+    # the measurement stays on the reducer — nothing process-global changes, an explicit setting wins, and a saved plan
+    # pins a resumed run to the same arithmetic path
+    assert ops.FactoredGrads.max_rows_gathered == before
+    explicit = GradientReducer(Tiny(), world, shard_min_rows=640)
+    explicit.calibrate(nbytes=1 << 20, iters=1)
+    assert explicit.shard_min_rows == 640 and explicit.rates["explicit"]["shard_min_rows"]
+    resumed = GradientReducer(Tiny(), world)
+    resumed.load_state_dict(red.state_dict())
+    resumed.calibrate(nbytes=1 << 20, iters=1)
+    assert (resumed.shard_min_rows, resumed.max_rows_gathered) == (red.shard_min_rows, red.max_rows_gathered)
     dist.destroy_process_group()
 
 
@@ -212,7 +255,7 @@ def test_exchange_plan_prices_the_alternatives():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_gradient_reducer(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
 
