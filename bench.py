@@ -259,6 +259,10 @@ def main():
                          "net_factory_3d, utils.losses, six .item() per iteration, eager) with torch.optim.SGD and with the one-line "
                          "FusedSGD swap; reported as config.reference_loop beside the headline (3D U-Net ICL, one rank)")
     ap.add_argument("--force-ddp", action="store_true", help="with --gpus 1: run the data-parallel step on a one-rank RCCL group")
+    ap.add_argument("--project-world", type=int, default=0,
+                    help="with --gpus 1 --force-ddp: add config.ddp_plan.projection — this one-rank step projected to W ranks with "
+                         "ddp.project_world at the assumed 300 / 250 GB/s all-gather / all-reduce rates per rank (a projection from this "
+                         "run's own numbers, NOT a measurement; no multi-GPU node was available to any round)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="exercise ONLY the multi-rank plumbing (self-launch, rendezvous, barrier-bracketed timing, MAX over ranks, "
                          "rank-0 JSON relay) on a gloo group with a sleep as the step: no GPU, no kernels; used by tests/")
@@ -556,6 +560,18 @@ def main():
                                                 "frac": round(v[2] / (v[1] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
                                             for k, v in sorted(wa.items())}
 
+    projection = None
+    if rank == 0 and use_ddp and world == 1 and args.project_world > 1 and ddp.last_plan:
+        from icl_amd.ddp import project_world
+        mats = [dict(rows=m["rows_gathered"], elems=m["shape"][0] * m["shape"][1], out_rows=m["shape"][0]) for m in ddp.last_plan]
+        # bytes one rank contributes to the factor-row all-gather: a g row (out floats) + an x row (in floats) per factor row of the
+        # 13,824^2 matrices (the 1,728^2 ones add < 2 %)
+        fac_bytes = 4.0 * sum(m["rows_gathered"] * (m["shape"][0] + m["shape"][1]) for m in ddp.last_plan)
+        small = 4.0 * sum(p.numel() for p in model.parameters() if p.grad is not None)
+        projection = project_world(mats, args.project_world, dt / args.steps * 1e3, small_grad_bytes=small, factor_bytes_per_rank=fac_bytes)
+        projection["note"] = ("projected from this one-rank measurement with ddp.project_world (update times of tools/sgd_probe.py, assumed "
+                              "link rates); the 8-GPU bench is the driver's to run")
+
     if rank == 0:
         out = {
             "metric": "3D volumes/sec/node (fwd+bwd, 96^3 patch)", "value": round(value, 3), "unit": "volumes/s",
@@ -567,7 +583,7 @@ def main():
                        **({"rehearsal": "every rank on ONE device over gloo (ICL_BENCH_SHARE_GPU=1): exercises the multi-rank code path, "
                                         "the timing is meaningless"} if share else {}),
                        **({"rccl_ranks": torch.distributed.get_world_size(), "collective_backend": torch.distributed.get_backend(),
-                           "ddp_plan": {"rates": ddp.rates, "matrices": ddp.last_plan}}
+                           "ddp_plan": {"rates": ddp.rates, "matrices": ddp.last_plan, **({"projection": projection} if projection else {})}}
                           if use_ddp else {}),
                        "launch": ("eager" if not graphed else "hipGraph replay" if ddp is None else
                                   "hipGraph replay (forward/backward, optimiser) + eager RCCL collectives"),

@@ -197,20 +197,15 @@ __global__ __launch_bounds__(256) void conv_bf16x3_split_weights_kernel(const fl
   }
 }
 
-// Schedule variants (ICL_CONV_SPLIT_V, A/B tool tools/conv_ab.py):
-// V = 0: the round-2 schedule: halo values stay fp32 until the store phase, which splits them between two barriers.
-// V & 1: straight-line halo loads (clamped address + select; V = 0 emits exec-mask branches around the predicated loads).
-// V & 4: halo loads as buffer loads (32-bit lane offset against a descriptor of the 16-channel chunk; out-of-volume and idle lanes
-//        are handed offset 2^31 and the hardware returns 0): no branches, no address clamps, no selects.
-// V & 8: (one cout block) all three weight planes of the channel chunk stay in LDS (43 KB beside the 104 KB halo tile) instead of
-//        one plane per dz stage: two barriers per work item instead of six, and a single-chunk layer (16 -> 16) loads its weights
-//        once per workgroup instead of once per tile.  DEFAULT (round 3, batch 2: 16->16 @96^3 137 vs 152 us, 48->16 406 vs 423).
-//        V & 4 measured neutral on top of it (139 / 419) and alone (152 / 430).
-// V & 2: each staging round is split into its three packed bf16 planes INSIDE the multiply phase (one round per tap pair of the
-//        dz = 1 / 2 stages, pinned there), so that the store phase is 15 ds_write_b128 per thread and nothing else.  MEASURED
-//        SLOWER (round 3, batch 2: 16->16 @96^3 171 vs 161 us, 48->16 473 vs 438, 32->32 @48^3 71.8 vs 67.8): the two waves of a
-//        SIMD run the multiply phase together, the matrix pipe is already saturated there, and the extra VALU lengthens each
-//        wave's in-order stream instead of hiding in the other wave's MFMAs.  Kept as a measurement variant, not the default.
+// Schedule of conv3d_bf16x3_fwd_kernel (the template parameter V is kept at 60 = 8 + 16 + 32 + 4 for the probes that name it; the other
+// variants were removed in round 5 — measurements in DESIGN.md §4 and profiles/r3_pmc_conv.md):
+//   8   (one cout block) all three weight planes of the channel chunk stay in LDS (43 KB beside the 104 KB halo tile): two barriers per
+//       work item instead of six (round 3, batch 2: 16->16 @96^3 137 vs 152 us, 48->16 406 vs 423);
+//   16  operand fragments fetched one half-step ahead; 32: every fragment read issued behind one MFMA of the half before it
+//       (scheduling groups); 4: the halo loads of the next work item as buffer loads (hardware zero fill, no branches), one staging round
+//       woven into each tap pair of the dz = 0 stage.  Together -7..13 % against 8 alone.
+//   Measured and removed: the operand split pinned into the multiply phase (V & 2: +6-8 % time), straight-line loads with selects
+//   (V & 1: +7 %), one weight plane per dz stage for one cout block (V = 0), the un-pipelined pair loop (V < 16).
 // The same for up to kSplitMulti packed weights in ONE launch (grid.y = weight): a training step splits every convolution weight
 // once, up front (they only change in the optimiser), instead of one small launch in front of every convolution call.
 constexpr int kSplitMulti = 32;
@@ -259,42 +254,18 @@ __device__ long long g_bf3_stamps[2 * 3 * 32];
 #define BF3_STAMP(k) ((void)0)
 #endif
 
-#if defined(BF3_PLANES_PROBE)
-// fp32 [N][C][S] -> planes [split 3][N][C / 8][S] of 8 packed bf16 (probe builds: what a producer would write)
-__global__ __launch_bounds__(256) void conv_bf16x3_split_planes_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int N, int C, long S) {
-  const long total = (long)N * (C / 8) * S;
-  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-    const long pos = it % S, no = it / S;
-    const int oct = (int)(no % (C / 8)), n = (int)(no / (C / 8));
-    float v[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) v[c] = x[((long)n * C + oct * 8 + c) * S + pos];
-    uint4 o1, o2, o3;
-    bf3_split8(v, o1, o2, o3);
-    planes[it] = o1; planes[it + total] = o2; planes[it + 2 * total] = o3;
-  }
-}
-#endif
 
-template <int NBT, int TY, int V = 8, bool FLAT = false>
+template <int NBT, int TY, int V = 60, bool FLAT = false>
 __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {
   typedef typename std::conditional<FLAT, Bf3F24, Bf3T<TY>>::type TC;
   constexpr int MB = FLAT ? 3 : 4;                      // row blocks per wave
-  static_assert(!FLAT || (TY == 8 && (V & 48) == 48), "the flat tile exists for the pipelined schedule of eight waves");
-  // three cout blocks: 48 accumulators + 36 weight-fragment + 24 weight-prefetch registers leave no room for the split planes
-  // (432 B of scratch when tried): those instantiations take the straight-line loads of V = 1 and keep the split in the store phase
-  constexpr bool EARLY = (V & 2) != 0 && NBT < 3;
-  constexpr bool STRAIGHT = (V & 1) != 0, BUFFER = (V & 4) != 0, WHOLE = (V & 8) != 0 && NBT == 1;
-  // V & 16: operand fragments fetched one half-step ahead (see the multiply loop).  B fragments are double-buffered up to two cout
-  // blocks; with three the second set does not fit the register budget (B of the next pair is then read behind the last MFMA)
-  constexpr bool PIPE = (V & 16) != 0 && !EARLY, PIPE_B2 = NBT < 3;
-  // V & 32 (with 16): the reads of a half-step are not issued as a burst in front of its MFMAs but one behind every NBT-th MFMA
-  // (scheduling groups): in-kernel stamps showed a wave alone at 560-600 cycles per pair against 384 of matrix-pipe time — the
-  // burst's issue time — and the two waves of a SIMD in lockstep (same code, same barrier), bursting together
-  constexpr bool WEAVE = (V & 32) != 0 && PIPE;
-  constexpr bool WOVEN = WEAVE && BUFFER;
-  static_assert(!WOVEN || TC::ROUNDS <= 5, "one staging round per tap pair of the first dz stage");
+  static_assert(V == 60, "one schedule (see the comment above the weight-split kernels)");
+  static_assert(!FLAT || TY == 8, "the flat tile exists for eight waves");
+  // one cout block: all three weight planes of a chunk resident in LDS; B fragments double-buffered up to two cout blocks (with three
+  // the second set does not fit the register budget: B of the next pair is then read behind the last MFMA)
+  constexpr bool WHOLE = NBT == 1, PIPE_B2 = NBT < 3;
+  static_assert(TC::ROUNDS <= 5, "one staging round per tap pair of the first dz stage");
   constexpr int WPL = WHOLE ? 3 : 1;                    // weight planes staged together
   constexpr int NB = 16 * NBT, PX = TC::PX, PY = TC::PY, NPOSP = TC::NPOSP, ROUNDS = TC::ROUNDS, NT = TC::NT;
   constexpr int WITEMS = WPL * 6 * Bf3::SLOTS * NB, WU = (WITEMS + NT - 1) / NT;      // 16-byte weight slots per staging step
@@ -314,24 +285,17 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   // ---- staging: item = (channel octet, halo position); lanes walk the positions of the tile in LDS order, so the three 16-byte
   // writes of an item land on consecutive LDS slots across the lanes (no bank conflicts) and the 8 loads of a wave-instruction
   // read runs of 18 consecutive floats.  Tile-invariant part of the addressing:
-  int s_zyx[ROUNDS], s_dst[ROUNDS], s_ch[ROUNDS], s_rel[BUFFER ? ROUNDS : 1];
+  int s_zyx[ROUNDS], s_dst[ROUNDS], s_rel[ROUNDS];
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int it = tid + r * NT;
     const int o = it / TC::NPOS, pos = it % TC::NPOS;
     const int px = pos % PX, row = pos / PX, py = row % PY, pz = row / PY;
     s_zyx[r] = it < TC::ITEMS ? (pz << 16) | (py << 8) | px : -1;
-    s_ch[r] = o * 8;                                    // first channel of the octet
     s_dst[r] = o * NPOSP + pos;
-    if (BUFFER) s_rel[r] = o * 8 * (int)DHW + (pz - 1) * (int)HW + (py - 1) * g.W + (px - 1);
+    s_rel[r] = o * 8 * (int)DHW + (pz - 1) * (int)HW + (py - 1) * g.W + (px - 1);
   }
   float xv[ROUNDS][8];
-#if defined(BF3_PLANES_PROBE)
-  // PROBE BUILD ONLY (tools/planes_probe.py; result, round 3: 16->16 @96^3 154-162 us against 161-172, 48->16 429 / 484, 32->32 @48^3
-  // 73.0 / 73.5, 48->48 @96^3 1040 / 1027 — a producer-side split is worth 0-11 % of this kernel): `x` holds the operand planes already — [split 3][sample][octet][D][H][W] of 8 packed bf16,
-  // written by conv_bf16x3_split_planes_kernel — and a staging item is three 16-byte loads and three LDS stores, no VALU split
-  uint4 xpl[ROUNDS][3];
-#endif
   // the (sample, z0, y0, x0) of a tile: five integer divisions of wave-uniform values (a reciprocal sequence on the VALU each) — once
   // per work item, not once per staging round
   struct Origin { const float* xb; int z0, y0, x0, b, chunk; };
@@ -351,78 +315,31 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       const int gz = z0 - 1 + (s_zyx[r] >> 16), gy = y0 - 1 + ((s_zyx[r] >> 8) & 255), gx = x0 - 1 + (s_zyx[r] & 255);
       // (bitwise &: the short-circuit form compiles to a chain of exec-mask branches)
       const bool ok = (s_zyx[r] >= 0) & ((unsigned)gz < (unsigned)g.D) & ((unsigned)gy < (unsigned)g.H) & ((unsigned)gx < (unsigned)g.W);
-      // 32-bit lane offset against a wave-uniform channel base (16 channels x D*H*W < 2^31 elements, checked by the launcher)
-      const int off = ok ? s_ch[r] * (int)DHW + gz * (int)HW + gy * g.W + gx : 0;
-#if defined(BF3_PLANES_PROBE)
-      if (BUFFER) {
-        // o.xb was computed for fp32 planes: recover (sample, chunk) from it
-        const int bb = o.b, ch = o.chunk;
-        const int oct = s_ch[r] >> 3, nb = g.ntiles / (g.ntz * g.nty * g.ntx);
-        const icl_rsrc_t pr = icl_make_rsrc(x, (unsigned)((long)3 * nb * (g.Cin / 8) * DHW * 16));
-        const long plane = (long)nb * (g.Cin / 8) * DHW;
-        const long pos = ((long)bb * (g.Cin / 8) + ch * 2 + oct) * DHW + (long)gz * HW + (long)gy * g.W + gx;
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) xpl[r][sp] = icl_buffer_load_u32x4(pr, ok ? (unsigned)((pos + sp * plane) * 16) : 0x80000000u);
-        continue;
-      }
-#endif
-      if (BUFFER) {
-        const icl_rsrc_t xr = icl_make_rsrc(xb, (unsigned)(16 * DHW * 4));
-        // lane part: the tile-invariant offset of the lane's halo position and channel octet (s_rel) + the tile's origin; the
-        // channel plane c enters as the scalar offset of the load
-        const unsigned boff = ok ? (unsigned)(s_rel[r] + (z0 * (int)HW + y0 * g.W + x0)) * 4u : 0x80000000u;
+      // buffer loads: 32-bit lane offset against a descriptor of the 16-channel chunk (16 channels x D*H*W < 2^31 elements, checked by
+      // the launcher); out-of-volume and idle lanes are handed offset 2^31 and the hardware returns 0 — no branches, no clamps.  Lane
+      // part: the tile-invariant offset of the lane's halo position and channel octet (s_rel) + the tile's origin; the channel plane c
+      // enters as the scalar offset of the load
+      const icl_rsrc_t xr = icl_make_rsrc(xb, (unsigned)(16 * DHW * 4));
+      const unsigned boff = ok ? (unsigned)(s_rel[r] + (z0 * (int)HW + y0 * g.W + x0)) * 4u : 0x80000000u;
 #pragma unroll
 #if defined(BF3_DEBUG) && (BF3_DEBUG & 32)
-        for (int c = 0; c < 8; ++c) xv[r][c] = __uint_as_float(boff + c);      // ablation: the address arithmetic without the loads
+      for (int c = 0; c < 8; ++c) xv[r][c] = __uint_as_float(boff + c);      // ablation: the address arithmetic without the loads
 #else
-        for (int c = 0; c < 8; ++c) xv[r][c] = icl_buffer_load_f32(xr, boff, (unsigned)c * (unsigned)DHW * 4u);
+      for (int c = 0; c < 8; ++c) xv[r][c] = icl_buffer_load_f32(xr, boff, (unsigned)c * (unsigned)DHW * 4u);
 #endif
-      } else if (!STRAIGHT) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) xv[r][c] = ok ? (xb + c * DHW)[off] : 0.f;
-      } else {
-        // unconditional loads from an always-valid address (offset 0 of the channel plane), then a select: no branch per load
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float v = (xb + c * DHW)[off];
-          xv[r][c] = ok ? v : 0.f;
-        }
-      }
     }
   };
   auto load_x = [&](int tile, int chunk) { load_x_at(origin_of(tile, chunk), 0, ROUNDS); };
-  uint4 xsp[EARLY ? ROUNDS : 1][3];          // V = 1: the split planes of a staging round, produced during the multiply phase
-  auto split_round = [&](int r) {
-    bf3_split8(xv[r], xsp[EARLY ? r : 0][0], xsp[EARLY ? r : 0][1], xsp[EARLY ? r : 0][2]);
-    // pin the planes to this point of the program: left alone the compiler sinks the whole split to the end of the loop body
-    // (behind the last MFMA, in front of the barrier), which is the round-2 schedule again
-#pragma unroll
-    for (int s = 0; s < 3; ++s) ICL_PIN4(xsp[EARLY ? r : 0][s]);
-  };
   auto store_x = [&]() {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       if (s_zyx[r] < 0) continue;
       uint4* d = Xs + s_dst[r];
-#if defined(BF3_PLANES_PROBE)
-      if (BUFFER) {
-        d[0] = xpl[r][0];
-        d[2 * NPOSP] = xpl[r][1];
-        d[4 * NPOSP] = xpl[r][2];
-        continue;
-      }
-#endif
-      if (!EARLY) {
-        uint4 o1, o2, o3;
-        bf3_split8(xv[r], o1, o2, o3);
-        d[0] = o1;
-        d[2 * NPOSP] = o2;
-        d[4 * NPOSP] = o3;
-      } else {
-        d[0] = xsp[r][0];
-        d[2 * NPOSP] = xsp[r][1];
-        d[4 * NPOSP] = xsp[r][2];
-      }
+      uint4 o1, o2, o3;
+      bf3_split8(xv[r], o1, o2, o3);
+      d[0] = o1;
+      d[2 * NPOSP] = o2;
+      d[4 * NPOSP] = o3;
     }
   };
   // weights: already split (conv_bf16x3_split_weights_kernel): one dz plane = 60 NB slots of 16 bytes, copied through registers
@@ -468,7 +385,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   const uint4* wb = Ws + (half * Bf3::SLOTS + tp) * NB + lr;
 
   f32x4 acc[4][NBT];
-  uint4 pa1[PIPE ? 4 : 1], pa23[PIPE ? 4 : 1][2], pb[PIPE && PIPE_B2 ? 2 : 1][3][NBT];      // V & 16: fragments fetched ahead
+  uint4 pa1[4], pa23[4][2], pb[PIPE_B2 ? 2 : 1][3][NBT];      // fragments fetched one half-step ahead
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -485,10 +402,6 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   if (tile < g.ntiles) {
     load_w(0, 0);
     load_x(tile, 0);
-    if (EARLY) {
-#pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) split_round(r);
-    }
   }
   // the bias of the lane's output channels, loaded once (inside the epilogue it is a global load per work item whose latency every wave
   // waits out in front of its stores: conv_bf16x3_ws.h)
@@ -533,16 +446,15 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
         BF3_STAMP(3);
         if (g.nchunks > 1 && ntile < g.ntiles) load_w(nchunk, 0);
       }
-      // WOVEN: the halo loads of the next work item are not issued here as one burst (in-kernel stamps: 2.7-4.1k of a 20k-cycle
-      // item during which both waves of a SIMD compute addresses and the matrix pipe idles) but one staging round per tap pair
-      // of the dz = 0 stage, inside that pair's scheduling region (buffer loads: no branches; past the last tile the current one
-      // is loaded again and never stored)
-      if (dz == 0 && ntile < g.ntiles && !WOVEN) load_x(ntile, nchunk);
-      if (WOVEN && dz == 0) nxt = origin_of(ntile < g.ntiles ? ntile : tile, ntile < g.ntiles ? nchunk : chunk);
+      // the halo loads of the next work item are not issued here as one burst (in-kernel stamps: 2.7-4.1k of a 20k-cycle item during
+      // which both waves of a SIMD compute addresses and the matrix pipe idles) but one staging round per tap pair of the dz = 0
+      // stage, inside that pair's scheduling region (buffer loads: no branches; past the last tile the current one is loaded again
+      // and never stored)
+      if (dz == 0) nxt = origin_of(ntile < g.ntiles ? ntile : tile, ntile < g.ntiles ? nchunk : chunk);
       if (dz == 0) BF3_STAMP(4);
       // stage dz holds the tap slots 10 dz .. 10 dz + 9 (27 taps + one zero slot = 14 pairs in stages of 5 / 5 / 4: a pair may
       // straddle two dz planes); lane group tp takes the first or the second tap of the pair: its halo offset is a select
-      if constexpr (PIPE) {
+      {
         // A pair's 24 NBT products in two halves of 12 NBT: X = the a1 terms (a1 b3, a1 b2, a1 b1: one operand plane of the four row
         // blocks, 4 reads), Y = (a3 b1, a2 b2, a2 b1: two planes, 8 reads).  The reads of a half are issued in front of the MFMAs of the
         // half before it — Y of this pair under X, X and the weight fragments of the NEXT pair under Y — so a wave waits for LDS
@@ -592,23 +504,20 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #pragma unroll
         for (int pair = 0; pair < np; ++pair) {
           const int cur = PIPE_B2 ? (5 * dz + pair) & 1 : 0;
-          if (WOVEN && dz == 0 && pair < ROUNDS) load_x_at(nxt, pair, pair + 1);
+          if (dz == 0 && pair < ROUNDS) load_x_at(nxt, pair, pair + 1);
           load_x23(dz, pair);
-          if (!WEAVE) ICL_SCHED_BARRIER();
 #pragma unroll
           for (int sb = 2; sb >= 0; --sb)
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
               for (int j = 0; j < NBT; ++j) acc[m][j] = icl_mfma_16x16x32_bf16(pa1[m], pb[cur][sb][j], acc[m][j]);
-          if (WEAVE) {
 #pragma unroll
-            for (int i = 0; i < 2 * MB; ++i) {
-              ICL_SCHED_GROUP(0x008, NBT);
-              ICL_SCHED_GROUP(0x100, 1);
-            }
-            ICL_SCHED_GROUP(0x008, MB * NBT);
+          for (int i = 0; i < 2 * MB; ++i) {
+            ICL_SCHED_GROUP(0x008, NBT);
+            ICL_SCHED_GROUP(0x100, 1);
           }
+          ICL_SCHED_GROUP(0x008, MB * NBT);
           ICL_SCHED_BARRIER();
           const bool more = pair + 1 < np || (WHOLE && dz < 2);
           const int ndz = pair + 1 < np ? dz : dz + 1, npair = pair + 1 < np ? pair + 1 : 0;
@@ -619,7 +528,6 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
             load_x1(ndz, npair);
             if (PIPE_B2) load_b(cur ^ 1, ndz, npair, 0, 2);
           }
-          if (!WEAVE) ICL_SCHED_BARRIER();
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
             constexpr int sa[3] = {1, 0, 0}, sbb[3] = {0, 1, 0};      // a3 b1, a2 b2, a2 b1
@@ -628,7 +536,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #pragma unroll
               for (int j = 0; j < NBT; ++j) acc[m][j] = icl_mfma_16x16x32_bf16(pa23[m][sa[t]], pb[cur][sbb[t]][j], acc[m][j]);
           }
-          if (WEAVE && more) {
+          if (more) {
             constexpr int R = MB + (PIPE_B2 ? 3 * NBT : 0);      // reads of this half-step
             constexpr int NM = 3 * MB * NBT;                     // its MFMAs
 #pragma unroll
@@ -642,55 +550,6 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
           if (more && !PIPE_B2) load_b(0, ndz, npair);
           BF3_STAMP(5 + 5 * dz + pair);
         }
-      } else {
-#pragma unroll
-      for (int pair = 0; pair < (dz < 2 ? 5 : 4); ++pair) {
-        const int tA = 10 * dz + 2 * pair, tB = tA + 1 < 27 ? tA + 1 : 26;      // the zero slot multiplies any valid position
-        const int offA = (tA / 9) * PY * PX + ((tA / 3) % 3) * PX + tA % 3, offB = (tB / 9) * PY * PX + ((tB / 3) % 3) * PX + tB % 3;
-        const uint4* xp = xa + (tp ? offB : offA);
-        // the operand fragments of MB row blocks first (V = 0: all four; V = 1 with two or three cout blocks: two at a time, which
-        // frees 24 registers for the split planes), then their 6 MB NBT MFMAs: the other wave of the SIMD multiplies while this one waits
-        constexpr int MB = (!EARLY || NBT == 1) ? 4 : 2;
-        uint4 b[3][NBT];
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-          for (int j = 0; j < NBT; ++j) b[s][j] = wb[((WHOLE ? dz * 6 : 0) * Bf3::SLOTS + s * 2 * Bf3::SLOTS + pair * 2) * NB + j * 16];
-#pragma unroll
-        for (int m0 = 0; m0 < 4; m0 += MB) {
-          uint4 a[MB][3];
-#pragma unroll
-          for (int m = 0; m < MB; ++m)
-#pragma unroll
-            for (int s = 0; s < 3; ++s) a[m][s] = xp[2 * s * NPOSP + (m0 + m) * PX];
-          ICL_SCHED_BARRIER();
-          if (EARLY && m0 == 0) {
-            // staging round q of the NEXT work item (its loads were issued at dz = 0) becomes three packed planes here, in the same
-            // scheduling region as the pair's MFMAs: slots are the pairs 2..4 of dz = 1 and 0..3 of dz = 2
-            // (unconditional — a branch would cut the scheduling region; without a next work item the values are never stored)
-            static_assert(ROUNDS <= 7, "one staging round per slot");
-            const int q = dz == 1 ? pair - 2 : dz == 2 ? 3 + pair : -1;
-            if (q >= 0 && q < ROUNDS) split_round(q);
-          }
-#pragma unroll
-          for (int t = 0; t < 6; ++t) {
-            // (a split, b split) of the six products, smallest terms first; consecutive MFMAs go to different accumulators
-            constexpr int sa[6] = {2, 1, 0, 1, 0, 0}, sb[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-              for (int j = 0; j < NBT; ++j) {
-#if defined(BF3_DEBUG) && (BF3_DEBUG & 1)
-                acc[m0 + m][j][0] += __uint_as_float(a[m][sa[t]].x ^ b[sb[t]][j].y);
-#else
-                acc[m0 + m][j] = icl_mfma_16x16x32_bf16(a[m][sa[t]], b[sb[t]][j], acc[m0 + m][j]);
-#endif
-              }
-          }
-          ICL_SCHED_BARRIER();
-        }
-        BF3_STAMP(5 + 5 * dz + pair);
-      }
       }
     }
     BF3_STAMP(20);
@@ -741,17 +600,9 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient, split products
-// dW[co][ci][tap] = sum over voxels of dY[co][p] * x[ci][p + tap - 1] with the same exact three-way splits.  GEMM view per tap:
-// rows = 16 output channels, columns = 16 input channels, k = 32 voxels = two (z, y) rows x 16 x.  Lane group lq supplies 8
-// consecutive x of row (lq >> 1), half (lq & 1) — which is how NCDHW stores both tensors, so no transposition: LDS holds
-//   Gs[split 3][tile row 32][half 2][cout 16][8 x]                     dY of a 4 x 8 x 16 voxel tile
-//   Xs[split 3][halo row 60][half 2][cin 16][8 x] + [cin 16] edge dwords   x rows with the neighbours x0-1 | x0+16 packed per row
-// The dx = 1 tap reads its B fragment as stored; dx = 0 / 2 are the same 16 bytes shifted by one bf16 with the last / first element
-// of the neighbouring segment (v_alignbit: 4 per fragment).  A wave owns ALL 27 taps (108 accumulator registers) for four of the 16
-// k-steps of a tile — no tap split, so every staged value feeds 27 taps x 6 terms; four waves per workgroup, one per SIMD, so that a
-// wave may use the whole 512-entry register file (accumulators in AGPRs) — and the waves add their accumulators
-// through LDS after the workgroup's run of tiles; one packed slab per workgroup, summed by reduce_unpack_wgrad_kernel in a fixed
-// order as for the fp32 kernels.  One (16 cout, 16 cin) block pair per workgroup (grid.y).
+// Geometry of the split-product weight gradient (conv_wgrad_tr.h: transposing LDS reads, two LDS buffers, eight waves).  The first form
+// of round 2 (conv3d_bf16x3_wgrad_kernel: x-major LDS images, v_alignbit tap shifts, all 27 taps per wave in AGPRs; 1.1-1.4x the fp32
+// kernels, 0.67x the round-3 form) lived here until round 5; its measurements are in DESIGN.md §4 and profiles/r2_pmc_conv.md.
 struct Bf3WGeom {
   int Cin, Cout, CinP, CoutP, D, H, W;
   int ntz, nty, ntx, ntiles;      // tiles per sample; ntiles = batch * ntz * nty * ntx
@@ -760,228 +611,5 @@ struct Bf3WGeom {
   int dbg;                        // timing ablations of conv_wgrad_tr.h (ICL_WGRAD_TR_DBG; results are wrong when set): 1 no global
                                   // loads, 2 no split / LDS stores, 4 no multiply
 };
-
-// NCB cout blocks of 16 per workgroup (every staged x value then feeds NCB x 27 x 6 MFMA terms) on a TZ x 8 x 16 voxel tile:
-// <1, 4>: 152 KB of LDS, 108 accumulator registers; <2, 2>: 118 KB, 216 accumulator registers (AGPRs).
-template <int NCB_, int TZ_>
-struct Bf3WT {
-  static constexpr int NCB = NCB_, TZ = TZ_, TY = 8, TX = 16, PZ = TZ + 2, PY = 10, HROWS = PZ * PY, TROWS = TZ * TY, NW = 4, NT = 256;
-  static constexpr int XROW = 36, GROW = 32 * NCB;                   // uint4 per row: 2 x 16 segments (+ 16 edge dwords) / 2 x 16 NCB
-  static constexpr int XS_U4 = 3 * HROWS * XROW, GS_U4 = 3 * TROWS * GROW;
-  static constexpr size_t LDS_BYTES = (size_t)(XS_U4 + GS_U4) * 16;
-  static constexpr int XITEMS = HROWS * 32, GITEMS = TROWS * GROW;
-  static constexpr int XR = (XITEMS + NT - 1) / NT, GR = (GITEMS + NT - 1) / NT;
-  static_assert((size_t)(NW / 2) * 27 * 4 * 64 * 4 <= LDS_BYTES, "the cross-wave sum (one cout block at a time) must fit in the tile buffers");
-};
-typedef Bf3WT<1, 4> Bf3W;
-
-// one fp32 -> its three bf16 terms as the high halves of three dwords (same round-to-nearest split as bf3_split2)
-__device__ __forceinline__ void bf3_split1(float v, unsigned& h1, unsigned& h2, unsigned& h3) {
-  bf3_split2(0.f, v, h1, h2, h3);
-}
-
-template <int NCB, int TZ>
-__global__ __launch_bounds__(256) void conv3d_bf16x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                  float* __restrict__ gwp, Bf3WGeom g) {
-  typedef Bf3WT<NCB, TZ> C;
-  ICL_DYN_LDS(uint4, lds);
-  uint4* Xs = lds;
-  uint4* Gs = lds + C::XS_U4;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lq = lane >> 4;
-  const int hf = lq & 1, rsel = lq >> 1;
-  const int ncb = (g.CinP + 15) / 16;
-  const int co0 = (blockIdx.y / ncb) * 16 * NCB, c0 = (blockIdx.y % ncb) * 16;
-  const long HW = (long)g.H * g.W, DHW = g.D * HW;
-  const int tiles_per = g.ntz * g.nty * g.ntx;
-
-  // ---- staging tables (tile-invariant): item -> (row, half, channel)
-  float xv[C::XR][9], gv[C::GR][8];      // xv[.][8]: the neighbour of the row segment pair (x0 - 1 for half 0, x0 + 16 for half 1)
-  auto tile_origin = [&](int tile, int& b, int& x0, int& y0, int& z0) {
-    b = tile / tiles_per;
-    const int bt = tile % tiles_per;
-    x0 = (bt % g.ntx) * C::TX; y0 = ((bt / g.ntx) % g.nty) * C::TY; z0 = (bt / (g.ntx * g.nty)) * C::TZ;
-  };
-  auto load_tile = [&](int tile) {
-    int b, x0, y0, z0;
-    tile_origin(tile, b, x0, y0, z0);
-    const float* xb = x + (long)b * g.x_bstride + (long)c0 * DHW;
-    const float* gb = gy + (long)b * g.gy_bstride + (long)co0 * DHW;
-#pragma unroll
-    for (int r = 0; r < C::XR; ++r) {
-      const int it = tid + r * C::NT, ci = it & 15, h = (it >> 4) & 1, R = it >> 5;
-      const int gz = z0 - 1 + R / C::PY, gyy = y0 - 1 + R % C::PY, gx = x0 + 8 * h;
-      const bool ok = it < C::XITEMS && c0 + ci < g.Cin && gz >= 0 && gz < g.D && gyy >= 0 && gyy < g.H && gx + 7 < g.W;
-      const float* p = xb + (ok ? (long)ci * DHW + gz * HW + (long)gyy * g.W + gx : 0L);
-      // unconditional loads from an always-valid address (p points at the block's first element when the item is outside), then a
-      // select: straight-line code, all loads of the tile in flight together (a predicated load is a branch per load)
-      const float4 lo = *reinterpret_cast<const float4*>(p);
-      const float4 hi = *reinterpret_cast<const float4*>(p + 4);
-      xv[r][0] = ok ? lo.x : 0.f; xv[r][1] = ok ? lo.y : 0.f; xv[r][2] = ok ? lo.z : 0.f; xv[r][3] = ok ? lo.w : 0.f;
-      xv[r][4] = ok ? hi.x : 0.f; xv[r][5] = ok ? hi.y : 0.f; xv[r][6] = ok ? hi.z : 0.f; xv[r][7] = ok ? hi.w : 0.f;
-      // the element next to the 16-wide row: the aligned quad in front of half 0 / behind half 1 (contiguous with the segment)
-      const int ex = h ? x0 + 16 : x0 - 4;
-      const bool eok = ok && ex >= 0 && ex + 3 < g.W;
-      const float4 e4 = *reinterpret_cast<const float4*>(p + (eok ? (h ? 8 : -4) : 0));
-      xv[r][8] = eok ? (h ? e4.x : e4.w) : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < C::GR; ++r) {
-      const int it = tid + r * C::NT, co = it % (16 * NCB), h = (it / (16 * NCB)) & 1, row = it / (32 * NCB);
-      const int gz = z0 + row / C::TY, gyy = y0 + row % C::TY, gx = x0 + 8 * h;
-      const bool ok = it < C::GITEMS && co0 + co < g.Cout && gz < g.D && gyy < g.H && gx + 7 < g.W;
-      const float* p = gb + (ok ? (long)co * DHW + gz * HW + (long)gyy * g.W + gx : 0L);
-      const float4 lo = *reinterpret_cast<const float4*>(p);
-      const float4 hi = *reinterpret_cast<const float4*>(p + 4);
-      gv[r][0] = ok ? lo.x : 0.f; gv[r][1] = ok ? lo.y : 0.f; gv[r][2] = ok ? lo.z : 0.f; gv[r][3] = ok ? lo.w : 0.f;
-      gv[r][4] = ok ? hi.x : 0.f; gv[r][5] = ok ? hi.y : 0.f; gv[r][6] = ok ? hi.z : 0.f; gv[r][7] = ok ? hi.w : 0.f;
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int r = 0; r < C::XR; ++r) {
-      const int it = tid + r * C::NT, ci = it & 15, h = (it >> 4) & 1, R = it >> 5;
-      if (it >= C::XITEMS) continue;
-      uint4 o1, o2, o3;
-      bf3_split8(xv[r], o1, o2, o3);
-      uint4* d = Xs + R * C::XROW + h * 16 + ci;
-      d[0] = o1;
-      d[C::HROWS * C::XROW] = o2;
-      d[2 * C::HROWS * C::XROW] = o3;
-      // edge dword of (row, channel): low half = x0 + 16 (written by the half-1 item), high half = x0 - 1 (half-0 item)
-      unsigned e1, e2, e3;
-      bf3_split1(xv[r][8], e1, e2, e3);
-      unsigned short* e = reinterpret_cast<unsigned short*>(Xs + R * C::XROW + 32) + 2 * ci + (h ? 0 : 1);
-      e[0] = (unsigned short)(e1 >> 16);
-      e[C::HROWS * C::XROW * 8] = (unsigned short)(e2 >> 16);
-      e[2 * C::HROWS * C::XROW * 8] = (unsigned short)(e3 >> 16);
-    }
-#pragma unroll
-    for (int r = 0; r < C::GR; ++r) {
-      const int it = tid + r * C::NT, co = it % (16 * NCB), h = (it / (16 * NCB)) & 1, row = it / (32 * NCB);
-      if (it >= C::GITEMS) continue;
-      uint4 o1, o2, o3;
-      bf3_split8(gv[r], o1, o2, o3);
-      uint4* d = Gs + row * C::GROW + h * 16 * NCB + co;
-      d[0] = o1;
-      d[C::TROWS * C::GROW] = o2;
-      d[2 * C::TROWS * C::GROW] = o3;
-    }
-  };
-
-  f32x4 acc[NCB][27];
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-    for (int t = 0; t < 27; ++t) acc[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // lane pointers: segment of this lane's half, and the dwords holding the neighbours x - 1 (high half) / x + 8 (low half)
-  const unsigned* xdw = reinterpret_cast<const unsigned*>(Xs);
-  const int seg_off = hf * 16 + lr;                                                   // uint4 index inside a row
-  const int prev_off = hf ? (0 * 16 + lr) * 4 + 3 : 32 * 4 + lr;                       // dword index inside a row
-  const int next_off = hf ? 32 * 4 + lr : (1 * 16 + lr) * 4 + 0;
-
-  const int t_begin = blockIdx.x * g.tiles_per_wg;
-  const int t_end = t_begin + g.tiles_per_wg < g.ntiles ? t_begin + g.tiles_per_wg : g.ntiles;
-  if (t_begin < t_end) load_tile(t_begin);
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    __syncthreads();
-#if !defined(BF3W_DEBUG) || !(BF3W_DEBUG & 2)
-    store_tile();
-#endif
-    __syncthreads();
-#if !defined(BF3W_DEBUG) || !(BF3W_DEBUG & 4)
-    if (tile + 1 < t_end) load_tile(tile + 1);
-#endif
-#pragma unroll 1
-    for (int kk = 0; kk < C::TROWS / 2 / C::NW; ++kk) {
-      const int rr0 = 2 * (wid + C::NW * kk);             // first tile row of the k-step
-      const int trow = rr0 + rsel;                        // this lane's tile row
-      const int tz = trow / C::TY, ty = trow % C::TY;
-      uint4 a[NCB][3];
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) a[cb][s] = Gs[(s * C::TROWS + trow) * C::GROW + hf * 16 * NCB + cb * 16 + lr];
-      // raw fragments of tap row unit u + 1 are read while unit u is multiplied (one wave per SIMD: nobody else hides the LDS latency)
-      uint4 m[2][3];
-      unsigned pv[2][3], nx[2][3];
-      auto read_unit = [&](int buf, int u) {
-        const int R = (tz + u / 3) * C::PY + ty + u % 3;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const int row = (s * C::HROWS + R) * C::XROW;
-          m[buf][s] = Xs[row + seg_off];
-          pv[buf][s] = xdw[row * 4 + prev_off];
-          nx[buf][s] = xdw[row * 4 + next_off];
-        }
-      };
-      read_unit(0, 0);
-#pragma unroll
-      for (int u = 0; u < 9; ++u) {
-        const int cur = u & 1;
-        if (u < 8) read_unit(cur ^ 1, u + 1);
-        ICL_SCHED_BARRIER();
-        uint4 b[3][3];                                     // [dx][split]
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          b[0][s] = make_uint4(icl_alignbit(m[cur][s].x, pv[cur][s], 16), icl_alignbit(m[cur][s].y, m[cur][s].x, 16), icl_alignbit(m[cur][s].z, m[cur][s].y, 16),
-                               icl_alignbit(m[cur][s].w, m[cur][s].z, 16));
-          b[1][s] = m[cur][s];
-          b[2][s] = make_uint4(icl_alignbit(m[cur][s].y, m[cur][s].x, 16), icl_alignbit(m[cur][s].z, m[cur][s].y, 16), icl_alignbit(m[cur][s].w, m[cur][s].z, 16),
-                               icl_alignbit(nx[cur][s], m[cur][s].w, 16));
-        }
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-          // (dY split, x split) of the six terms, smallest first; consecutive MFMAs go to the three dx accumulators
-          constexpr int sa[6] = {2, 1, 0, 1, 0, 0}, sb[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#if defined(BF3W_DEBUG) && (BF3W_DEBUG & 1)
-              acc[cb][u * 3 + dx][0] += __uint_as_float(a[cb][sa[t]].x ^ b[dx][sb[t]].y);
-#else
-              acc[cb][u * 3 + dx] = icl_mfma_16x16x32_bf16(a[cb][sa[t]], b[dx][sb[t]], acc[cb][u * 3 + dx]);
-#endif
-        }
-      }
-    }
-  }
-
-  // ---- sum the waves' accumulators through LDS (2 + 1 writers, one cout block at a time), wave 0 stores the slab
-  float* red = reinterpret_cast<float*>(lds);
-#pragma unroll
-  for (int step = C::NW / 2; step >= 1; step >>= 1) {
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-      __syncthreads();
-      if (wid >= step && wid < 2 * step) {
-        float* d = red + (long)(wid - step) * (27 * 4 * 64) + lane;
-#pragma unroll
-        for (int t = 0; t < 27; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) d[(t * 4 + r) * 64] = acc[cb][t][r];
-      }
-      __syncthreads();
-      if (wid < step) {
-        const float* d = red + (long)wid * (27 * 4 * 64) + lane;
-#pragma unroll
-        for (int t = 0; t < 27; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[cb][t][r] += d[(t * 4 + r) * 64];
-      }
-    }
-  }
-  if (wid == 0 && c0 + lr < g.CinP) {
-    float* dst = gwp + (long)blockIdx.x * (27L * g.CinP * g.CoutP) + (long)(c0 + lr) * g.CoutP + co0 + 4 * lq;
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-      for (int t = 0; t < 27; ++t)
-        if (co0 + cb * 16 < g.CoutP)
-          *reinterpret_cast<float4*>(dst + (long)t * g.CinP * g.CoutP + cb * 16) =
-              make_float4(acc[cb][t][0], acc[cb][t][1], acc[cb][t][2], acc[cb][t][3]);
-  }
-}
 
 }  // namespace icl

@@ -54,16 +54,6 @@ __device__ __forceinline__ void reduce_slabs_quad(const float* slab, float* out,
   *reinterpret_cast<float4*>(out + m * ldo + n) = a;
 }
 
-// The same sum over the rectangle rows [r0, r1) x columns [c0, c1) (multiples of 4), by the NT threads of ONE workgroup: what the
-// workgroup that drew a region's last ticket runs (common.h ticket_is_last) instead of a second launch.  Bitwise the result of
-// gemm_reduce_slabs_kernel: same order, same operations.
-__device__ __forceinline__ void reduce_slabs_rect(const float* slab, float* out, const float* __restrict__ bias, int S, int r0,
-                                                  int r1, int c0, int c1, long spitch, long sstride, long ldo, int act_flags, int tid, int nt) {
-  const int nq = (c1 - c0) >> 2;
-  const int total = (r1 - r0) * nq;
-  for (int it = tid; it < total; it += nt) reduce_slabs_quad(slab, out, bias, S, r0 + it / nq, c0 + (it % nq) * 4, spitch, sstride, ldo, act_flags);
-}
-
 // ------------------------------------------------------------------------------------------------ weight streaming
 // Skinny products against a big row-major weight W [O][K] (the 13,824^2 token-axis MLP, <= 32 activation rows):
 //   NN = false  forward         part[s][m][o] = sum_{k in slice s} xs[m][k] W[o][k]      xs = x  [M][K]
@@ -82,7 +72,7 @@ __device__ __forceinline__ void reduce_slabs_rect(const float* slab, float* out,
 template <int MT, bool NN, int P>
 __global__ __launch_bounds__(512) void linear_stream_kernel(const float* __restrict__ xs, const float* __restrict__ w, float* __restrict__ slab,
                                                             int M, int K, int O, int slice_len, int upw, const float* __restrict__ bias,
-                                                            int act, float* __restrict__ y, unsigned* __restrict__ tickets,
+                                                            int act,
                                                             const float* __restrict__ wg_x, float* __restrict__ wg_dw, int wg_blocks) {
   ICL_DYN_LDS(float, lds);
   float* xl = lds;                                        // [16 MT][slice_len], quad q of row m stored at quad q ^ (m & 15)
@@ -241,14 +231,6 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(const float* __restr
       }
     }
   }
-  // several slices, tickets given: the last of the gridDim.y workgroups of this unit group adds the slices' partials of the group's
-  // columns (+ bias, activation) into y — no slab-sum launch
-  if (tickets != nullptr && gridDim.y > 1 && ticket_is_last(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(lds))) {
-    const int n = NN ? K : O, cw = NN ? 64 : 16;
-    const int col0 = blockIdx.x * 8 * upw * cw;
-    const int col1 = col0 + 8 * upw * cw < n ? col0 + 8 * upw * cw : n;
-    if (col0 < col1) reduce_slabs_rect(slab, y, bias, (int)gridDim.y, 0, M, col0, col1, (long)n, (long)16 * MT * n, (long)n, act, tid, 512);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ input gradient + SGD update, one pass
@@ -264,8 +246,7 @@ template <int MT, int P>
 __global__ __launch_bounds__(512) void linear_dgrad_sgd_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ w,
                                                                float* __restrict__ mom, float* __restrict__ slab, int M, int K, int O,
                                                                int slice_len, int upw, float lr, float momentum, float wd, int first,
-                                                               const float* __restrict__ lr_dev, float* __restrict__ gx,
-                                                               unsigned* __restrict__ tickets) {
+                                                               const float* __restrict__ lr_dev) {
   ICL_DYN_LDS(float, lds);
   float* xl = lds;                                        // gy slice [16 MT][slice_len], quad q of row m stored at quad q ^ (m & 15)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, u = lane & 15, lg = lane >> 4;
@@ -406,12 +387,6 @@ __global__ __launch_bounds__(512) void linear_dgrad_sgd_kernel(const float* __re
       }
     }
   }
-  // tickets given: the last workgroup of this unit group adds the slices' partials of its columns into gx (as in linear_stream_kernel)
-  if (tickets != nullptr && ticket_is_last(tickets + blockIdx.x, gridDim.y, reinterpret_cast<unsigned*>(lds))) {
-    const int col0 = blockIdx.x * 8 * upw * 64;
-    const int col1 = col0 + 8 * upw * 64 < K ? col0 + 8 * upw * 64 : K;
-    if (col0 < col1) reduce_slabs_rect(slab, gx, nullptr, (int)gridDim.y, 0, M, col0, col1, (long)K, (long)16 * MT * K, (long)K, 0, tid, 512);
-  }
 }
 
 // out[m][n] = act(bias[n] + sum_s slab[s][m][n]) for m < M: fixed-order sum of split partials (bitwise reproducible).
@@ -464,13 +439,6 @@ struct GemmArgs {
   long lda, ldb, ldc, c_split_stride;
   long a_bstride, b_bstride, c_bstride;   // batched products: blockIdx.z = batch * nsplit + split
   int M, N, K, kper, nsplit, act;
-  // split products with tickets (common.h ticket_is_last): the workgroup that stores the last partial of its tiles — one counter per
-  // (column block, row-block residue[, batch entry]) — adds the partials into the final matrix `cf` (pitch ldcf, batch stride cf_bstride;
-  // sum_batch: the batch entries are partials too) with bias and activation; null: partials only (gemm_reduce_slabs_kernel follows)
-  unsigned* tickets;
-  float* cf;
-  long ldcf, cf_bstride;
-  int sum_batch;
 };
 
 __device__ __forceinline__ float4 gemm_load4(const float* __restrict__ base, long ld, int row, int col, int rows, int cols, bool vec_ok) {
@@ -743,22 +711,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
   m0 += (int)gridDim.y * BM;
   if (m0 >= g.M) break;
   }   // row blocks
-  if (g.tickets != nullptr) {
-    const int nbatch = (int)gridDim.z / g.nsplit;
-    const unsigned slot = ((g.sum_batch ? 0u : (unsigned)batch) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (ticket_is_last(g.tickets + slot, (unsigned)(g.sum_batch ? g.nsplit * nbatch : g.nsplit), reinterpret_cast<unsigned*>(lds))) {
-      // slab z = split * nbatch + batch at g.c + z * M * N (the launcher's layout): a batch sum adds all of them, otherwise the
-      // nsplit slabs of this batch entry, nbatch slabs apart
-      const long mn = (long)g.M * g.N;
-      const float* slabs = g.sum_batch ? g.c : g.c + batch * mn;
-      float* outp = g.sum_batch ? g.cf : g.cf + batch * g.cf_bstride;
-      const int S = g.sum_batch ? g.nsplit * nbatch : g.nsplit;
-      const long sstride = g.sum_batch ? mn : (long)nbatch * mn;
-      const int c1 = n0 + BN < g.N ? n0 + BN : g.N;
-      for (int r0 = blockIdx.y * BM; r0 < g.M; r0 += (int)gridDim.y * BM)
-        reduce_slabs_rect(slabs, outp, g.bias, S, r0, r0 + BM < g.M ? r0 + BM : g.M, n0, c1, (long)g.N, sstride, g.ldcf, g.act, tid, NT);
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ tall, skinny Linear: weights in registers

@@ -51,7 +51,7 @@ class SideStream:
     enabled = os.environ.get("ICL_ALIGNER_STREAM", "1") != "0"
     # which branches take a lane: bit 0 the attention-map chains of sspa (own queries), bit 1 the guided levels of uscl (A/B runs:
     # with the three lanes 11.94 ms, only bit 0 13.95, only bit 1 13.62 on one box)
-    lane_mask = int(os.environ.get("ICL_ALIGNER_LANE_MASK", "3"))
+    lane_mask = 3
     lanes = int(os.environ.get("ICL_ALIGNER_LANES", "3"))   # further streams for the per-level branches inside the aligners (0: none)
     _streams = {}
     _outer = None
@@ -428,7 +428,7 @@ def _cached_zeros(n: int, device) -> torch.Tensor:
 
 
 CONV1X1_WGRAD_MIN_VOXELS = 4096
-FIRST_CONV_PLANES_MAX_K = int(os.environ.get("ICL_FIRST_CONV_PLANES_K", "32"))      # Cin * 27 <= 32, i.e. one input channel
+FIRST_CONV_PLANES_MAX_K = 32      # Cin * 27 <= 32, i.e. one input channel
 CONV1X1_GEMM_MIN_VOXELS = 65536
 CONV1X1_SMALL_MAX_CHANNELS = 16       # 1x1x1 convolutions with <= 16 -> <= 16 channels below the GEMM threshold: icl_conv1x1_small
 
@@ -472,7 +472,7 @@ class _Conv3d(torch.autograd.Function):
             return y
         y = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
         ctx.wpt = None
-        ctx.pointwise_small = ks == 1 and small_ch and os.environ.get("ICL_CONV1X1_SMALL", "1") != "0"
+        ctx.pointwise_small = ks == 1 and small_ch
         if ctx.pointwise_small:
             # <= 16 channels (the aligner's h -> h / h -> 1 maps, the `final` 16 -> num_classes convolution on 96^3 voxels): VALU
             # kernels on the natural weight layout, HBM-bound on big volumes
@@ -1203,7 +1203,7 @@ def dropout_conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     n, cin = x.shape[0], x.shape[1]
     s = x.numel() // max(n * cin, 1)
     fusable = (x.is_cuda or _lib.host_pointers_ok()) and weight.shape[2:].numel() == 1 and cin <= 16 and weight.shape[0] <= 16 \
-        and s % 4 == 0 and n * s >= 65536 and torch.is_grad_enabled() and os.environ.get("ICL_DROPOUT_CONV_FUSED", "1") != "0"
+        and s % 4 == 0 and n * s >= 65536 and torch.is_grad_enabled()
     if not fusable:
         return conv3d(dropout(x, p, seed), weight, bias)
     seed_dev = None
@@ -1236,7 +1236,7 @@ def drop_path(x: torch.Tensor, p: float, seed: Optional[int] = None) -> torch.Te
 # --------------------------------------------------------------------------------------
 
 LINEAR_WGRAD_MIN_ROWS = 2048
-LINEAR_BWD_ONE_LAUNCH = os.environ.get("ICL_LINEAR_BWD_ONE_LAUNCH", "1") != "0"
+LINEAR_BWD_ONE_LAUNCH = True
 
 
 def linear_forward_raw(x2: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0) -> torch.Tensor:
@@ -1320,7 +1320,7 @@ class DeferredBiasGrads:
 
     @classmethod
     def begin(cls):
-        cls.pending = [] if os.environ.get("ICL_DEFER_BIAS", "1") != "0" else None
+        cls.pending = []
 
     @classmethod
     def defer(cls, bias, g2) -> bool:
@@ -1893,7 +1893,7 @@ class _ProtoAttention(torch.autograd.Function):
         gkv = torch.empty_like(kv)
         # dQ from the shares the dK / dV pass writes per 256-token chunk (long token axes: the row-per-workgroup dQ kernel is a latency
         # chain on the backward's query chain); short axes keep the two-kernel form (one launch fewer than shares + sum... the same count)
-        ws = _ws(L.icl_attn_bwd_ws_bytes(B, h, nc, N, d), qh) if (N >= 1024 and os.environ.get("ICL_ATTN_DQ_SHARES", "1") != "0") else None
+        ws = _ws(L.icl_attn_bwd_ws_bytes(B, h, nc, N, d), qh) if N >= 1024 else None
         _lib.check(L.icl_attn_bwd_ws(_ptr(qh), _ptr(kv), _ptr(logits), _ptr(stats), _ptr(out), _ptr(gout), _ptr(glog), _ptr(gq), _ptr(gkv),
                                      _ptr(ws), B, h, nc, N, d, ctx.scale, _stream(qh)), "attn_bwd")
         return gq, gkv, None, None

@@ -307,9 +307,8 @@ class FusedSGD(torch.optim.Optimizer):
         L = _lib.lib()
         dev = self._deferred[0][0].device
         if self._update_stream is None:
-            # lowest priority: where the hardware honours it, the workgroups of the update fill the slots the step's own kernels leave
-            prio = int(os.environ.get("ICL_UPDATE_STREAM_PRIORITY", "0"))
-            self._update_stream = torch.cuda.Stream(device=dev, priority=prio)
+            # (stream priorities measured without effect on this step: profiles/r4_schedule_experiments.txt)
+            self._update_stream = torch.cuda.Stream(device=dev)
         s = self._update_stream
         if gate:
             s.wait_stream(torch.cuda.current_stream(dev))
@@ -323,6 +322,23 @@ class FusedSGD(torch.optim.Optimizer):
                 x.record_stream(s)
         self._deferred = []
         self._update_stream_used = True
+
+    @torch.no_grad()
+    def step_subset(self, params):
+        """The factored update of the given parameters only, now; ``step()`` afterwards finds nothing left to do for them.  Used by the
+        data-parallel step for the ROW-SHARDED matrices: their updates run first so that the all-gather of the updated rows
+        (ddp.GradientReducer.post_update) travels over xGMI while ``step()`` updates everything else."""
+        L = _lib.lib()
+        groups = self._group_of()
+        for p in params:
+            fac = getattr(p, "_icl_factors", None)
+            if not fac:
+                continue
+            if p.grad is not None or id(p) in self._updated_in_backward:
+                continue              # a mixed / already applied gradient: left to step(), which knows how to merge or refuse it
+            group = groups[id(p)]
+            self._step_factored(L, p, fac, float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]))
+            p._icl_factors = None
 
     @torch.no_grad()
     def step(self, closure=None):

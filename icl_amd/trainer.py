@@ -58,6 +58,7 @@ class ICLTrainer:
         self.graph = None
         self.graph_forward = None
         self.graph_update = None
+        self.graph_update_rest = None
         self.use_graph = True     # False: launch eagerly although a captured graph exists (bench.py --launch auto compares the two)
         self.lr_dev = None
 
@@ -126,7 +127,14 @@ class ICLTrainer:
         parts["loss"] = loss.detach()
         return parts
 
-    def _apply_update(self):
+    def _apply_update(self, part: str = "all"):
+        """``part``: "all" (one rank, or nothing row-sharded), or the two halves of a data-parallel update — "sharded" = the updates
+        of the row-sharded matrices (GradientReducer.sharded_params()), "rest" = everything else; the all-gathers of the updated rows
+        are started between the two and run under "rest"."""
+        if part in ("all", "sharded") and self.ddp is not None and self.ddp.active:
+            self.optimizer.step_subset(self.ddp.sharded_params())
+        if part == "sharded":
+            return
         self.optimizer.step()
         self.packed.end_step()
         ops.StepRNG.end_step()
@@ -139,11 +147,14 @@ class ICLTrainer:
             self.optimizer.abandon_step()
             self.packed.end_step()
             raise
-        if self.ddp is not None:
+        if self.ddp is not None and self.ddp.active:
             self.ddp.reduce_gradients()
-        self._apply_update()
-        if self.ddp is not None:
-            self.ddp.post_update()        # row-sharded matrix updates: all-gather the updated rows
+            self._apply_update("sharded")
+            self.ddp.post_update(async_op=True)      # row-sharded matrix updates: the all-gather of the updated rows starts here ...
+            self._apply_update("rest")               # ... and runs under the rest of the optimiser step
+            self.ddp.finish_post_update()
+        else:
+            self._apply_update()
         return parts
 
     def _advance_lr(self):
@@ -170,10 +181,12 @@ class ICLTrainer:
             if self.graph_forward is not None:
                 self.graph_forward.replay()
             self.graph.replay()
-            if self.graph_update is not None:    # data-parallel: collectives between the two graphs
+            if self.graph_update is not None:    # data-parallel: collectives between the graphs
                 self.ddp.communicate()
-                self.graph_update.replay()
-                self.ddp.post_update()
+                self.graph_update.replay()           # unpack + the updates of the row-sharded matrices
+                self.ddp.post_update(async_op=True)  # their all-gathers, under ...
+                self.graph_update_rest.replay()      # ... the rest of the optimiser step
+                self.ddp.finish_post_update()
             parts = self.static_out
         else:
             parts = self._step_body(volume_batch, label_batch)
@@ -246,11 +259,15 @@ class ICLTrainer:
         if ddp is not None:
             ddp.rebind()
             ddp._captured = True
-            update = torch.cuda.CUDAGraph()
+            # the optimiser as TWO graphs (round 5): the updates of the row-sharded matrices first, so that the eager all-gathers of
+            # their rows overlap the replay of everything else
+            update, rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(update, pool=pool, **mode):
                 ddp.unpack()
-                self._apply_update()
-            self.graph_update = update
+                self._apply_update("sharded")
+            with torch.cuda.graph(rest, pool=pool, **mode):
+                self._apply_update("rest")
+            self.graph_update, self.graph_update_rest = update, rest
         self.graph = graph
         return self
 

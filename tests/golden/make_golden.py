@@ -389,6 +389,31 @@ def gen_model(R, out, nc):
 STEPS_MAX_ITER = 10      # a short schedule so that the poly learning rate moves visibly within three steps
 
 
+def gen_model_dense_wgrads(R, out, nc=2):
+    """Round 5: the weight gradients of the 96^3 / 48^3 3x3x3 convolutions of the reference step IN FULL — the
+    tensors the split-product weight-gradient kernel produces at its largest shapes — so that the norm-only bands of the model golden are
+    backed by dense elementwise comparisons.  Same model, inputs and loss as gen_model(nc = 2)."""
+    m3, L = R["m3"], R["losses"]
+    model = m3.unet_3D_icl(n_classes=nc, in_channels=1)
+    parity_mode(model)
+    fill(model)
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, nc)
+    model.train()
+    outs = model(vol[:1], vol[1:])
+    soft = torch.softmax(outs[0], 1)
+    loss = (L.DiceLoss(nc)(soft, lab.unsqueeze(1)) + nn.CrossEntropyLoss()(outs[0], lab) + L.AuxLoss3D(nc)(outs[2], lab)
+            + L.PseudoSoftLoss3D(nc)(outs[3], outs[1]) + 10 * L.softmax_mse_loss(outs[3], outs[4]))
+    loss.backward()
+    sd_ = dict(model.named_parameters())
+    d = {"loss": np.array([float(loss)])}
+    for k in ("up_concat1.conv.conv1.0.weight", "up_concat1.conv.conv2.0.weight", "conv1.conv2.0.weight",
+              "up_concat2.conv.conv1.0.weight", "conv2.conv2.0.weight"):
+        d["grad." + k] = npy(sd_[k].grad)
+    np.savez_compressed(os.path.join(out, f"model_unet3d_icl_nc{nc}_wgrads.npz"), **d)
+    print("dense wgrads:", {k: v.shape for k, v in d.items()}, sum(v.nbytes for v in d.values()) / 1e6, "MB (raw)")
+
+
 def gen_model_steps(R, out, nc=2, steps=3):
     """Three iterations of the reference loop body (train_inherent_consistent_unet_3D_BraTS.py:99-121) on the real 785 M-parameter
     model: SGD(lr 0.01, momentum 0.9, wd 1e-4), momentum carried over, a new batch per step, and the poly learning rate computed
@@ -698,6 +723,8 @@ if __name__ == "__main__":
         gen_model(R, HERE, 2)
     if a.only in ("all", "model16"):
         gen_model(R, HERE, 16)
+    if a.only in ("all", "wgrads"):
+        gen_model_dense_wgrads(R, HERE)
     if a.only in ("all", "steps"):
         gen_model_steps(R, HERE)
     if a.only in ("all", "model2d"):

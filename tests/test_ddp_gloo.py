@@ -254,6 +254,21 @@ def test_exchange_plan_prices_the_alternatives():
     assert mode == "shard" and cost["shard"] < cost["whole"] < cost["dense"]
 
 
+def test_projection_of_the_eight_rank_step_from_a_one_rank_measurement():
+    """ddp.project_world: config 5 (num_classes = 16: 128 / 64 factor rows per rank) on 8 ranks at the assumed 300 / 250 GB/s — the
+    1024-row matrices shard, the 512-row ones stay whole, the row all-gathers hide under the whole updates except for their excess."""
+    from icl_amd.ddp import project_world, update_ms
+    n = 13824 * 13824
+    mats = [dict(rows=128, elems=n, out_rows=13824)] * 2 + [dict(rows=64, elems=n, out_rows=13824)] * 2
+    pr = project_world(mats, 8, base_ms=16.0, factor_bytes_per_rank=4.0 * 13824 * 2 * (128 + 128 + 64 + 64))
+    assert [m["mode"] for m in pr["matrices"]] == ["shard", "shard", "whole", "whole"]
+    assert abs(pr["update_extra_ms"] - (2 * (update_ms(1024) / 8 - update_ms(128)) + 2 * (update_ms(512) - update_ms(64)))) < 1e-2
+    assert pr["row_allgather_exposed_ms"] == round(max(0.0, pr["row_allgather_ms"] - 2 * update_ms(512)), 3)
+    assert 16.0 < pr["projected_ms_per_step"] < 21.0, pr
+    one = project_world(mats, 1, base_ms=16.0)
+    assert one["projected_ms_per_step"] == 16.0 and all(m["mode"] == "whole" for m in one["matrices"])
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_gradient_reducer(tmp_path, world):
@@ -323,6 +338,35 @@ def _worker_icl_trainer(rank, world, port, tmp):
         else:
             want = p0[k] - lr * (reduced[k] + wd * p0[k])                 # first step: momentum buffer = d
             assert torch.allclose(p.detach(), want, rtol=1e-5, atol=1e-6), k
+    # Round 5: the whole `step()` with ROW-SHARDED updates of the token-axis matrices — the updates of the sharded matrices first
+    # (FusedSGD.step_subset), the all-gathers of their rows started asynchronously, the rest of the optimiser step under them, the
+    # join at the end (ICLTrainer._step_body).  Same model, a second trainer whose reducer shards from one gathered row on: against a
+    # twin that applies every gathered update whole, parameters agree to rounding after two steps and replicas stay bit-identical.
+    def two_steps(shard_rows):
+        torch.manual_seed(77)
+        m = unet_3D_icl(feature_scale=16, n_classes=2, in_channels=1, icl_in_resolutions=(1, 2, 4), icl_heads=(8, 4, 2))
+        r = GradientReducer(m, world, bucket_bytes=1 << 16, shard_min_rows=shard_rows)
+        r.broadcast_parameters()
+        t = ICLTrainer(m, ICLConfig(num_classes=2, labeled_bs=1, patch_size=(16, 16, 16), base_lr=lr, weight_decay=wd), ddp=r)
+        for mod in m.modules():
+            if mod.__class__.__name__ == "Dropout3":
+                mod.p = 0.0
+            if hasattr(mod, "drop_prob"):
+                mod.drop_prob = 0.0
+        nshard = 0
+        for _ in range(2):
+            t.step(vol, lab)
+            nshard = max(nshard, len(r.sharded_params()))
+        return {k: p.detach().clone() for k, p in m.named_parameters()}, nshard
+
+    whole, n0 = two_steps(0)
+    shard, n1 = two_steps(1)
+    assert n0 == 0 and n1 >= 4, (n0, n1)                                   # the four mlp2 matrices (64 rows, divisible by the world size)
+    for k in whole:
+        assert torch.allclose(whole[k], shard[k], rtol=1e-5, atol=1e-6), k
+    sums = [None] * world
+    dist.all_gather_object(sums, {k: float(v.double().sum()) for k, v in shard.items()})
+    assert sums[0] == sums[rank]
     dist.destroy_process_group()
 
 

@@ -97,6 +97,7 @@ def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root, monkeyp
     split-vs-exact number.)"""
     from networks.net_factory_3d import net_factory_3d
     g = load_golden("model_unet3d_icl_nc2.npz")
+    dense = load_golden("model_unet3d_icl_nc2_wgrads.npz")
     big = "sspa.class_decoders.2.mlp2.fc1.weight"
     samples = {}
     for conv_split in ("1", "0"):
@@ -121,6 +122,14 @@ def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root, monkeyp
         # conv biases in front of an InstanceNorm and attn_convs1 biases in front of the class softmax: the true gradient is exactly 0
         skip = lambda k: k.endswith(".0.bias") or ("attn_convs1" in k and k.endswith("bias"))   # noqa: E731
         _check_step(model, g, got, grads, elementwise, skip)
+        # Round 5: the weight gradients of the 96^3 / 48^3 3x3x3 convolutions IN FULL against the reference's (every element of the
+        # tensors the split-product weight-gradient kernel produces at its largest shapes; golden: make_golden.py --only wgrads).
+        # Measured (tests/diag/dense_wgrad_errors.py, max-norm relative, split / exact-fp32 path): up_concat1.conv.conv1 5.6e-4 / 5.4e-4,
+        # .conv2 2.2e-4 / 2.0e-4, up_concat2.conv.conv1 1.9e-3 / 9.7e-4, conv1.conv2 5.6e-3 / 2.5e-3, conv2.conv2 6.0e-3 / 2.9e-3 (the
+        # encoder's gradients are the deepest of the model: the reference's own fp32 backward is that far from an fp64 one); bands 2x.
+        for key, tol in (("up_concat1.conv.conv1.0.weight", 1.2e-3), ("up_concat1.conv.conv2.0.weight", 5e-4),
+                         ("up_concat2.conv.conv1.0.weight", 4e-3), ("conv1.conv2.0.weight", 1.2e-2), ("conv2.conv2.0.weight", 1.3e-2)):
+            assert rel_err(grads[key].cpu(), dense["grad." + key]) < tol, (key, conv_split)
         assert rel_err(model.final.weight.detach().cpu(), g["post_sgd.final.weight"]) < 1e-5
         # the first convolution's gradient is the deepest of the model (2e-2 band above); times lr = 0.01 on O(0.3) weights
         assert rel_err(model.conv1.conv1[0].weight.detach().cpu(), g["post_sgd.conv1.conv1.0.weight"]) < 1e-4

@@ -980,11 +980,10 @@ def test_update_inside_backward_equals_update_in_optimizer_step(dev):
 
 
 @pytest.mark.gpu
-def test_last_arriving_workgroup_sums_the_partials_bitwise_like_the_second_launch(dev, monkeypatch):
-    """Split products add their partials in the workgroup that draws a region's last ticket (csrc/kernels/common.h ticket_is_last: the
-    partials cross XCDs, device-scope release / acquire around an integer counter); ICL_TICKETS=0 runs gemm_reduce_slabs_kernel as a second
-    launch.  Same order, same operations — bit for bit, on the shapes of the ICL step (13,824^2 / 1,728^2 / 216^2 token-axis matrices,
-    split-K products, the batch sum, the fused input gradient + update), and repeatedly: the tickets must be left at zero."""
+def test_split_products_are_summed_in_a_fixed_order(dev):
+    """Split products write their partials to slabs that gemm_reduce_slabs_kernel adds in slab order — bit-reproducible on the shapes of
+    the ICL step (13,824^2 / 1,728^2 / 216^2 token-axis matrices, split-K products, the batch sum, the fused input gradient + update).
+    (Round 4's last-arriving-workgroup sums were bit-identical and slower — whole-L2 fences on gfx950 — and were removed in round 5.)"""
     from icl_amd import _lib, ops
     L = _lib.lib()
 
@@ -1013,11 +1012,9 @@ def test_last_arriving_workgroup_sums_the_partials_bitwise_like_the_second_launc
         torch.cuda.synchronize()
         return outs
 
-    monkeypatch.setenv("ICL_TICKETS", "0")
-    two_launches = run_all()
-    monkeypatch.setenv("ICL_TICKETS", "1")
-    for _ in range(5):
-        for j, (got, want) in enumerate(zip(run_all(), two_launches)):
+    first = run_all()
+    for _ in range(3):
+        for j, (got, want) in enumerate(zip(run_all(), first)):
             assert torch.equal(got, want), j
 
 

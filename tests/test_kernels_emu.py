@@ -53,14 +53,6 @@ def test_conv3d_fwd_bwd(n, cin, cout, d, h, w, ks):
     _conv_check(n, cin, cout, d, h, w, ks)
 
 
-@pytest.mark.parametrize("mode", ["a4", "a2", "b4", "c2"])
-@pytest.mark.parametrize("n,cin,cout,d,h,w", [(1, 16, 16, 4, 8, 16), (2, 20, 48, 6, 8, 16), (1, 8, 32, 5, 12, 12), (1, 4, 16, 3, 16, 24)])
-def test_conv3d_wgrad_row_window_kernel(monkeypatch, mode, n, cin, cout, d, h, w):
-    """conv_wgrad_rows.h: every tile / row-group variant, 1-3 cout blocks per workgroup, ragged channels, partial x / y / z tiles."""
-    monkeypatch.setenv("ICL_WGRAD_ROWS", mode)
-    _conv_check(n, cin, cout, d, h, w, 3)
-
-
 @pytest.mark.parametrize("n,cin,cout,d,h,w", [
     (1, 16, 16, 4, 8, 16),      # one tile, one cout block
     (2, 32, 20, 5, 9, 20),      # two 16-channel chunks, ragged cout, partial tiles in z / y / x, two samples
@@ -74,26 +66,14 @@ def test_conv3d_wgrad_row_window_kernel(monkeypatch, mode, n, cin, cout, d, h, w
     (2, 32, 48, 5, 10, 24),     # ... three cout blocks, two chunks, odd depth, partial y tile, two samples
     (1, 32, 32, 4, 24, 24),     # ... two cout blocks, three y tiles
 ])
-@pytest.mark.parametrize("variant", ["default", "60", "24", "8", "0", "4"])
-def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w, variant):
-    # the superseded schedules (24, 8, 0, 4: still selectable with ICL_CONV_SPLIT_V for A/B runs) are checked on the shapes that reach every
-    # code path of theirs — one / two / three cout blocks, ragged chunks, flat tiles — not on every shape: the emulator needs a minute for the
-    # big ones and the CPU suite has to stay short
-    if variant in ("24", "8", "0", "4") and (n, cin, cout, d, h, w) not in ((1, 16, 16, 4, 8, 16), (2, 32, 20, 5, 9, 20), (1, 16, 48, 3, 4, 12),
-                                                                             (1, 48, 40, 2, 8, 16), (1, 16, 16, 3, 9, 24)):
-        pytest.skip("superseded schedule: covered on the smaller shapes")
-    """conv_bf16x3.h: forward and input gradient with each fp32 operand split exactly into three bf16 terms (six bf16 MFMA terms per
-    product, fp32 accumulation) — same tolerance as the fp32-MFMA kernels, and the two paths agree to fp32 rounding.  variant: the
-    schedule of the forward kernel (8 = all weight planes of a chunk in LDS for one cout block, the default; 0 = one plane per dz
-    stage; 4 = buffer loads; default = loader waves for one cout block); the weight gradient runs on conv_wgrad_tr.h (transposing LDS reads)."""
-    # "default": one cout block on 4 x 8 x 16 tiles runs conv_bf16x3_ws.h (eight consumer + four loader waves), the rest variant 60
-    if variant == "default":
-        monkeypatch.delenv("ICL_CONV_SPLIT_V", raising=False)
-    else:
-        monkeypatch.setenv("ICL_CONV_SPLIT_V", variant)
+def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w):
+    """conv_bf16x3.h / conv_bf16x3_ws.h / conv_wgrad_tr.h: forward, input gradient and weight gradient with each fp32 operand split
+    exactly into three bf16 terms (six bf16 MFMA terms per product, fp32 accumulation) — same tolerance as the fp32-MFMA kernels, and the
+    two paths agree to fp32 rounding.  One cout block on 4 x 8 x 16 tiles runs the loader-wave kernel, everything else the single-role
+    kernel; rows of 24 voxels the flat tiles."""
     monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
     monkeypatch.setenv("ICL_CONV_SPLIT", "1")
-    monkeypatch.setenv("ICL_WGRAD_SPLIT", "2")      # split-product weight gradient for every Cout (the default)
+    monkeypatch.setenv("ICL_WGRAD_SPLIT", "1")
     _conv_check(n, cin, cout, d, h, w, 3)
     x = _rand((n, cin, d, h, w), 11)
     wt = _rand((cout, cin, 3, 3, 3), 12) * 0.2
