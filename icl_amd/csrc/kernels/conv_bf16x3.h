@@ -35,6 +35,7 @@ struct Bf3Geom {
   long x_bstride, y_bstride;
   float* stats;               // != nullptr: InstanceNorm statistics of the output, produced in the epilogue (bf3_stats_* below)
   int nbatch;                 // samples (the statistics of a workgroup are written for every sample: zeros for the ones it never sees)
+  int wgs;                    // workgroups along x = statistics slots per (sample, channel): computed ONCE by the launcher (grid.x)
   int flags;                  // bit 1: non-temporal output stores (round 4, batch 2: 16->48 @96^3 348 vs 368 us, 32->32 @48^3 67.7 vs
                               // 69.7, 16->16 @96^3 137 vs 139: the launcher sets it for three cout blocks).  (Bit 0 was a y-slowest
                               // tile order inside an XCD's share of the tile list, so that z- and x-neighbours run at the same time
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
     chunk = nchunk;
   }
   if (g.stats)
-    bf3_stats_flush<NBT, TC::NW>(run, reinterpret_cast<float*>(Ws + WPL * TC::ws_u4(NB)), g.stats, my_sample, g.nbatch, g.Cout, n0, (int)gridDim.x,
+    bf3_stats_flush<NBT, TC::NW>(run, reinterpret_cast<float*>(Ws + WPL * TC::ws_u4(NB)), g.stats, my_sample, g.nbatch, g.Cout, n0, g.wgs,
                                  (int)blockIdx.x, wid, lane, tid);
 }
 

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(768) void conv3d_bf16x3_fwd_ws_kernel(const float* 
   }
   // (the loader waves have returned: the barrier inside counts the eight consumer waves)
   if (g.stats)
-    bf3_stats_flush<NBT, 8>(run, reinterpret_cast<float*>(Ws + WPL * TC::ws_u4(NB)), g.stats, my_sample, g.nbatch, g.Cout, n0, (int)gridDim.x,
+    bf3_stats_flush<NBT, 8>(run, reinterpret_cast<float*>(Ws + WPL * TC::ws_u4(NB)), g.stats, my_sample, g.nbatch, g.Cout, n0, g.wgs,
                             (int)blockIdx.x, wid, lane, tid);
 }
 

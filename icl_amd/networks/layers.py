@@ -58,7 +58,17 @@ class ConvBlock(nn.Sequential):
         super().__init__(Conv3d(cin, cout, 3, device=device, kaiming_normal=True, feeds_instance_norm=True),
                          InstanceNormReLU(), _Identity())
 
+    def _stock(self) -> bool:
+        """The fused operator stands for exactly these three children with nothing attached: a child swapped through the
+        reference-compatible Sequential indices, or a forward hook on one of them, must keep working."""
+        c, n, a = self[0], self[1], self[2]
+        return (type(c) is Conv3d and type(n) is InstanceNormReLU and type(a) is _Identity and c.groups == 1 and c.ks == 3
+                and c.feeds_instance_norm and not (c._forward_hooks or c._forward_pre_hooks or n._forward_hooks or n._forward_pre_hooks
+                                                   or a._forward_hooks or a._forward_pre_hooks))
+
     def forward(self, x):
+        if not self._stock():
+            return super().forward(x)
         # the three children as ONE operator: the convolution's epilogue hands the normalisation its statistics (ops.py)
         return ops.conv3d_instance_norm_act(x, self[0].weight, self[0].bias, act=1)
 

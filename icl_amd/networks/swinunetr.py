@@ -328,6 +328,12 @@ class UnetResBlock(nn.Module):
             self.conv3 = _ConvOnly(cin, cout, 1, device=device)
 
     def forward(self, x):
+        hooked = any(m._forward_hooks or m._forward_pre_hooks for m in (self.conv1, self.conv2, self.conv1.conv, self.conv2.conv))
+        if hooked or type(self.conv1) is not _ConvOnly or type(self.conv2) is not _ConvOnly:
+            # children with hooks or swapped children: the unfused composition, module by module
+            out = ops.instance_norm_act(self.conv1(x), act=2)
+            res = ops.instance_norm_act(self.conv3(x), act=0) if self.downsample else x
+            return ops.instance_norm_add_act(self.conv2(out), res, act=2)
         # conv -> InstanceNorm -> act as one operator each: the convolution's epilogue hands the normalisation its statistics (ops.py)
         out = ops.conv3d_instance_norm_act(x, self.conv1.conv.weight, None, act=2)
         res = ops.instance_norm_act(self.conv3(x), act=0) if self.downsample else x

@@ -822,3 +822,23 @@ def test_fused_sgd_step_scope_equals_the_plain_loop_with_torch_sgd():
         assert not bad, bad[:8]
     finally:
         ops.FactoredGrads.min_elems = old_min
+
+
+def test_conv_block_falls_back_to_its_children_when_they_are_hooked_or_swapped():
+    """ConvBlock.forward runs its three children as one fused operator only while they are the stock modules with no
+    forward hooks; a hook on a child fires (and sees the child's output), a swapped child is honoured — results equal the fused path."""
+    from icl_amd.networks.layers import ConvBlock
+    torch.manual_seed(3)
+    blk = ConvBlock(4, 8)
+    x = _rand((1, 4, 4, 8, 16), 5)
+    with torch.no_grad():
+        fused = blk(x)
+        seen = []
+        h = blk[1].register_forward_hook(lambda m, i, o: seen.append(o.shape))
+        hooked = blk(x)
+        h.remove()
+        assert seen == [fused.shape] and torch.allclose(hooked, fused, rtol=1e-5, atol=1e-6)
+        assert blk._stock()
+        blk[2] = torch.nn.Hardtanh(0.0, 0.5)          # swapped through the reference-compatible index
+        assert not blk._stock()
+        assert torch.allclose(blk(x), fused.clamp(0.0, 0.5), rtol=1e-5, atol=1e-6)

@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
   const int gx = g.ntiles < 256 ? (g.ntiles + 7) / 8 * 8 : 256;
   CK(hipMalloc(&dstats, (size_t)N * cout * gx * 3 * 4)); CK(hipMalloc(&dssout, (size_t)N * cout * 2 * 4));
   float* dstats0; CK(hipMalloc(&dstats0, (size_t)N * cout * gx * 3 * 4));
-  g.stats = dstats0; g.nbatch = N;      // both kernels produce the InstanceNorm statistics of their output
+  g.stats = dstats0; g.nbatch = N; g.wgs = gx;      // both kernels produce the InstanceNorm statistics of their output
   icl::ClGeom c{};
   c.src[0] = icl::ClSrc{ds0, (long)c0 * S, norm ? dss0 : nullptr, c0 / 16};
   c.src[1] = icl::ClSrc{ds1, (long)c1 * S, norm ? dss1 : nullptr, c1 / 16};

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
   g.nchunks = cin / 16; g.x_bstride = cin * S; g.y_bstride = cout * S;
   const int gx = g.ntiles < 256 ? (g.ntiles + 7) / 8 * 8 : 256;
   CK(hipMalloc(&dst, (size_t)N * cout * gx * 3 * 4));
-  g.stats = dst; g.nbatch = N;
+  g.stats = dst; g.nbatch = N; g.wgs = gx;
   const size_t lds = icl::Bf3T<8>::lds_bytes(1, 3);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_bf16x3_fwd_ws_kernel<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&icl::conv3d_bf16x3_fwd_ws_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
