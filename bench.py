@@ -95,7 +95,7 @@ def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
 HBM_TRAFFIC_FILE = "profiles/r4_hbm_traffic.json"
 
 
-def reference_loop_bench(nc: int, steps: int, warmup: int, dev, fused: bool):
+def reference_loop_bench(nc: int, steps: int, warmup: int, dev, fused: bool, graph: bool = False):
     """The loop body of the UNCHANGED reference trainer (/root/reference/code/train_inherent_consistent_unet_3D_BraTS.py:63-64,85-90,
     103-133) — its statements, its names — through the `compat/` import root (`networks.net_factory_3d`, `utils.losses`), eager, with the
     six `.item()` reads of its logging line; on the same HBM-resident synthetic batch as the headline.  ``fused``: the one-line optimiser
@@ -114,7 +114,7 @@ def reference_loop_bench(nc: int, steps: int, warmup: int, dev, fused: bool):
         model.train()
         if fused:
             from icl_amd.optim import FusedSGD
-            optimizer = FusedSGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001)
+            optimizer = FusedSGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001, graph=graph)
         else:
             optimizer = optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001)
         ce_loss = CrossEntropyLoss()
@@ -145,7 +145,7 @@ def reference_loop_bench(nc: int, steps: int, warmup: int, dev, fused: bool):
             iter_num = iter_num + 1
             logged = (iter_num, loss.item(), loss_ce.item(), loss_dice.item(), loss_aux.item(), loss_pse.item(), 10 * loss_aux_consis.item())
 
-        for _ in range(max(warmup, 2)):
+        for _ in range(max(warmup, 2) + (4 if graph else 0)):      # graph=True: three eager iterations, the capture, one replay
             iteration()
         torch.cuda.synchronize()
         t = time.perf_counter()
@@ -155,7 +155,11 @@ def reference_loop_bench(nc: int, steps: int, warmup: int, dev, fused: bool):
         dt = (time.perf_counter() - t) / steps
         dense = sum(p.grad.numel() for p in model.parameters() if p.grad is not None)
         out = {"ms_per_step": round(dt * 1e3, 3), "value": round(2.0 / dt, 3), "unit": "volumes/s",
-               "optimizer": "icl_amd.optim.FusedSGD (one-line swap; step scope opened from the model's forward hook)" if fused else "torch.optim.SGD",
+               "optimizer": ("icl_amd.optim.FusedSGD(..., graph=True) (one-line swap; forward and backward of the model replayed as hipGraphs, "
+                             "losses / zero_grad / step / .item() of the loop eager)" if fused and graph else
+                             "icl_amd.optim.FusedSGD (one-line swap; step scope opened from the model's forward hook)" if fused else "torch.optim.SGD"),
+               **({"graphed": bool(getattr(optimizer, "_graph_state", None) is not None), "capture_error": getattr(optimizer, "_graph_failed", None)}
+                  if fused and graph else {}),
                "dense_gradient_elements": int(dense), "last_logged_loss": round(float(logged[1]), 6)}
         del model, optimizer
         torch.cuda.empty_cache()
@@ -446,6 +450,7 @@ def main():
                               "six .item() reads per iteration), same HBM-resident synthetic batch",
                     "torch_optim_sgd": reference_loop_bench(nc, args.steps, args.warmup, dev, fused=False),
                     "fused_sgd_one_line_swap": reference_loop_bench(nc, args.steps, args.warmup, dev, fused=True),
+                    "fused_sgd_one_line_swap_graphed": reference_loop_bench(nc, args.steps, args.warmup, dev, fused=True, graph=True),
                     "icl_trainer_eager_ms_per_step": round(eager_ms, 3)}
 
     exact = None

@@ -41,7 +41,8 @@ class FusedSGD(torch.optim.Optimizer):
     followed by ``optimizer.step()`` (the big matrices are updated inside their backward pass); pass ``update_in_backward=False`` for
     loops that accumulate gradients over several backward passes, ``step_scope=False`` to get a plain fused optimiser."""
 
-    def __init__(self, params, lr=0.01, momentum=0.9, weight_decay=0.0, step_scope: bool = True, update_in_backward: bool = True):
+    def __init__(self, params, lr=0.01, momentum=0.9, weight_decay=0.0, step_scope: bool = True, update_in_backward: bool = True,
+                 graph: bool = False, graph_warmup: int = 3):
         if momentum <= 0:
             raise ValueError("FusedSGD implements the momentum form used by the ICL trainers")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
@@ -50,6 +51,16 @@ class FusedSGD(torch.optim.Optimizer):
         self._scope_update_in_backward = bool(update_in_backward)
         self._scope_packed = None
         self._scope_hook = None
+        # graph=True (round 5, needs the step scope): after `graph_warmup` eager training iterations the model's forward and backward
+        # are captured into two hipGraphs (the step scope's bookkeeping inside them) and every later `model(x_lab, x_unlab)` /
+        # `loss.backward()` of the UNCHANGED loop replays them; the losses, `optimizer.zero_grad()`, `optimizer.step()` and the
+        # `.item()` reads of the loop stay eager.  See _GraphedStep.
+        self._graph_on = bool(graph) and bool(step_scope)
+        self._graph_warmup = max(int(graph_warmup), 1)
+        self._graph_state = None
+        self._graph_failed = None
+        self._train_calls = 0
+        self._cap_stream = None      # the stream of every training forward before AND during the capture (see _install_graphed_forward)
         if step_scope:
             models = {id(m): m for m in (getattr(p, "_icl_model", lambda: None)() for g in self.param_groups for p in g["params"])
                       if m is not None}
@@ -63,6 +74,8 @@ class FusedSGD(torch.optim.Optimizer):
                     if opt is not None:
                         opt._open_scope(module)
                 self._scope_hook = model.register_forward_pre_hook(pre_forward)
+                if self._graph_on:
+                    _install_graphed_forward(self, model)
         self.lr_dev = None   # optional device scalar read by the kernels instead of group['lr'] (hipGraph replay)
         self._groups = None  # id(parameter) -> its group (update_in_backward)
         self._updated_in_backward = set()   # ids of the parameters whose update of this step already ran inside backward
@@ -113,11 +126,13 @@ class FusedSGD(torch.optim.Optimizer):
             self._close_scope(flush=False)
 
     # ---- step scope (see the class docstring)
-    def _open_scope(self, module):
+    def _open_scope(self, module, capturing: bool = False):
         from . import ops
         from .networks.layers import BatchNormAct
         if not module.training or not torch.is_grad_enabled():
             return
+        if self._graph_state is not None and not capturing:
+            return                       # the captured graphs carry the scope's work; nothing runs eagerly
         if self._scope_open:
             self.abandon_step()          # a forward pass whose backward / step never came
         if ops.PackedWeights.current is not None or ops.FactoredGrads.uses is not None:
@@ -409,3 +424,183 @@ class FusedSGD(torch.optim.Optimizer):
                 _lib.check(L.icl_sgd_step_multi(P_, G_, M_, N_, n, lr, mom, wd, first, lrp, stream), "sgd_step_multi")
         self._updated_in_backward.clear()
         return loss
+
+
+# ------------------------------------------------------------------------------------------------ graphed forward / backward of the unchanged loop
+def _flatten_outputs(out):
+    """(tensors, rebuild): the tensors of a nested tuple / list output in order, and a function that rebuilds the structure."""
+    flat = []
+
+    def walk(o):
+        if isinstance(o, torch.Tensor):
+            flat.append(o)
+            return ("t", len(flat) - 1)
+        if isinstance(o, (list, tuple)):
+            return ("l" if isinstance(o, list) else "u", [walk(v) for v in o])
+        return ("c", o)
+
+    spec = walk(out)
+
+    def rebuild(ts, node=spec):
+        kind, v = node
+        if kind == "t":
+            return ts[v]
+        if kind == "c":
+            return v
+        seq = [rebuild(ts, n) for n in v]
+        return seq if kind == "l" else tuple(seq)
+
+    return flat, rebuild
+
+
+class _GraphedFn(torch.autograd.Function):
+    """Connects the replayed forward graph's static outputs to autograd: backward copies the incoming gradients into the static
+    gradient buffers, replays the backward graph and re-binds the parameters' (static) gradients and factored gradients — the loop's
+    `optimizer.zero_grad()` between forward and backward has dropped the references, the buffers themselves belong to the graphs."""
+
+    @staticmethod
+    def forward(ctx, state, anchor, *outs):
+        ctx.state = state
+        ctx.set_materialize_grads(False)
+        return tuple(o.detach() for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        st = ctx.state
+        with torch.no_grad():
+            for buf, g in zip(st.gouts, gs):
+                if g is None:
+                    buf.zero_()
+                else:
+                    buf.copy_(g)
+            opt = st.opt()
+            opt.lr_dev.fill_(float(opt.param_groups[0]["lr"]))
+            st.gb.replay()
+            for p, g in st.grads:
+                p.grad = g
+            for p, f in st.factors:
+                p._icl_factors = list(f)
+        return (None, None) + (None,) * len(gs)
+
+
+class _GraphedStep:
+    """Forward and backward of ONE icl_amd model as two hipGraphs, driven by the unchanged reference loop (FusedSGD(graph=True)).
+
+    Capture (at the first training forward after the warm-up iterations, on the tensors of that call): graph F = the step scope's opening
+    (all convolution weights packed and split in one launch each, dropout counter) + `model.forward`; graph B = `torch.autograd.backward`
+    of the outputs against static gradient buffers + the scope's closing (lane join, BatchNorm counters, deferred bias gradients) + the
+    join of FusedSGD's update stream.  The big token-axis matrices are updated INSIDE graph B (update_in_backward), everything else by the
+    loop's own eager `optimizer.step()` from gradients that live in the graphs' memory pool.  Two graphs, not one, because forked streams
+    that wait on each other in both directions crash hipStreamEndCapture on ROCm 7.2 (trainer.ICLTrainer.capture)."""
+
+    def __init__(self, opt, module, orig_forward, args):
+        from . import ops
+        self.opt = weakref.ref(opt)
+        dev = args[0].device
+        if opt._scope_open:
+            opt._close_scope(flush=False)       # the pre-hook opened an eager scope for this call: the captured one replaces it
+        params = [p for g in opt.param_groups for p in g["params"]]
+        for p in params:
+            p.grad = None
+            if getattr(p, "_icl_factors", None) is not None:
+                p._icl_factors = None
+        torch.cuda.synchronize(dev)
+        if ops.StepRNG.tensor is None or ops.StepRNG.tensor.device != dev:
+            ops.StepRNG.enable(dev)
+        if opt.lr_dev is None:
+            opt.lr_dev = torch.full((1,), float(opt.param_groups[0]["lr"]), dtype=torch.float32, device=dev)
+        self.static_in = [a.detach().clone() for a in args]
+        self.shapes = [tuple(a.shape) for a in args]
+        pool = torch.cuda.graph_pool_handle()
+        self.gf, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gf, pool=pool, stream=opt._cap_stream):
+            ops.StepRNG.begin_step()
+            opt._open_scope(module, capturing=True)
+            out = orig_forward(*self.static_in)
+        flat, self.rebuild = _flatten_outputs(out)
+        if not flat or not all(t.requires_grad for t in flat):
+            raise RuntimeError("graphed step: every output of the training forward is expected to require grad")
+        self.outs = flat
+        self.souts = [t.detach() for t in flat]      # the static output buffers, cut loose from the autograd graph of the capture
+        self.gouts = [torch.zeros_like(t) for t in flat]
+        with torch.cuda.graph(self.gb, pool=pool, stream=opt._cap_stream):
+            torch.autograd.backward(flat, self.gouts)
+            if opt._scope_open:
+                opt._close_scope()
+            opt.flush_deferred(gate=True)
+            if opt._update_stream_used:
+                torch.cuda.current_stream(dev).wait_stream(opt._update_stream)
+            ops.StepRNG.end_step()
+        # nothing of the capture has run: forget the Python-side traces of a backward pass that never executed
+        opt._deferred = []
+        opt._update_stream_used = False
+        opt._updated_in_backward.clear()
+        self.grads = [(p, p.grad) for p in params if p.grad is not None]
+        self.factors = [(p, list(p._icl_factors)) for p in params if getattr(p, "_icl_factors", None)]
+        self.anchor = next(p for p in params if p.requires_grad)
+        self.outs = None      # (drops the autograd graph of the capture: its kernels live in the hipGraphs, its buffers in their pool)
+        for p in params:
+            p.grad = None
+            if getattr(p, "_icl_factors", None) is not None:
+                p._icl_factors = None
+
+    def matches(self, args) -> bool:
+        return len(args) == len(self.shapes) and all(isinstance(a, torch.Tensor) and tuple(a.shape) == s for a, s in zip(args, self.shapes))
+
+    def run(self, args):
+        with torch.no_grad():
+            for buf, a in zip(self.static_in, args):
+                if a.data_ptr() != buf.data_ptr():
+                    buf.copy_(a)
+        self.gf.replay()
+        outs = _GraphedFn.apply(self, self.anchor, *self.souts)
+        return self.rebuild(list(outs))
+
+
+def _install_graphed_forward(opt, model):
+    """Instance-level `forward` of the model: eager for inference / evaluation / the warm-up iterations, graph replay afterwards."""
+    orig = model.forward
+    me = weakref.ref(opt)
+
+    def forward(*args, **kwargs):
+        o = me()
+        train = (o is not None and o._graph_on and o._graph_failed is None and model.training and torch.is_grad_enabled() and not kwargs
+                 and len(args) == 2 and all(isinstance(a, torch.Tensor) and a.is_cuda for a in args))
+        if not train:
+            return orig(*args, **kwargs)
+        st = o._graph_state
+        if st is None:
+            o._train_calls += 1
+            dev = args[0].device
+            if o._cap_stream is None:
+                o._cap_stream = torch.cuda.Stream(device=dev)
+            if o._train_calls <= o._graph_warmup:
+                # Eager iterations (allocator warm-up, momentum buffers, one-time kernel attributes) — on the stream the capture will
+                # use.  A parameter's AccumulateGrad node keeps the stream of the forward pass that created it, and the loop's own
+                # variables (`outputs`, `loss` of the previous iteration) keep that node alive into the next forward: created on the
+                # default stream it would run there during the capture of the backward graph, which hipStreamEndCapture does not survive.
+                cur = torch.cuda.current_stream(dev)
+                o._cap_stream.wait_stream(cur)
+                with torch.cuda.stream(o._cap_stream):
+                    out = orig(*args)
+                cur.wait_stream(o._cap_stream)
+                for t in _flatten_outputs(out)[0]:
+                    t.record_stream(cur)
+                return out
+            try:
+                st = _GraphedStep(o, model, orig, args)
+            except Exception as e:          # noqa: BLE001 — a model that cannot be captured keeps training eagerly
+                o._graph_failed = repr(e)
+                o._graph_state = None
+                import warnings
+                warnings.warn(f"FusedSGD(graph=True): capture failed, staying eager: {e!r}")
+                if o._scope_open:
+                    o._close_scope(flush=False)
+                o._open_scope(model)
+                return orig(*args)
+            o._graph_state = st
+        if not st.matches(args):
+            return orig(*args)              # another batch shape: eager (the pre-hook's scope stayed closed: plain autograd path)
+        return st.run(args)
+
+    model.forward = forward

@@ -184,6 +184,63 @@ def test_reference_loop_body_with_the_one_line_fused_sgd_swap(compat_root):
     torch.cuda.empty_cache()
 
 
+def test_one_line_swap_with_graph_replay_equals_the_eager_swap(compat_root):
+    """`FusedSGD(model.parameters(), ..., graph=True)`: after its warm-up iterations the model's forward and backward are replayed as
+    two hipGraphs while the loop's losses, `zero_grad()`, `step()` and `.item()` reads stay eager.  Five iterations of the reference loop
+    body (two eager, the capture, two replays) leave every parameter and every logged loss where the eager one-line swap leaves them
+    (parity mode: no dropout randomness), inference and evaluation forwards bypass the graphs, and nothing of the scope leaks."""
+    import torch.optim as optim  # noqa: F401
+    from torch.nn.modules.loss import CrossEntropyLoss
+    from networks.net_factory_3d import net_factory_3d
+    from utils import losses
+    from icl_amd import ops
+    from icl_amd.optim import FusedSGD
+    results = {}
+    for graph in (False, True):
+        model = net_factory_3d(net_type="unet_3D_icl", in_chns=1, class_num=2)
+        fill_like_reference_init(list(model.named_parameters()))
+        _parity_mode(model)
+        dev = next(model.parameters()).device
+        vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
+        lab = synthetic_labels((2, 96, 96, 96), 4242, 2).to(dev)
+        base_lr, max_iterations = 0.01, 30000
+        optimizer = FusedSGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001, graph=graph, graph_warmup=2)
+        ce_loss, dice_loss = CrossEntropyLoss(), losses.DiceLoss(2)
+        aux_loss, pse_loss = losses.AuxLoss3D(2), losses.PseudoSoftLoss3D(2)
+        logged = []
+        for iter_num in range(5):
+            outputs = model(vol[:1], vol[1:])
+            outputs_soft = torch.softmax(outputs[0], dim=1)
+            loss_ce = ce_loss(outputs[0], lab[:1])
+            loss_dice = dice_loss(outputs_soft, lab[:1].unsqueeze(1))
+            loss_aux = aux_loss(outputs[2], lab[:1])
+            loss_pse = pse_loss(outputs[3], outputs[1])
+            loss_aux_consis = losses.softmax_mse_loss(outputs[3], outputs[4])
+            loss = loss_dice + loss_ce + loss_aux + loss_pse + 10 * loss_aux_consis
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            lr_ = base_lr * (1.0 - iter_num / max_iterations) ** 0.9
+            for param_group in optimizer.param_groups:
+                param_group['lr'] = lr_
+            logged.append([loss.item(), loss_ce.item(), loss_dice.item(), loss_aux.item(), loss_pse.item(), loss_aux_consis.item()])
+        assert (optimizer._graph_state is not None) == graph, optimizer._graph_failed
+        assert ops.PackedWeights.current is None and ops.FactoredGrads.uses is None and not ops.FactoredGrads.enabled
+        with torch.no_grad():
+            model.eval()
+            y = model(vol[:1], inference=True)
+            model.train()
+        assert y.shape == (1, 2, 96, 96, 96)
+        results[graph] = (np.array(logged), {k: p.detach().clone() for k, p in model.named_parameters()})
+        del model, optimizer, outputs, loss
+        ops.StepRNG.tensor = None
+        torch.cuda.empty_cache()
+    la, lb = results[False][0], results[True][0]
+    assert np.allclose(la, lb, rtol=1e-5, atol=1e-6), (la, lb)
+    bad = [k for k in results[False][1] if not torch.allclose(results[False][1][k], results[True][1][k], rtol=1e-5, atol=1e-7)]
+    assert not bad, bad[:8]
+
+
 def test_reference_loop_body_swinunetr_icl_through_compat_root(compat_root):
     from networks.net_factory_3d import net_factory_3d
     g = load_golden("model_swinunetr_icl_nc2.npz")
