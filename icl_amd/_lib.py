@@ -47,6 +47,12 @@ _SIGNATURES = {
     "icl_norm_res_fwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, L, I, I, I, F, F, P, P]),
     "icl_norm_res_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, L, I, I, I, P, P]),
     "icl_rstd_from_var": (c_int, [P, P, I, F, P]),
+    "icl_norm_finalize_stats": (c_int, [P, I, I, I, F, P, P, P, P]),
+    "icl_norm_apply": (c_int, [P, P, P, I, I, L, P]),
+    "icl_maxpool2_fwd_norm": (c_int, [P, P, P, P, L, I, I, I, I, P]),
+    "icl_upsample2x_concat_norm": (c_int, [P, P, P, P, P, I, I, I, I, I, I, P]),
+    "icl_conv1x1_dropout_norm": (c_int, [P, P, P, P, P, I, I, I, L, I, I, ctypes.c_uint32, F, P, P]),
+    "icl_conv1x1_wgrad_dropout_norm": (c_int, [P, P, P, P, P, P, I, I, I, L, L, ctypes.c_uint32, F, P, P]),
     "icl_maxpool2_fwd": (c_int, [P, P, P, L, I, I, I, I, P]),
     "icl_maxpool2_bwd": (c_int, [P, P, P, L, I, I, I, I, P]),
     "icl_maxpool2_bwd_add": (c_int, [P, P, P, P, I, I, I, I, I, I, L, P]),

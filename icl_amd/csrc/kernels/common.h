@@ -33,6 +33,12 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// relu(InstanceNorm(v)) from the (scale, shift) pair of norm_finalize_stats_kernel: what a consumer of a deferred normalisation sees
+__device__ __forceinline__ float norm_relu1(float v, float sc, float sh) { return fmaxf(fmaf(v, sc, sh), 0.f); }
+__device__ __forceinline__ float4 norm_relu4(float4 v, float sc, float sh) {
+  return make_float4(norm_relu1(v.x, sc, sh), norm_relu1(v.y, sc, sh), norm_relu1(v.z, sc, sh), norm_relu1(v.w, sc, sh));
+}
+
 // component j of a float4 (j is a compile-time constant after unrolling)
 __device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 

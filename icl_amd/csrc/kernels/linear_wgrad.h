@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restr
       if (rv && ov[a]) av[a] = *reinterpret_cast<const float4*>(g + b * g_bstride + (long)(o0 + a * 16 + lr) * S + v);
       if (rv && iv[a]) {
         bv[a] = *reinterpret_cast<const float4*>(x + b * x_bstride + (long)(i0 + a * 16 + lr) * S + v);
+        if (dr.ss) bv[a] = norm_relu4(bv[a], dr.ss[2 * (b * I + (i0 + a * 16 + lr))], dr.ss[2 * (b * I + (i0 + a * 16 + lr)) + 1]);
         if (dr.mode == 1) bv[a] = drop_apply4(bv[a], dseed, dr.thresh, dr.scale, (b * I + (i0 + a * 16 + lr)) * S + v);
       }
     }

@@ -110,6 +110,8 @@ struct DropSpec {
   float scale;
   const unsigned* seed_dev;
   int mode;
+  const float* ss;      // != nullptr: the kernel's x operand is a RAW convolution output; relu(fma(x, scale, shift)) per (sample, channel) is
+                        // applied on load, in front of the mask (deferred InstanceNorm + ReLU, norm.h norm_finalize_stats_kernel)
 };
 __device__ __forceinline__ unsigned drop_seed(const DropSpec& d) { return d.seed_dev ? mix32(d.seed ^ mix32(*d.seed_dev + 0x632BE5ABu)) : d.seed; }
 __device__ __forceinline__ float drop_apply(float v, unsigned seed, unsigned thresh, float scale, long k) {
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const float* __rest
     const float* xp = x + b * CI * S + (v4 << 2);
     for (int i = 0; i < CI; ++i) {
       float4 xv = *reinterpret_cast<const float4*>(xp + (long)i * S);
+      if (dr.ss) xv = norm_relu4(xv, dr.ss[2 * (b * CI + i)], dr.ss[2 * (b * CI + i) + 1]);
       if (dr.mode == 1) xv = drop_apply4(xv, dseed, dr.thresh, dr.scale, (b * CI + i) * S + (v4 << 2));      // dropout -> conv: the mask on load
 #pragma unroll
       for (int o = 0; o < OB; ++o) {

@@ -116,6 +116,25 @@ __device__ __forceinline__ void norm_group_stats(const float* __restrict__ part,
   mean_out = bc[0]; var_out = bc[1]; n_out = bc[2];
 }
 
+// Deferred normalisation (round 5): InstanceNorm statistics of a convolution output from the summaries its epilogue wrote — mean, rstd
+// (for the backward pass) and the (scale, shift) = (rstd, -mean * rstd) pair with which the CONSUMERS of that output apply
+// relu(fma(y, scale, shift)) while they load it (pool_resize.h maxpool2 / upsample2x / copy, misc.h conv1x1_stream_kernel, linear_wgrad.h
+// conv1x1_wgrad_kernel): the normalised tensor of the 96^3 / 48^3 `conv2` layers is never written.  The same merge, in the same order, as
+// norm_act_fwd_kernel's; the consumers' fma is the expression that kernel evaluates.  grid R (= samples x channels), 64 threads.
+__global__ __launch_bounds__(64) void norm_finalize_stats_kernel(const float* __restrict__ part, int R, int C, int nchunks, float eps,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ ss) {
+  const int g = blockIdx.x;
+  float m, var, n;
+  norm_group_stats(part, g, R, C, nchunks, 0, m, var, n);
+  if (threadIdx.x == 0) {
+    const float rs = 1.0f / sqrtf(var + eps);
+    mean[g] = m;
+    rstd[g] = rs;
+    ss[2 * g] = rs;
+    ss[2 * g + 1] = 0.f - m * rs;
+  }
+}
+
 // y = act(((x-mean[g])*rstd[g]) * gamma[c] + beta[c] [+ res]); act 0 = identity, 1 = ReLU, 2 = LeakyReLU(0.01)
 // (nn.LeakyReLU default).  `res` (optional, same shape as x) is the residual branch of MONAI's UnetResBlock:
 // lrelu(norm2(conv2(.)) + residual) in one pass.   grid (nchunks, R)

@@ -11,8 +11,11 @@ namespace icl {
 
 // ---- max pooling, window pd x 2 x 2 (pd = 2: MaxPool3d(2); pd = 1: MaxPool2d(2) on a D=1 volume), stride = window.
 // idx = argmax in (dz,dy,dx) scan order with strict '>' so the first maximum wins, as ATen's max_pool does.
+// ss != nullptr: x is a RAW convolution output whose InstanceNorm + ReLU is applied on load (norm.h norm_finalize_stats_kernel): the
+// maximum and its index are those of the normalised tensor (ReLU ties resolve to the first maximum, as on a materialised tensor).
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                           unsigned char* __restrict__ idx, long NC, int Do, int Ho, int Wo, int pd) {
+                                                           unsigned char* __restrict__ idx, long NC, int Do, int Ho, int Wo, int pd,
+                                                           const float* __restrict__ ss) {
   const long total = NC * Do * Ho * Wo;
   const int H = Ho * 2, W = Wo * 2;
   const int nk = 4 * pd;
@@ -24,10 +27,12 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
     const int oz = (int)(t % Do);
     const long nc = t / Do;
     const float* p = x + ((nc * (Do * pd) + oz * pd) * H + oy * 2) * (long)W + ox * 2;
-    float best = p[0];
+    const float sc = ss ? ss[2 * nc] : 1.f, sh = ss ? ss[2 * nc + 1] : 0.f;
+    float best = ss ? norm_relu1(p[0], sc, sh) : p[0];
     int bi = 0;
     for (int k = 1; k < nk; ++k) {
-      const float v = p[((k >> 2) * H + ((k >> 1) & 1)) * (long)W + (k & 1)];
+      float v = p[((k >> 2) * H + ((k >> 1) & 1)) * (long)W + (k & 1)];
+      if (ss) v = norm_relu1(v, sc, sh);
       if (v > best) { best = v; bi = k; }
     }
     y[o] = best;
@@ -180,7 +185,7 @@ __device__ __forceinline__ float up2_even(float prev, float cur, bool first) { r
 __device__ __forceinline__ float up2_odd(float cur, float next) { return 0.75f * cur + 0.25f * next; }
 
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int Di,
-                                                             int Hi, int Wi, long y_bstride) {
+                                                             int Hi, int Wi, long y_bstride, const float* __restrict__ ss) {
   const unsigned wq = (unsigned)Wi >> 1;
   const unsigned total = (unsigned)N * C * Di * Hi * wq;
   const int Ho = 2 * Hi, Wo = 2 * Wi;
@@ -194,6 +199,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
     const int c = (int)(t % (unsigned)C);
     const int n = (int)(t / (unsigned)C);
     const float* p = x + ((long)n * C + c) * Di * Hi * Wi;
+    const float sc = ss ? ss[2 * (n * C + c)] : 1.f, sh = ss ? ss[2 * (n * C + c) + 1] : 0.f;      // deferred InstanceNorm + ReLU of x
     const int ix = (int)xq * 2;
     const int xa = ix > 0 ? ix - 1 : 0, xd = ix + 2 < Wi ? ix + 2 : Wi - 1;
     float r[3][3][4];   // after the x pass: [z][y][ox]
@@ -206,7 +212,8 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
         int yy = iy + dy - 1;
         yy = yy < 0 ? 0 : (yy > Hi - 1 ? Hi - 1 : yy);
         const float* row = p + ((long)z * Hi + yy) * Wi;
-        const float a = row[xa], b = row[ix], cc = row[ix + 1], d = row[xd];
+        float a = row[xa], b = row[ix], cc = row[ix + 1], d = row[xd];
+        if (ss) { a = norm_relu1(a, sc, sh); b = norm_relu1(b, sc, sh); cc = norm_relu1(cc, sc, sh); d = norm_relu1(d, sc, sh); }
         r[dz][dy][0] = up2_even(a, b, ix == 0);
         r[dz][dy][1] = up2_odd(b, cc);
         r[dz][dy][2] = up2_even(b, cc, false);
@@ -251,7 +258,7 @@ __device__ __forceinline__ void up2_adj_weights(int i, int n, float w[4]) {
 // 32 outputs instead of 36 for 16 — the two-voxel kernel streams a 96^3 x 32-channel output at 3.1 TB/s, bound by its load instructions),
 // eight 16-byte stores.  Every output is computed by the formulas of the two-voxel kernel: bit-identical.
 __global__ __launch_bounds__(256) void upsample2x_fwd_x4_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int Di,
-                                                                int Hi, int Wi, long y_bstride) {
+                                                                int Hi, int Wi, long y_bstride, const float* __restrict__ ss) {
   const unsigned wq = (unsigned)Wi >> 2;
   const unsigned total = (unsigned)N * C * Di * Hi * wq;
   const int Ho = 2 * Hi, Wo = 2 * Wi;
@@ -265,6 +272,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_x4_kernel(const float* __r
     const int c = (int)(t % (unsigned)C);
     const int n = (int)(t / (unsigned)C);
     const float* p = x + ((long)n * C + c) * Di * Hi * Wi;
+    const float sc = ss ? ss[2 * (n * C + c)] : 1.f, sh = ss ? ss[2 * (n * C + c) + 1] : 0.f;
     const int ix = (int)xq * 4;
     const int xa = ix > 0 ? ix - 1 : 0, xd = ix + 4 < Wi ? ix + 4 : Wi - 1;
     float r[3][3][8];   // after the x pass: [z][y][ox]
@@ -278,7 +286,11 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_x4_kernel(const float* __r
         yy = yy < 0 ? 0 : (yy > Hi - 1 ? Hi - 1 : yy);
         const float* row = p + ((long)z * Hi + yy) * Wi;
         const float4 q = *reinterpret_cast<const float4*>(row + ix);
-        const float v[6] = {row[xa], q.x, q.y, q.z, q.w, row[xd]};
+        float v[6] = {row[xa], q.x, q.y, q.z, q.w, row[xd]};
+        if (ss) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v[k] = norm_relu1(v[k], sc, sh);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {     // input ix + k: outputs 2k (from v[k], v[k+1]) and 2k + 1 (from v[k+1], v[k+2])
           r[dz][dy][2 * k] = up2_even(v[k], v[k + 1], ix + k == 0);
@@ -545,6 +557,19 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long r = e / row_elems, i = e - r * row_elems;
     dst[r * dst_stride + i] = src[r * src_stride + i];
+  }
+}
+
+// dst[n][c][:] = relu(fma(src[n][c][:], scale, shift)) for the skip half of a concat buffer whose source is a deferred normalisation:
+// rows = N * C channel rows of S floats (S % 4 == 0), the destination sample stride differs from the source's (the concat buffer).
+__global__ __launch_bounds__(256) void copy_rows_norm_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, long S,
+                                                             long dst_bstride, const float* __restrict__ ss) {
+  const long S4 = S >> 2, total = (long)N * C * S4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long q = e % S4, r = e / S4;
+    const int c = (int)(r % C), n = (int)(r / C);
+    const float4 v = *reinterpret_cast<const float4*>(src + r * S + (q << 2));
+    *reinterpret_cast<float4*>(dst + (long)n * dst_bstride + (long)c * S + (q << 2)) = norm_relu4(v, ss[2 * r], ss[2 * r + 1]);
   }
 }
 

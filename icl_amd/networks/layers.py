@@ -72,6 +72,14 @@ class ConvBlock(nn.Sequential):
         # the three children as ONE operator: the convolution's epilogue hands the normalisation its statistics (ops.py)
         return ops.conv3d_instance_norm_act(x, self[0].weight, self[0].bias, act=1)
 
+    def forward_lazy(self, x):
+        """The same block with its InstanceNorm + ReLU DEFERRED to the consumers of the output (``ops.LazyAct``) where that pays — big
+        volumes inside a step scope — and the ordinary tensor otherwise.  Only for outputs whose consumers are ``ops.skip_and_pool``,
+        ``ops.upsample2x_concat`` and ``ops.conv1x1_lazy`` (the `conv2` blocks of the 3-D U-Net's upper levels)."""
+        if not self._stock():
+            return super().forward(x)
+        return ops.conv3d_instance_norm_act_lazy(x, self[0].weight, self[0].bias)
+
 
 class UnetConv3(nn.Module):
     """Two ConvBlocks (networks/utils.py:99-123)."""
@@ -81,8 +89,10 @@ class UnetConv3(nn.Module):
         self.conv1 = ConvBlock(cin, cout, device)
         self.conv2 = ConvBlock(cout, cout, device)
 
-    def forward(self, x):
-        return self.conv2(self.conv1(x))
+    def forward(self, x, lazy: bool = False):
+        """``lazy``: the output may be an ``ops.LazyAct`` (see ConvBlock.forward_lazy); the input may be one never."""
+        h = self.conv1(x)
+        return self.conv2.forward_lazy(h) if lazy else self.conv2(h)
 
 
 class UnetUp3_CT(nn.Module):
@@ -94,8 +104,9 @@ class UnetUp3_CT(nn.Module):
         self.conv = UnetConv3(in_size + out_size, out_size, device)
         self.up = _Identity()  # nn.Upsample has no parameters; kept for module-tree parity
 
-    def forward(self, skip, deep):
-        return self.conv(ops.upsample2x_concat(skip, deep))
+    def forward(self, skip, deep, lazy: bool = False):
+        """``skip`` / ``deep`` may be ``ops.LazyAct`` (their normalisation is applied while the concat buffer is written)."""
+        return self.conv(ops.upsample2x_concat(skip, deep), lazy)
 
 
 class Dropout3(nn.Module):

@@ -55,10 +55,14 @@ class UNet3DBackbone(nn.Module):
         from .. import ops
         # every encoder output feeds its level's skip connection AND the next level's pooling: ops.skip_and_pool returns both so that
         # the backward adds the two gradients inside the pooling backward's pass
-        c1, p1 = ops.skip_and_pool(self.conv1(x))
-        c2, p2 = ops.skip_and_pool(self.conv2(p1))
-        c3, p3 = ops.skip_and_pool(self.conv3(p2))
-        c4, p4 = ops.skip_and_pool(self.conv4(p3))
+        # Round 5: the encoder outputs and the two upper decoder outputs may come back as ops.LazyAct — the raw output of the block's
+        # second convolution with its InstanceNorm + ReLU applied by the consumers (pooling, skip / up-sampling into the concat buffer,
+        # the `final` convolution) while they read it; ops decides per tensor (>= 48^3 voxels, inside a step scope).  center / up4 / up3
+        # feed the aligner heads and stay ordinary tensors.
+        c1, p1 = ops.skip_and_pool(self.conv1(x, lazy=True))
+        c2, p2 = ops.skip_and_pool(self.conv2(p1, lazy=True))
+        c3, p3 = ops.skip_and_pool(self.conv3(p2, lazy=True))
+        c4, p4 = ops.skip_and_pool(self.conv4(p3, lazy=True))
         center = self.dropout1(self.center(p4))
         up4 = self.up_concat4(c4, center)
         up3 = self.up_concat3(c3, up4)
@@ -67,11 +71,15 @@ class UNet3DBackbone(nn.Module):
             # follow — the point from which an optimiser with gated update placement streams its big matrices (FusedSGD.flush_deferred)
             up3.register_hook(_open_update_gate)
         extra = heads([center, up4, up3]) if heads is not None else None
-        up2 = self.up_concat2(c2, up3)
-        up1 = self.up_concat1(c1, up2)
-        if self.dropout2.training and self.dropout2.p > 0.0:
+        up2 = self.up_concat2(c2, up3, lazy=True)
+        up1 = self.up_concat1(c1, up2, lazy=True)
+        drop = self.dropout2.p if (self.dropout2.training and self.dropout2.p > 0.0) else 0.0
+        if isinstance(up1, ops.LazyAct):
+            # final(dropout2(up1)) in one pass over the RAW output of up1's last convolution: InstanceNorm + ReLU, the mask, the 1x1x1 product
+            logits = ops.conv1x1_lazy(up1, self.final.weight, self.final.bias, drop)
+        elif drop > 0.0:
             # final(dropout2(up1)) with the mask applied inside the 1x1x1 convolution's passes (ops.dropout_conv1x1)
-            logits = ops.dropout_conv1x1(up1, self.final.weight, self.final.bias, self.dropout2.p)
+            logits = ops.dropout_conv1x1(up1, self.final.weight, self.final.bias, drop)
         else:
             logits = self.final(self.dropout2(up1))
         if heads is not None:

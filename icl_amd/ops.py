@@ -706,6 +706,108 @@ def instance_norm_act(x: torch.Tensor, act: int, eps: float = 1e-5) -> torch.Ten
     return _NormAct.apply(x, None, None, None, None, 0, True, int(act), eps, 0.0)
 
 
+# --------------------------------------------------------------------------------------
+# Deferred InstanceNorm3d + ReLU (round 5) — Conv3d -> InstanceNorm3d -> ReLU of UnetConv3 (networks/utils.py:107-109) whose output
+# feeds MaxPool3d, the skip concatenation, nn.Upsample or the `final` convolution (unet_3D_icl.py:41-53,116-117; utils.py:264,276)
+# --------------------------------------------------------------------------------------
+
+def _lazy_norm_min_voxels() -> int:
+    """Smallest volume whose normalisation is deferred; ICL_LAZY_NORM=0 turns the deferral off (both read per call: the tests switch them)."""
+    if os.environ.get("ICL_LAZY_NORM", "1") == "0":
+        return 1 << 62
+    return int(os.environ.get("ICL_LAZY_NORM_MIN", str(48 ** 3)))
+
+
+class LazyAct:
+    """A convolution output whose InstanceNorm + ReLU is deferred to its consumers.  ``t`` holds the RAW convolution output — in autograd
+    terms it already IS the normalised activation (its gradient is the gradient of relu(norm(y)); `_NormActLazy.backward` turns it into
+    the gradient of y) — and ``ss`` the per-(sample, channel) (scale, shift) pairs with which ``skip_and_pool``, ``upsample2x_concat`` and
+    ``dropout_conv1x1`` / ``conv1x1_lazy`` apply relu(fma(t, scale, shift)) while they load it.  Never hand ``t`` to anything else:
+    ``materialize()`` writes the normalised tensor out (one pass, what the non-deferred path always does).  Measured upper bound of not
+    writing the 96^3 / 48^3 activations of a step: profiles/r5_skip_norm_fwd_upper_bound.txt."""
+    __slots__ = ("t", "ss")
+
+    def __init__(self, t: torch.Tensor, ss: torch.Tensor):
+        self.t, self.ss = t, ss
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def materialize(self) -> torch.Tensor:
+        return _LazyMaterialize.apply(self.t, self.ss)
+
+
+def materialized(x):
+    return x.materialize() if isinstance(x, LazyAct) else x
+
+
+class _NormActLazy(torch.autograd.Function):
+    """(y, summaries) -> (y as the virtual normalised activation, ss).  Backward: InstanceNorm + ReLU backward exactly as _NormAct's."""
+
+    @staticmethod
+    def forward(ctx, y, stats, eps):
+        _require(y, stats)
+        L = _lib.lib()
+        n, c = y.shape[0], y.shape[1]
+        mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
+        rstd = torch.empty(n * c, dtype=torch.float32, device=y.device)
+        ss = torch.empty((n * c, 2), dtype=torch.float32, device=y.device)
+        _lib.check(L.icl_norm_finalize_stats(_ptr(stats), n, c, stats.shape[1], eps, _ptr(mean), _ptr(rstd), _ptr(ss), _stream(y)),
+                   "norm_finalize_stats")
+        ctx.save_for_backward(y, mean, rstd)
+        ctx.mark_non_differentiable(ss)
+        ctx.set_materialize_grads(False)
+        return y.view_as(y), ss
+
+    @staticmethod
+    def backward(ctx, ga, gss=None):
+        if ga is None:
+            return None, None, None
+        y, mean, rstd = ctx.saved_tensors
+        L = _lib.lib()
+        ga = ga.contiguous()
+        n, c = y.shape[0], y.shape[1]
+        s = y.numel() // (n * c)
+        gy = torch.empty_like(y)
+        ws = _ws(L.icl_norm_ws_bytes(n, c, s), y)
+        _lib.check(L.icl_norm_bwd(_ptr(ga), _ptr(y), _ptr(mean), _ptr(rstd), None, None, _ptr(gy), None, None, n, c, s, 0, 1, 1, _ptr(ws),
+                                  _stream(y)), "norm_bwd")
+        return gy, None, None
+
+
+class _LazyMaterialize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, ss):
+        L = _lib.lib()
+        n, c = t.shape[0], t.shape[1]
+        s = t.numel() // (n * c)
+        if s % 4:
+            sc = ss[:, 0].reshape(n, c, *([1] * (t.dim() - 2)))
+            sh = ss[:, 1].reshape(n, c, *([1] * (t.dim() - 2)))
+            return torch.clamp_min(torch.addcmul(sh, t, sc), 0.0)
+        out = torch.empty_like(t)
+        _lib.check(L.icl_norm_apply(_ptr(t), _ptr(ss), _ptr(out), n, c, s, _stream(t)), "norm_apply")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None      # `t` already stands for the normalised activation in the autograd graph
+
+
+def conv3d_instance_norm_act_lazy(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float = 1e-5):
+    """``conv3d_instance_norm_act(..., act=1)`` returning a ``LazyAct`` when the convolution's epilogue produced the statistics and the
+    volume is big enough for the normalisation pass to matter (>= 48^3 voxels), the normalised tensor otherwise."""
+    s = x.shape[2] * x.shape[3] * x.shape[4]
+    if weight.shape[2] != 3 or s < _lazy_norm_min_voxels() or s % 4 or not torch.is_grad_enabled():
+        return conv3d_instance_norm_act(x, weight, bias, act=1, eps=eps)
+    y, stats = _Conv3d.apply(x, weight, bias, True, True)
+    if not stats.numel():
+        return _NormAct.apply(y, None, None, None, None, 0, True, 1, eps, 0.0, None)
+    av, ss = _NormActLazy.apply(y, stats, eps)
+    return LazyAct(av, ss)
+
+
 class _InstanceNormAddAct(torch.autograd.Function):
     """act(InstanceNorm3d(x) + res): the tail of MONAI UnetResBlock.forward in one pass (and one backward pass that
     produces both gx and gres)."""
@@ -864,8 +966,33 @@ class _SkipAndPool(torch.autograd.Function):
         return gx if gskip is None else gx + gskip
 
 
-def skip_and_pool(x: torch.Tensor):
-    """Returns (x, MaxPool3d(2)(x)); use the FIRST output for the skip connection so that the backward can fuse the two gradients."""
+class _SkipAndPoolLazy(torch.autograd.Function):
+    """_SkipAndPool on a deferred normalisation: the pooling reads the raw tensor and normalises on load; the skip output stays deferred."""
+
+    @staticmethod
+    def forward(ctx, t, ss):
+        L = _lib.lib()
+        n, c, d, h, w = t.shape
+        y = torch.empty((n, c, d // 2, h // 2, w // 2), dtype=torch.float32, device=t.device)
+        idx = torch.empty(y.shape, dtype=torch.uint8, device=t.device)
+        _lib.check(L.icl_maxpool2_fwd_norm(_ptr(t), _ptr(ss), _ptr(y), _ptr(idx), n * c, d // 2, h // 2, w // 2, 2, _stream(t)), "maxpool2_fwd_norm")
+        ctx.save_for_backward(idx)
+        return t.view_as(t), y
+
+    @staticmethod
+    def backward(ctx, gskip, gy):
+        return _SkipAndPool.backward(ctx, gskip, gy), None
+
+
+def skip_and_pool(x):
+    """Returns (x, MaxPool3d(2)(x)); use the FIRST output for the skip connection so that the backward can fuse the two gradients.
+    ``x`` may be a ``LazyAct``: the skip output then is one too."""
+    if isinstance(x, LazyAct):
+        d, h, w = x.t.shape[2:]
+        if d % 2 == 0 and h % 2 == 0 and w % 2 == 0 and x.t.is_contiguous():
+            skip, pooled = _SkipAndPoolLazy.apply(x.t, x.ss)
+            return LazyAct(skip, x.ss), pooled
+        x = x.materialize()
     return _SkipAndPool.apply(x)
 
 
@@ -962,7 +1089,43 @@ class _UpCat(torch.autograd.Function):
         return gskip, gdeep
 
 
-def upsample2x_concat(skip: torch.Tensor, deep: torch.Tensor) -> torch.Tensor:
+class _UpCatLazy(torch.autograd.Function):
+    """_UpCat with either source given as a deferred normalisation (raw tensor + (scale, shift), applied while it is copied / up-sampled
+    into the concat buffer)."""
+
+    @staticmethod
+    def forward(ctx, skip, skip_ss, deep, deep_ss):
+        L = _lib.lib()
+        n, cs, d, h, w = skip.shape
+        cd = deep.shape[1]
+        out = torch.empty((n, cs + cd, d, h, w), dtype=torch.float32, device=skip.device)
+        _lib.check(L.icl_upsample2x_concat_norm(_ptr(skip), _ptr(skip_ss), _ptr(deep), _ptr(deep_ss), _ptr(out), n, cs, cd, d, h, w,
+                                                _stream(skip)), "upsample2x_concat_norm")
+        ctx.dims = (n, cs, cd, d, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx2 = ctx
+        needs = ctx.needs_input_grad
+
+        class _View:      # _UpCat.backward reads needs_input_grad[0] / [1] of (skip, deep)
+            dims = ctx2.dims
+            needs_input_grad = (needs[0], needs[2])
+        gskip, gdeep = _UpCat.backward(_View, g)
+        return gskip, None, gdeep, None
+
+
+def upsample2x_concat(skip, deep) -> torch.Tensor:
+    """cat([skip, upsample2x(deep)], 1); either argument may be a ``LazyAct`` (its normalisation is applied while it is read)."""
+    if isinstance(skip, LazyAct) or isinstance(deep, LazyAct):
+        st, dt = (skip.t if isinstance(skip, LazyAct) else skip), (deep.t if isinstance(deep, LazyAct) else deep)
+        n, cs, d, h, w = st.shape
+        ok = (d % 2 == 0 and h % 2 == 0 and w % 4 == 0 and tuple(dt.shape[2:]) == (d // 2, h // 2, w // 2) and dt.shape[0] == n
+              and st.is_contiguous() and dt.is_contiguous() and st.dtype == torch.float32 and (st.is_cuda or _lib.host_pointers_ok()))
+        if ok:
+            return _UpCatLazy.apply(st, skip.ss if isinstance(skip, LazyAct) else None, dt, deep.ss if isinstance(deep, LazyAct) else None)
+        skip, deep = materialized(skip), materialized(deep)
     return _UpCat.apply(skip, deep)
 
 
@@ -1194,6 +1357,75 @@ class _DropoutConv1x1(torch.autograd.Function):
                 _lib.check(L.icl_conv1x1_wgrad_dropout(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(ws), n, cin, cout, s, cout * s, seed, p,
                                                        _ptr(ctx.seed_dev), _stream(x)), "conv1x1_wgrad_dropout")
         return gx, gw, gb, None, None, None
+
+
+class _DropoutConv1x1Lazy(torch.autograd.Function):
+    """_DropoutConv1x1 on a deferred normalisation: y = conv1x1(dropout(relu(fma(t, scale, shift)), p)) — InstanceNorm + ReLU, the dropout
+    mask and the convolution in one pass over the raw tensor (p = 0: no mask); the weight gradient applies both on its x operand."""
+
+    @staticmethod
+    def forward(ctx, t, ss, weight, bias, p, seed, seed_dev):
+        L = _lib.lib()
+        n, cin = t.shape[0], t.shape[1]
+        cout = weight.shape[0]
+        s = t.numel() // (n * cin)
+        y = torch.empty((n, cout) + tuple(t.shape[2:]), dtype=torch.float32, device=t.device)
+        _lib.check(L.icl_conv1x1_dropout_norm(_ptr(t), _ptr(ss), _ptr(weight), _ptr(bias), _ptr(y), n, cin, cout, s, cin, 1, seed, p,
+                                              _ptr(seed_dev), _stream(t)), "conv1x1_dropout_norm")
+        ctx.save_for_backward(t, ss, weight)
+        ctx.cfg = (p, seed, bias is not None)
+        ctx.seed_dev = seed_dev
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        t, ss, weight = ctx.saved_tensors
+        p, seed, has_bias = ctx.cfg
+        L = _lib.lib()
+        gy = gy.contiguous()
+        n, cin = t.shape[0], t.shape[1]
+        cout = weight.shape[0]
+        s = t.numel() // (n * cin)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(t)      # the gradient of the NORMALISED activation (what `t` stands for in the autograd graph)
+            if p > 0.0:
+                _lib.check(L.icl_conv1x1_dropout(_ptr(gy), _ptr(weight), None, _ptr(gx), n, cout, cin, s, 1, cin, 2, seed, p, _ptr(ctx.seed_dev),
+                                                 _stream(t)), "conv1x1_dropout dgrad")
+            else:
+                _lib.check(L.icl_conv1x1_small(_ptr(gy), _ptr(weight), None, _ptr(gx), n, cout, cin, s, 1, cin, _stream(t)), "conv1x1_small dgrad")
+        if ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3]):
+            gw = torch.empty_like(weight)
+            gb = torch.empty(cout, dtype=torch.float32, device=t.device) if has_bias else None
+            ws = _ws(L.icl_conv1x1_wgrad_ws_bytes(n, s, cin, cout), t)
+            with _timed("conv1x1_wgrad_kernel", 2.0 * cin * cout * s * n, 4.0 * n * s * (cin + cout), t):
+                _lib.check(L.icl_conv1x1_wgrad_dropout_norm(_ptr(t), _ptr(ss), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(ws), n, cin, cout, s, cout * s,
+                                                            seed, p, _ptr(ctx.seed_dev), _stream(t)), "conv1x1_wgrad_dropout_norm")
+        return gx, None, gw, gb, None, None, None
+
+
+def conv1x1_lazy(x, weight: torch.Tensor, bias: Optional[torch.Tensor], p: float = 0.0, seed: Optional[int] = None) -> torch.Tensor:
+    """``conv3d(dropout(relu(norm(y)), p), weight, bias)`` for a 1x1x1 convolution whose input is a ``LazyAct`` — `final(dropout2(up1))`
+    (unet_3D_icl.py:116-117) in one pass over the RAW output of up1's last convolution; p = 0: `final(up1)`.  Shapes the fused kernels do
+    not take are materialised and run the ordinary operators."""
+    if not isinstance(x, LazyAct):
+        return dropout_conv1x1(x, weight, bias, p, seed) if p > 0.0 else conv3d(x, weight, bias)
+    t = x.t
+    n, cin = t.shape[0], t.shape[1]
+    s = t.numel() // max(n * cin, 1)
+    fusable = ((t.is_cuda or _lib.host_pointers_ok()) and weight.shape[2:].numel() == 1 and cin <= 16 and weight.shape[0] <= 16
+               and s % 4 == 0 and n * s >= 65536 and t.is_contiguous())
+    if not fusable:
+        a = x.materialize()
+        return dropout_conv1x1(a, weight, bias, p, seed) if p > 0.0 else conv3d(a, weight, bias)
+    seed_dev = None
+    if p > 0.0 and seed is None:
+        if StepRNG.tensor is not None and StepRNG.tensor.device == t.device:
+            seed = StepRNG.next_seed()
+            seed_dev = StepRNG.tensor
+        else:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return _DropoutConv1x1Lazy.apply(t, x.ss, weight.contiguous(), bias, float(p), int(seed or 0) & 0xFFFFFFFF, seed_dev)
 
 
 def dropout_conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], p: float, seed: Optional[int] = None) -> torch.Tensor:

@@ -106,6 +106,23 @@ int icl_norm_res_bwd(const float* gy, const float* x, const float* res, const fl
                      int use_batch_stats, int act, void* ws, void* stream);
 int icl_rstd_from_var(const float* var, float* rstd, int c, float eps, void* stream);
 
+/* ---- Deferred InstanceNorm3d + ReLU (round 5).  Reference: Conv3d -> InstanceNorm3d -> ReLU in UnetConv3
+ * (/root/reference/code/networks/utils.py:107-109) whose output feeds MaxPool3d / the skip concatenation / nn.Upsample / the `final`
+ * convolution (unet_3D_icl.py:41-53,116-117, utils.py:264,276).  The convolution stores its RAW output and (count, mean, M2) summaries
+ * (icl_conv3d_fwd_presplit_stats); icl_norm_finalize_stats turns them into mean / rstd (for icl_norm_bwd) and the per-(sample, channel)
+ * pair ss = (scale, shift) = (rstd, -mean * rstd); the consumers below apply relu(fma(x, scale, shift)) while they load x, so the
+ * normalised tensor is never written.  ss: [n * c][2] floats. */
+int icl_norm_finalize_stats(const float* part, int n, int c, int nslots, float eps, float* mean, float* rstd, float* ss, void* stream);
+/* y = relu(fma(x, scale, shift)) written out (a consumer that cannot apply the deferred normalisation on load); s % 4 == 0 */
+int icl_norm_apply(const float* x, const float* ss, float* y, int n, int c, int64_t s, void* stream);
+/* MaxPool3d(2) of the normalised tensor from the raw one (values and argmax of relu(fma(x, scale, shift))) */
+int icl_maxpool2_fwd_norm(const float* x, const float* ss, float* y, uint8_t* idx, int64_t nc, int dout, int hout, int wout, int pool_depth,
+                          void* stream);
+/* out = cat([skip, upsample2x(deep)], 1) (utils.py:264,276): skip [n, cs, d, h, w], deep [n, cd, d/2, h/2, w/2], out [n, cs + cd, d, h, w];
+ * skip_ss / deep_ss: that source is raw with deferred normalisation (NULL: used as stored).  d, h even, w % 4 == 0. */
+int icl_upsample2x_concat_norm(const float* skip, const float* skip_ss, const float* deep, const float* deep_ss, float* out, int n, int cs,
+                               int cd, int d, int h, int w, void* stream);
+
 /* ---- MaxPool3d(2) (networks/unet_3D_icl.py:41-53) and MaxPool2d(2) (networks/unet_icl.py:64, pool_depth = 1 on a
  * D = 1 volume); idx = uint8 argmax within the pool_depth x 2 x 2 window. */
 int icl_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int64_t nc, int dout, int hout, int wout, int pool_depth, void* stream);
@@ -153,6 +170,12 @@ int icl_conv1x1_dropout(const float* x, const float* w, const float* bias, float
                         int w_istride, int mask_mode, uint32_t seed, float p, const uint32_t* seed_dev, void* stream);
 int icl_conv1x1_wgrad_dropout(const float* x, const float* gy, float* gw, float* gbias, void* ws, int n, int cin, int cout, int64_t s,
                               int64_t gy_bstride, uint32_t seed, float p, const uint32_t* seed_dev, void* stream);
+/* the same pair with x given raw + ss (deferred InstanceNorm + ReLU of `up1`, then dropout2, then `final`; p = 0: no mask): forward
+ * (n * s >= 65536) and weight gradient; the input gradient is icl_conv1x1_dropout(mask_mode 2) as before. */
+int icl_conv1x1_dropout_norm(const float* x, const float* ss, const float* w, const float* bias, float* y, int n, int cin, int cout, int64_t s,
+                             int w_ostride, int w_istride, uint32_t seed, float p, const uint32_t* seed_dev, void* stream);
+int icl_conv1x1_wgrad_dropout_norm(const float* x, const float* ss, const float* gy, float* gw, float* gbias, void* ws, int n, int cin,
+                                   int cout, int64_t s, int64_t gy_bstride, uint32_t seed, float p, const uint32_t* seed_dev, void* stream);
 
 /* ---- nn.Dropout(p) (networks/unet_3D_icl.py:67-68,110,116): y = keep ? x/(1-p) : 0 with a counter-based
  * mask keyed by (seed, element index); calling it again with the same seed on dY is the backward.  seed_dev (may be

@@ -842,3 +842,91 @@ def test_conv_block_falls_back_to_its_children_when_they_are_hooked_or_swapped()
         blk[2] = torch.nn.Hardtanh(0.0, 0.5)          # swapped through the reference-compatible index
         assert not blk._stock()
         assert torch.allclose(blk(x), fused.clamp(0.0, 0.5), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.timeout(900)
+def test_deferred_instance_norm_equals_the_materialised_path(monkeypatch):
+    """Round 5: inside a step scope the `conv2` blocks of the U-Net's upper levels hand their consumers the RAW convolution output plus
+    (scale, shift) (ops.LazyAct): max-pooling, the skip / up-sampling into the concat buffer and `final(dropout2(.))` apply
+    relu(fma(y, scale, shift)) while they read it.  On a two-level U-Net built from the backbone's own blocks (threshold lowered so that
+    both levels defer; every consumer kind is reached: pooling of a LazyAct, a LazyAct skip, a LazyAct deep map, the lazy 1x1x1
+    convolution with and without dropout) logits, the input gradient and every parameter gradient equal the path that writes the
+    normalised tensors (ICL_LAZY_NORM=0)."""
+    from icl_amd.networks.layers import Conv3d, UnetConv3, UnetUp3_CT
+    monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
+    x = _rand((2, 1, 16, 16, 16), 21)
+
+    class Mini(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.conv2 = UnetConv3(1, 16), UnetConv3(16, 32)
+            self.up = UnetUp3_CT(32, 16)
+            self.final = Conv3d(16, 2, 1, kaiming_normal=True)
+
+        def forward(self, x, p):
+            c1, p1 = ops.skip_and_pool(self.conv1(x, lazy=True))
+            c2 = self.conv2(p1, lazy=True)
+            kinds = [isinstance(c1, ops.LazyAct), isinstance(c2, ops.LazyAct)]
+            up1 = self.up(c1, c2, lazy=True)
+            kinds.append(isinstance(up1, ops.LazyAct))
+            if isinstance(up1, ops.LazyAct):
+                return ops.conv1x1_lazy(up1, self.final.weight, self.final.bias, p, seed=77), kinds
+            return (ops.dropout_conv1x1(up1, self.final.weight, self.final.bias, p, seed=77) if p > 0 else self.final(up1)), kinds
+
+    def run(lazy, p):
+        monkeypatch.setenv("ICL_LAZY_NORM", "1" if lazy else "0")
+        monkeypatch.setenv("ICL_LAZY_NORM_MIN", "64")
+        torch.manual_seed(5)
+        model = Mini()
+        packed = ops.PackedWeights()
+        xin = x.clone().requires_grad_()
+        for it in range(2):          # the second iteration runs with packed + split weights: the epilogue statistics exist
+            packed.begin_step()
+            for q in model.parameters():
+                q.grad = None
+            xin.grad = None
+            y, kinds = model(xin, p)
+            (y * _rand(tuple(y.shape), 22)).sum().backward()
+            packed.end_step()
+        return y.detach(), xin.grad.clone(), {k: q.grad.clone() for k, q in model.named_parameters() if q.grad is not None}, kinds
+
+    for p in (0.0, 0.3):
+        y0, gx0, g0, k0 = run(False, p)
+        y1, gx1, g1, k1 = run(True, p)
+        assert k0 == [False, False, False] and k1 == [True, True, True], (k0, k1)          # the deferred path really ran
+        # (n * s < 65536 here: the lazy 1x1x1 convolution materialises and runs the ordinary operators; its fused kernels are GPU-tested)
+        assert rel_err(y1, y0) < 2e-5 and rel_err(gx1, gx0) < 2e-4, (p, rel_err(y1, y0), rel_err(gx1, gx0))
+        assert sorted(g0) == sorted(g1)
+        # (conv biases in front of an InstanceNorm have a true gradient of 0: both paths hold rounding noise there)
+        bad = [(k, rel_err(g1[k], g0[k])) for k in g0 if not k.endswith(".0.bias") and rel_err(g1[k], g0[k]) > 5e-4]
+        assert not bad, (p, bad[:6])
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_lazy_final_convolution_fused_kernels(p):
+    """ops.conv1x1_lazy on a volume big enough for the fused kernels (icl_conv1x1_dropout_norm / icl_conv1x1_wgrad_dropout_norm):
+    y = conv1x1(dropout(relu(fma(t, scale, shift)))) in one pass over the raw tensor == the same operators on the materialised tensor,
+    forward, input gradient (the gradient of the normalised activation) and weight / bias gradients; same dropout mask (same seed)."""
+    n, cin, cout, r = 2, 16, 2, 32
+    t = _rand((n, cin, r, r, r), 31)
+    ss = torch.stack([0.5 + 0.1 * _rand((n * cin,), 32).abs(), 0.2 * _rand((n * cin,), 33)], 1).contiguous()
+    w = (_rand((cout, cin, 1, 1, 1), 34) * 0.3)
+    b = _rand((cout,), 35)
+    gy = _rand((n, cout, r, r, r), 36)
+    res = []
+    for lazy in (True, False):
+        tt = t.clone().requires_grad_()
+        ww, bb = w.clone().requires_grad_(), b.clone().requires_grad_()
+        la = ops.LazyAct(tt, ss)
+        if lazy:
+            y = ops.conv1x1_lazy(la, ww, bb, p, seed=91)
+        else:
+            a = la.materialize()
+            y = ops.dropout_conv1x1(a, ww, bb, p, seed=91) if p > 0 else ops.conv3d(a, ww, bb)
+        y.backward(gy)
+        res.append((y.detach(), tt.grad.clone(), ww.grad.clone(), bb.grad.clone()))
+    for a, b_ in zip(*res):
+        assert rel_err(a, b_) < 2e-5
+    ref = torch.clamp_min(t * ss[:, 0].view(n, cin, 1, 1, 1) + ss[:, 1].view(n, cin, 1, 1, 1), 0)
+    if p == 0.0:
+        assert rel_err(res[0][0], F.conv3d(ref, w, b)) < 2e-5
