@@ -92,7 +92,7 @@ def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
             "sample": f"{steps} full ICL step(s) of the same workload (2 volumes 96^3 each, nc={num_classes}) after a 32^3 conv warm-up: {t:.2f} s"}
 
 
-HBM_TRAFFIC_FILE = "profiles/r4_hbm_traffic.json"
+HBM_TRAFFIC_FILE = "profiles/r5_hbm_traffic.json"
 
 
 def reference_loop_bench(nc: int, steps: int, warmup: int, dev, fused: bool, graph: bool = False):
@@ -535,7 +535,7 @@ def main():
                     "per_kernel": {k: {"launches_per_step": v[0] // 3, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
                                        "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2),
                                        "frac": round(v[2] / (v[1] * 1e-3) / 1e12 /
-                                                     (PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS if ("bf16x3" in k or "wgrad_tr" in k) else PEAK_F32_MFMA_TFLOPS), 4)}
+                                                     (PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS if ("bf16x3" in k or "wgrad_tr" in k or "wgrad_zs" in k) else PEAK_F32_MFMA_TFLOPS), 4)}
                                    for k, v in sorted(conv.items())}}
             st = {k: v for k, v in summ.items() if k.startswith("linear_stream")}
             if st:   # the 13,824^2 token-axis MLP products: the weight matrix streamed once per launch (csrc/kernels/gemm.h)

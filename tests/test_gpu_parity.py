@@ -1190,7 +1190,7 @@ def test_split_bf16_convolution_propagates_non_finite_inputs(dev, monkeypatch, b
 @pytest.mark.parametrize("kind", ["normal", "positive", "wide", "denormal"])
 @pytest.mark.parametrize("cin,cout", [(32, 16), (32, 32), (16, 64), (32, 48)])
 def test_split_bf16_weight_gradient(dev, monkeypatch, cin, cout, kind):
-    """conv3d_bf16x3_wgrad_kernel<1, 4> / <2, 2> (the default; ICL_WGRAD_SPLIT=0 = fp32 MFMA): the weight gradient from split products is as close
+    """conv3d_wgrad_zs_kernel<1, 10> / <2, 8> / <3, 8> (the default at 48^3; ICL_WGRAD_SPLIT=0 = fp32 MFMA): the weight gradient from split products is as close
     to the fp64 gradient as the fp32-MFMA kernels' (both sum 110,592 voxels per element in fp32), for every operand class of
     _split_operands; errors per (cout, cin) filter so that the small filters of the wide-range case count."""
     from icl_amd import ops
@@ -1207,7 +1207,7 @@ def test_split_bf16_weight_gradient(dev, monkeypatch, cin, cout, kind):
             wg = w.to(dev).requires_grad_()
             ops.conv3d(x.to(dev), wg, None).backward(gy.to(dev))
         names = list(kt.summary())
-        assert any("bf16x3_wgrad" in k or "wgrad_tr" in k for k in names) == (split == "2"), names   # the path under test really ran
+        assert any("wgrad_tr" in k or "wgrad_zs" in k for k in names) == (split == "2"), names   # the path under test really ran
         assert torch.isfinite(wg.grad).all()
         d = (wg.grad.cpu().double() - wr.grad).abs().amax(dim=(2, 3, 4))
         scale = wr.grad.abs().amax(dim=(2, 3, 4))

@@ -88,6 +88,42 @@ def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w):
     assert e1 <= 3.0 * e0 + 2e-7 * float(ref.abs().max()), (e1, e0)
 
 
+@pytest.mark.parametrize("n,cin,cout,d,h,w,wgs", [
+    (2, 16, 16, 10, 16, 16, 3),     # one cout block; 2 samples x 2 columns x 10 tiles on three workgroups: runs that start inside a column and cross into the next
+    (1, 20, 32, 9, 8, 40, 2),       # two cout blocks, ragged cin block, three columns in x (the last one 8 of 16 wide), odd depth
+    (1, 16, 48, 8, 8, 16, 1),       # three cout blocks (one tile of loads in flight), one column walked by one workgroup
+    (2, 40, 16, 8, 16, 16, 0),      # three cin blocks (the last ragged); the launcher's own split: one tile per workgroup (prologue path only)
+])
+def test_conv3d_weight_gradient_walking_z_columns(monkeypatch, n, cin, cout, d, h, w, wgs):
+    """conv_wgrad_zs.h: 1 x 8 x 16 tiles walked down z with a ring of four halo planes in LDS — a phase stages only the plane the next
+    tile adds; a column's first tile stages its other two planes behind the barrier.  Against torch's weight gradient in fp64, and
+    against the 2 x 4 x 16-tile kernel (conv_wgrad_tr.h) to fp32 rounding.  Reference: nn.Conv3d backward, networks/utils.py:104."""
+    monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
+    monkeypatch.setenv("ICL_CONV_SPLIT", "1")
+    monkeypatch.setenv("ICL_WGRAD_SPLIT", "1")
+    monkeypatch.setenv("ICL_WGRAD_ZS", "1")
+    if wgs:
+        monkeypatch.setenv("ICL_WGRAD_ZS_MAX_WGS", str(wgs))
+    x = _rand((n, cin, d, h, w), 31)
+    gy = _rand((n, cout, d, h, w), 32)
+    wt = (_rand((cout, cin, 3, 3, 3), 33) * 0.2)
+
+    def wgrad():
+        wl = wt.clone().requires_grad_()
+        ops.conv3d(x, wl, None).backward(gy)
+        return wl.grad
+
+    g1 = wgrad()
+    monkeypatch.setenv("ICL_WGRAD_ZS", "0")
+    g0 = wgrad()
+    wr = wt.double().requires_grad_()
+    F.conv3d(x.double(), wr, None, padding=1).backward(gy.double())
+    scale = float(wr.grad.abs().max())
+    e1, e0 = float((g1.double() - wr.grad).abs().max()), float((g0.double() - wr.grad).abs().max())
+    assert e1 < 2e-6 * scale + 3.0 * e0, (e1, e0, scale)
+    assert not torch.equal(g1, g0) or n * d * h * w < 2048      # the two kernels sum in different orders: equal bits would mean the switch did nothing
+
+
 @pytest.mark.parametrize("n,cin,cout,d,h,w", [
     (2, 16, 16, 8, 8, 16),      # one cout block: the loader-wave kernel; two samples, one XCD share each... (16 tiles: 2 per XCD)
     (1, 32, 40, 5, 9, 20),      # three cout blocks (ragged), partial tiles in z / y / x: values outside the volume must not be counted
