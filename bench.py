@@ -51,7 +51,9 @@ PIPE_BUSY = {"conv3d_mfma_fwd_static_kernel": 0.81, "conv3d_bf16x3_fwd_kernel<1,
              # variant 60 (profiles/r3_pmc_conv.md, second table)
              "conv3d_bf16x3_fwd_kernel<1, 8, 60>": 0.56, "conv3d_bf16x3_fwd_kernel<2, 8, 60>": 0.55, "conv3d_bf16x3_fwd_kernel<3, 8, 60>": 0.66,
              # round 4 (profiles/r4_pmc_conv.md): the loader-wave kernel for one cout block
-             "conv3d_bf16x3_fwd_ws_kernel<1>": 0.66}
+             "conv3d_bf16x3_fwd_ws_kernel<1>": 0.66,
+             # round 5 (profiles/r5_pmc_conv.md, second table): the weight gradient walking z-columns
+             "conv3d_wgrad_zs_kernel<1, 10>": 0.52, "conv3d_wgrad_zs_kernel<2, 8>": 0.50}
 
 
 def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
