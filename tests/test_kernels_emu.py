@@ -893,7 +893,7 @@ def test_deferred_instance_norm_equals_the_materialised_path(monkeypatch):
     normalised tensors (ICL_LAZY_NORM=0)."""
     from icl_amd.networks.layers import Conv3d, UnetConv3, UnetUp3_CT
     monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
-    x = _rand((2, 1, 16, 16, 16), 21)
+    x = _rand((2, 1, 8, 16, 16), 21)
 
     class Mini(torch.nn.Module):
         def __init__(self):
@@ -914,7 +914,7 @@ def test_deferred_instance_norm_equals_the_materialised_path(monkeypatch):
 
     def run(lazy, p):
         monkeypatch.setenv("ICL_LAZY_NORM", "1" if lazy else "0")
-        monkeypatch.setenv("ICL_LAZY_NORM_MIN", "64")
+        monkeypatch.setenv("ICL_LAZY_NORM_MIN", "32")
         torch.manual_seed(5)
         model = Mini()
         packed = ops.PackedWeights()
@@ -929,7 +929,7 @@ def test_deferred_instance_norm_equals_the_materialised_path(monkeypatch):
             packed.end_step()
         return y.detach(), xin.grad.clone(), {k: q.grad.clone() for k, q in model.named_parameters() if q.grad is not None}, kinds
 
-    for p in (0.0, 0.3):
+    for p in (0.3,):      # (without dropout: test_lazy_final_convolution_fused_kernels[0.0] and every GPU golden test)
         y0, gx0, g0, k0 = run(False, p)
         y1, gx1, g1, k1 = run(True, p)
         assert k0 == [False, False, False] and k1 == [True, True, True], (k0, k1)          # the deferred path really ran
