@@ -53,6 +53,7 @@ PY
         T=$(find "$O/tl_prof" -name "*kernel_trace.csv" | head -1)
         python3 tools/timeline.py "$T" 3 0.25 > "$O/timeline.txt" 2>&1
         python3 tools/queue_tail.py "$T" 70 > "$O/queue_tails.txt" 2>&1      # the tails of the backward chains, per hardware queue
+        python3 tools/step_trace.py "$T" 2 > "$O/step_trace.txt" 2>&1                   # every kernel of one replayed step
         rm -f "$T"; head -60 "$O/timeline.txt" ;;
     pmc)
         for spec in "f16 16 16 96 fwd" "f48 48 16 96 fwd" "f32 32 32 48 fwd" "f4848 48 48 96 fwd" "w16 16 16 96 wgrad" "w32 32 32 48 wgrad"; do
