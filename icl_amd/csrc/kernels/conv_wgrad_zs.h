@@ -24,6 +24,17 @@
 // of one XCD are adjacent, so neighbouring columns (which share the cache lines of their x halos) meet in one L2.
 // One packed slab per workgroup, reduced in a fixed order by reduce_unpack_wgrad_kernel like the other weight-gradient kernels.
 // Reference op: the weight gradient of nn.Conv3d(k=3, pad=1) in UnetConv3 (/root/reference/code/networks/utils.py:104,107).
+//
+// Measured (round 5, batch 2, tools/probe/conv_wgrad_zs_probe.hip, against conv3d_wgrad_tr_kernel; profiles/r5_wgrad_zs_probe_*.txt):
+// 16->16 @96^3 148 vs 170 us, 48->16 436 vs 520, 32->16 282 vs 341, 48->48 (three cout blocks) 1038 vs 1314; 96->32 @48^3 183 vs 194,
+// 32->32 77 vs 76, 64->64 @24^3 50 vs 51.  Matrix pipe busy 40 -> 52 % (16->16 @96^3), 49 -> 50 % (32->32 @48^3); vector instructions
+// 27.7 -> 18.2 M per launch.  A phase is ~5.1 k cycles for 2.6 k of matrix-pipe time; multiply-only builds keep the pipe 93 % busy,
+// staging-only builds need 2.4 k per phase, and the two add up — also with four dedicated staging waves (12 waves, 159 us), at any
+// staging priority.  With operands that arrive pre-split (three 16-byte loads + three LDS stores per item, no vector arithmetic:
+// profiles/r5_wgrad_zs_probe_planes.txt) the kernel is only 1.09-1.17x faster: what is left beside the MFMAs is the ~60-100 cycles a
+// vector-memory instruction costs its SIMD there, not the split.  Dropped on the way: scalar-offset loads with the cursor advanced inside
+// the branch on the wave's role (the compiler made every load a readfirstlane loop: 175 us), a wave-uniform role (scalar-branch code
+// paths: 137 / 728 spilled registers with two / three cout blocks), all prologue loads in flight together (no change).
 #pragma once
 
 namespace icl {
