@@ -1187,6 +1187,34 @@ def test_split_bf16_convolution_propagates_non_finite_inputs(dev, monkeypatch, b
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,cin,cout,d,h,w", [
+    (2, 16, 16, 64, 128, 128),      # AMOS-like patch: eight x-columns, one cout block (ten-wave kernel), long z runs that cross columns
+    (1, 20, 32, 40, 80, 80),        # ragged cin block, five x-columns, two cout blocks
+    (1, 48, 48, 24, 48, 40),        # three cout blocks; W = 40: the third x-column is half empty
+    (2, 32, 16, 17, 8, 16),         # odd depth, one column per sample (2176 voxels: just above the split-product threshold)
+])
+def test_weight_gradient_kernels_agree_on_non_cubic_volumes(dev, monkeypatch, n, cin, cout, d, h, w):
+    """conv3d_wgrad_zs_kernel (z-column walk, round 5) against conv3d_wgrad_tr_kernel (2 x 4 x 16 tiles, round 3) on volumes that are not
+    the benchmark's cubes: both form the same products and differ only in the order of their fp32 sums — 2e-6 of the largest |dW| (the
+    accuracy statement proper, against fp64, is test_split_bf16_weight_gradient).  Reference: nn.Conv3d backward, networks/utils.py:104."""
+    from icl_amd import ops
+    x = synthetic_volume((n, cin, d, h, w), 411).to(dev)
+    gy = (synthetic_volume((n, cout, d, h, w), 412) * 0.01).to(dev)
+    wt = (synthetic_volume((cout, cin, 3, 3, 3), 413) * 0.1).to(dev)
+    got = {}
+    for zs in ("1", "0"):
+        monkeypatch.setenv("ICL_WGRAD_ZS", zs)
+        with ops.KernelTimer() as kt:
+            wl = wt.clone().requires_grad_()
+            ops.conv3d(x, wl, None).backward(gy)
+        names = list(kt.summary())
+        assert any(("wgrad_zs" if zs == "1" else "wgrad_tr") in k for k in names), names
+        got[zs] = wl.grad.detach().double().cpu()
+    scale = float(got["0"].abs().max())
+    assert scale > 0 and float((got["1"] - got["0"]).abs().max()) < 2e-6 * scale
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["normal", "positive", "wide", "denormal"])
 @pytest.mark.parametrize("cin,cout", [(32, 16), (32, 32), (16, 64), (32, 48)])
 def test_split_bf16_weight_gradient(dev, monkeypatch, cin, cout, kind):
