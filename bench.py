@@ -45,6 +45,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md dense bf16 matrix peak
 # speed of light in ALGORITHMIC (fp32) FLOP/s is therefore the bf16 peak / 6.
 SPLIT_TERMS = 6
 # matrix-pipe busy fraction of the kernel's cycles, PMC (profiles/r3_pmc_conv.md; <2, 8> / <3, 8>: profiles/r2_pmc_conv.md), static
+# profiles/r5_pmc_conv.md: 0.2191 M kernel cycles for a 127 us isolated launch (16->16 @96^3)
+KERNEL_CLOCK_GHZ = {"conv3d_bf16x3_fwd_ws_kernel<1>": 1.72}
 PIPE_BUSY = {"conv3d_mfma_fwd_static_kernel": 0.81, "conv3d_bf16x3_fwd_kernel<1, 8, 8>": 0.50, "conv3d_bf16x3_fwd_kernel<2, 8, 8>": 0.52,
              "conv3d_bf16x3_fwd_kernel<3, 8, 8>": 0.62, "conv3d_wgrad_tr_kernel<1>": 0.44, "conv3d_wgrad_tr_kernel<2>": 0.49,
              "conv3d_bf16x3_fwd_kernel<1, 8, 24>": 0.52,
@@ -522,6 +524,9 @@ def main():
                     # PMC (profiles/r3_pmc_conv.md, static): fraction of the kernel's cycles with the matrix pipe busy; the rest of
                     # the gap to the 2.4 GHz peak is the clock the chip holds under matrix load (1.8-2.1 GHz)
                     "matrix_pipe_busy_static_profile": busy,
+                    # kernel cycles (SQ_BUSY_CYCLES / 32) / duration of the isolated launch in the same PMC profile: the clock the chip holds
+                    # under this kernel; `peak` is a 2.4 GHz figure, so frac ~= pipe busy x clock / 2.4 (x what the lanes take in the step)
+                    **({"kernel_clock_ghz_static_profile": KERNEL_CLOCK_GHZ[name]} if name in KERNEL_CLOCK_GHZ else {}),
                     "launches_per_step": n // 3, "avg_launch_us": round(ms * 1e3 / n, 2),
                     # what the event pair itself adds to a bracketed launch on the idle eager stream (NOT subtracted above: the raw
                     # durations are the conservative ones; rocprofv3's per-kernel averages in profiles/ are shorter by about this much)
