@@ -1549,23 +1549,43 @@ class DeferredBiasGrads:
     all column sums in ONE launch and assigns (or accumulates into) ``bias.grad``.  Closed, every bias gradient is reduced on
     the spot as usual."""
     pending = None
+    producers = None      # the streams the queued tensors were produced on (the aligner lanes): flush() orders its stream after them
 
     @classmethod
     def begin(cls):
         cls.pending = []
+        cls.producers = set()
+
+    @classmethod
+    def note_producer(cls, t):
+        """The queued tensor is written by work on the CURRENT stream; flush() runs on the step's stream.  Autograd joins the streams of
+        the AccumulateGrad nodes that ran — a lane whose parameters are all deferred or adopted is none of them — so the flush orders
+        itself after every producing stream explicitly (round 5)."""
+        if cls.producers is not None and t.is_cuda:
+            cls.producers.add(torch.cuda.current_stream(t.device))
 
     @classmethod
     def defer(cls, bias, g2) -> bool:
         if cls.pending is None or not isinstance(bias, torch.nn.Parameter) or g2.shape[0] >= LINEAR_WGRAD_MIN_ROWS:
             return False
-        cls.pending.append((bias, g2.contiguous()))
+        g2 = g2.contiguous()
+        cls.pending.append((bias, g2))
+        cls.note_producer(g2)
         return True
 
     @classmethod
     def flush(cls):
         items, cls.pending = cls.pending, None
+        producers, cls.producers = cls.producers, None
         if not items:
             return
+        if producers:
+            here = torch.cuda.current_stream(items[0][1].device)
+            for s in producers:
+                if s != here:
+                    here.wait_stream(s)
+            for _, g in items:
+                g.record_stream(here)
         L = _lib.lib()
         n = len(items)
         sizes = [g.shape[1] for _, g in items]
@@ -1814,6 +1834,7 @@ class _LayerNorm(torch.autograd.Function):
             part = ws[:(ws.numel() // (2 * c)) * 2 * c].view(2, -1, c)
             DeferredBiasGrads.pending.append((ctx.params[0], part[0]))
             DeferredBiasGrads.pending.append((ctx.params[1], part[1]))
+            DeferredBiasGrads.note_producer(part)
         return gx, dg, db, None
 
 

@@ -173,6 +173,7 @@ class FusedSGD(torch.optim.Optimizer):
         else:
             BatchNormAct.deferred = None
             ops.DeferredBiasGrads.pending = None
+            ops.DeferredBiasGrads.producers = None
         self._scope_packed.end_step()
         self._scope_open = False
 
