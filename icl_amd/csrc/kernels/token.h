@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wgrad_kernel(const float* _
                                                                   float* __restrict__ part_g, float* __restrict__ part_b, long rows, int C,
                                                                   long rpb) {
   __shared__ float fold[2][3][64 * CPL];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  int wid = threadIdx.x >> 6;
+  ICL_WAVE_UNIFORM(wid);      // the row walk below is scalar control flow
   const long r0 = (long)blockIdx.x * rpb;
   const long r1 = r0 + rpb < rows ? r0 + rpb : rows;
   float a[CPL], b[CPL], gam[CPL];
@@ -185,16 +187,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wgrad_kernel(const float* _
       s1[u] = wave_sum(s1[u]) / (float)C;
       s2[u] = wave_sum(s2[u]) / (float)C;
     }
+    // b[k] is pinned in its own register after every add (ICL_PIN1: an empty asm, no instruction).  Round 5: without it the compiler
+    // packs the two columns' `b += gv` into one v_pk_add_f32 whose halves are crossed (op_sel:[0,1] op_sel_hi:[1,0]) and whose
+    // destination pair is also its second source; with kernels of other streams running beside this one (the aligner lanes) ONE row's
+    // term then went missing from b[0] in lanes 48..63 in a few chunks of most launches — the same row's gx and its dgamma term, computed
+    // from the same register, were exact (tests/diag/lane_dev_where.py; 21 of 30 steps with the packed add, 0 of 20 with the plain
+    // v_add_f32; the wave-uniform row walk alone did not change it).  Mechanism not established; DESIGN.md section 8.
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-      if (rb + u >= r1) break;
-      float* o = gx + (rb + u) * C;
+      if (rb + u < r1) {
+        float* o = gx + (rb + u) * C;
 #pragma unroll
-      for (int k = 0; k < CPL; ++k) {
-        const int c = lane + 64 * k;
-        if (c < C) o[c] = rs[u] * (gv[u][k] * gam[k] - s1[u] - xh[u][k] * s2[u]);
-        a[k] += gv[u][k] * xh[u][k];
-        b[k] += gv[u][k];
+        for (int k = 0; k < CPL; ++k) {
+          const int c = lane + 64 * k;
+          if (c < C) o[c] = rs[u] * (gv[u][k] * gam[k] - s1[u] - xh[u][k] * s2[u]);
+          a[k] += gv[u][k] * xh[u][k];
+          b[k] += gv[u][k];
+          ICL_PIN1(b[k]);
+        }
       }
     }
   }

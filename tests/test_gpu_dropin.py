@@ -247,11 +247,7 @@ def test_one_line_swap_with_graph_replay_equals_the_eager_swap(compat_root):
     assert results[True][2], results[True][3]
     la, lb = results[False][0], results[True][0]
     assert np.allclose(la, lb, rtol=1e-5, atol=1e-6), (la, lb)
-    # (the two bias vectors of tests/test_gpu_parity.py KNOWN_LANE_DEVIATION: their gradient may differ in 16 elements by a few per cent
-    # between any two runs with the aligner lanes on — five steps at lr 0.01 move them by up to ~5e-6)
-    from test_gpu_parity import KNOWN_LANE_DEVIATION
-    bad = [k for k in results[False][1] if not torch.allclose(results[False][1][k], results[True][1][k], rtol=1e-5,
-                                                               atol=5e-6 if k in KNOWN_LANE_DEVIATION else 1e-7)]
+    bad = [k for k in results[False][1] if not torch.allclose(results[False][1][k], results[True][1][k], rtol=1e-5, atol=1e-7)]
     assert not bad, bad[:8]
 
 
