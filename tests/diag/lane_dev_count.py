@@ -17,7 +17,8 @@ vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
 lab = synthetic_labels((1, 96, 96, 96), 4242, nc).to(dev)
 KEYS = ("uscl.norm_layers.1.bias", "uscl.class_decoders.1.norm1.bias")
 res = []
-for side, lanes in [(False, 0)] + [(True, 3)] * n:
+LANES = int(os.environ.get("LANES", "3"))
+for side, lanes in [(False, 0)] + [(True, LANES)] * n:
     ops.SideStream.enabled, ops.SideStream.lanes = side, lanes
     ops.StepRNG.tensor = None
     if which == "swin":
@@ -49,4 +50,4 @@ for g in res[1:]:
             else:
                 other += 1
     bad += hit
-print(f"LANEDEV {which} env={os.environ.get('ICL_LN_DBG', '-')}/{os.environ.get('AMD_OPT_FLUSH', '-')}/{os.environ.get('TAG', '-')}: {bad} of {n} lane steps deviate; other keys differing: {other}; {' '.join(detail)}")
+print(f"LANEDEV {which} lanes={LANES} wgrad_lane={os.environ.get('ICL_WGRAD_LANE', '-')} lib={'packed' if 'packed' in os.environ.get('ICL_HIP_LIB', '') else 'shipped'} env={os.environ.get('ICL_LN_DBG', '-')}/{os.environ.get('AMD_OPT_FLUSH', '-')}/{os.environ.get('TAG', '-')}: {bad} of {n} lane steps deviate; other keys differing: {other}; {' '.join(detail)}")
