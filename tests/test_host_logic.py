@@ -115,3 +115,34 @@ def test_bench_self_launches_its_ranks_and_relays_rank0_json():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 2 and f"{torch.cuda.device_count()} HIP device(s)" in r.stderr and r.stdout.strip() == ""
+
+
+def test_layernorm_backward_keeps_its_bias_sums_out_of_packed_adds(tmp_path):
+    """Round 5: with `b[k] += gv` packed into one `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (halves crossed,
+    destination pair = second source) layernorm_bwd_wgrad_kernel lost one row's term of dbeta in lanes 48..63 under concurrent streams.
+    The source pins b[k] after every add; this checks what the compiler makes of it, on the device assembly of every instantiation the
+    launcher uses: no packed add of that form, and the bias sums are plain v_add_f32."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc on this host")
+    csrc = os.path.join(ROOT, "icl_amd", "csrc")
+    sig = "(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long, int, long)"
+    insts = [(1, 4), (2, 4), (4, 2), (8, 1), (16, 1)]          # icl_abi.inc ICL_LN_BW
+    src = tmp_path / "ln.hip"
+    src.write_text('#include <hip/hip_runtime.h>\n#include "device_env_hip.h"\n#include "kernels/common.h"\n#include "kernels/token.h"\n'
+                   + "".join(f"template __global__ void icl::layernorm_bwd_wgrad_kernel<{c}, {r}>{sig};\n" for c, r in insts))
+    out = tmp_path / "ln.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", csrc, "-S", "--cuda-device-only", "-o", str(out), str(src)],
+                          stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    seen = 0
+    for m in re.finditer(r"^(_ZN3icl26layernorm_bwd_wgrad_kernel\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        seen += 1
+        body = m.group(2)
+        crossed = [ln for ln in body.splitlines() if "v_pk_add_f32" in ln and "op_sel:[0,1] op_sel_hi:[1,0]" in ln]
+        assert not crossed, (m.group(1), crossed[:2])
+        assert body.count("v_add_f32") >= 8, m.group(1)
+    assert seen == len(insts), seen
