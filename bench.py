@@ -382,9 +382,15 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.step(vol, lab)
+        last = trainer.step(vol, lab)
     barrier()
     dt = time.perf_counter() - t0
+    # a step timed on garbage is not a measurement (and runs FASTER: operands that do not toggle draw less power, the chip clocks higher —
+    # profiles/r5_wgrad_defer_ab.txt): the last loss and every parameter must be finite after the timed region
+    last_loss = float(last["loss"]) if isinstance(last, dict) and "loss" in last else float("nan")
+    params_finite = all(bool(torch.isfinite(p).all()) for p in trainer.model.parameters())
+    if not (last_loss == last_loss and abs(last_loss) != float("inf") and params_finite):
+        raise SystemExit(f"bench.py: the timed steps ended in a non-finite state (loss {last_loss}, parameters finite: {params_finite}); no number reported")
     if use_ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -600,6 +606,7 @@ def main():
                        "launch": ("eager" if not graphed else "hipGraph replay" if ddp is None else
                                   "hipGraph replay (forward/backward, optimiser) + eager RCCL collectives"),
                        **({"launch_probe": launch_probe} if launch_probe else {}),
+                       "finite_after_timed_steps": {"last_loss": round(last_loss, 6), "parameters": params_finite},
                        # every tensor, accumulator and result is fp32.  With ICL_CONV_SPLIT on (default) the 3x3x3 forward / input-
                        # gradient products of the large layers are formed from exact three-way bf16 splits of the fp32 operands (six
                        # bf16 MFMA terms per product, fp32 accumulate): outputs as close to fp64 as the fp32 MFMA kernels'
