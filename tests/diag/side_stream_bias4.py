@@ -1,4 +1,5 @@
-"""dY of the level-1 LayerNorm layers and the bias gradients that come out, single stream against lanes."""
+"""dY of the level-1 LayerNorm layers and the bias gradients that come out, single stream against lanes.  (The `DeferredBiasGrads.dbg` hook it
+reads was a temporary probe in ops.py and is gone; without it the script prints the gradient comparison only.)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,6 @@
-"""Which tensors differ between two identical two-step SwinUNETR-ICL runs (tests/test_gpu_parity.py::test_swinunetr_icl_steps_are_bit_reproducible)?"""
+"""Which tensors differ between identical SwinUNETR-ICL runs (tests/test_gpu_parity.py::test_swinunetr_icl_steps_are_bit_reproducible)?
+Usage: swin_repro_diff.py [steps]   (0: gradients of one forward/backward; n: the state after n trainer steps).  Round 5: located the
+gradient a deferred weight-gradient lane left uninitialised (profiles/r5_wgrad_defer_ab.txt)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,6 +39,6 @@ for i in range(1, 4):
             d = (runs[0][k].double() - runs[i][k].double()).abs()
             idx = (d > 0).nonzero()
             diff.append(f"{k} {tuple(runs[0][k].shape)}: {int((d > 0).sum())} elements, max {float(d.max()):.3e} of {float(runs[0][k].abs().max()):.3e}, first at {idx[0].tolist()} last at {idx[-1].tolist()}")
-    print(f"SWINDIFF defer={os.environ.get('ICL_WGRAD_DEFER', '1')} run {i} vs 0: {len(diff)} tensors differ")
+    print(f"SWINDIFF run {i} vs 0: {len(diff)} tensors differ")
     for l in diff[:12]:
         print("   ", l)
