@@ -2,7 +2,7 @@
 //
 // The build container has no GPU, so every kernel in icl_amd/csrc/kernels/*.h is written
 // against a small device environment (csrc/device_env_hip.h for the product).  This header
-// is the second implementation of that environment: each "GPU thread" is a ucontext fiber,
+// is the second implementation of that environment: each "GPU thread" is a fiber (own stack; see "Fiber switch" below),
 // a workgroup is a set of fibers stepped cooperatively, __syncthreads() and the wave-wide
 // collectives (shuffles, MFMA) are rendezvous points.  Blocks run sequentially per OS
 // thread and are spread over OS threads.  It is slow and only meant for tiny shapes:
@@ -63,15 +63,61 @@ namespace hipemu {
 constexpr int kWave = 64;
 constexpr size_t kStack = 256 * 1024;
 
+// Fiber switch.  glibc's swapcontext / getcontext save and restore the signal mask with a system call each — a quarter of the CPU suite's
+// time went there (23 of ~100 CPU-minutes in the kernel).  On x86-64 the switch is the textbook one instead: push the callee-saved
+// registers and the two floating-point control words, exchange stack pointers, pop, return; a new fiber's stack is laid out so that the
+// first switch "returns" into its entry function.  Elsewhere: ucontext as before.
+#if defined(__x86_64__)
+#define HIPEMU_ASM_SWITCH 1
+struct Ctx { void* sp = nullptr; };
+extern "C" void hipemu_switch(Ctx* from, Ctx* to);
+__asm__(
+    ".text\n"
+    ".globl hipemu_switch\n"
+    ".type hipemu_switch,@function\n"
+    "hipemu_switch:\n"
+    "    pushq %rbp\n    pushq %rbx\n    pushq %r12\n    pushq %r13\n    pushq %r14\n    pushq %r15\n"
+    "    subq $8, %rsp\n    stmxcsr (%rsp)\n    fnstcw 4(%rsp)\n"
+    "    movq %rsp, (%rdi)\n"
+    "    movq (%rsi), %rsp\n"
+    "    ldmxcsr (%rsp)\n    fldcw 4(%rsp)\n    addq $8, %rsp\n"
+    "    popq %r15\n    popq %r14\n    popq %r13\n    popq %r12\n    popq %rbx\n    popq %rbp\n"
+    "    ret\n"
+    ".size hipemu_switch,.-hipemu_switch\n");
+inline void ctx_switch(Ctx* from, Ctx* to) { hipemu_switch(from, to); }
+inline void ctx_make(Ctx* c, char* stack, size_t size, void (*entry)()) {
+  uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+  uint64_t* sp = (uint64_t*)(top - 16);      // the return address sits 16 below a 16-byte boundary: rsp % 16 == 8 at entry, as after a call
+  *sp = (uint64_t)(uintptr_t)entry;
+  for (int i = 0; i < 6; ++i) *--sp = 0;      // rbp, rbx, r12..r15
+  --sp;
+  uint32_t* cw = (uint32_t*)sp;
+  cw[0] = 0x1F80;                             // mxcsr: all exceptions masked, round to nearest
+  cw[1] = 0x037F;                             // x87 control word (low 16 bits are loaded)
+  c->sp = sp;
+}
+#else
+#define HIPEMU_ASM_SWITCH 0
+struct Ctx { ucontext_t uc; };
+inline void ctx_switch(Ctx* from, Ctx* to) { swapcontext(&from->uc, &to->uc); }
+inline void ctx_make(Ctx* c, char* stack, size_t size, void (*entry)()) {
+  getcontext(&c->uc);
+  c->uc.uc_stack.ss_sp = stack;
+  c->uc.uc_stack.ss_size = size;
+  c->uc.uc_link = nullptr;
+  makecontext(&c->uc, entry, 0);
+}
+#endif
+
 struct Fiber {
-  ucontext_t ctx;
+  Ctx ctx;
   char* stack = nullptr;
   int state = 0;  // 0 runnable, 1 wait-block, 2 wait-wave, 3 done
   dim3 tid;
 };
 
 struct Worker {
-  ucontext_t sched;
+  Ctx sched;
   std::vector<Fiber> fibers;
   int cur = -1;
   int nthreads = 0;
@@ -88,14 +134,15 @@ inline void trampoline() {
   Worker* w = W;
   (*w->body)();
   w->fibers[w->cur].state = 3;
-  swapcontext(&w->fibers[w->cur].ctx, &w->sched);
+  ctx_switch(&w->fibers[w->cur].ctx, &w->sched);
+  __builtin_unreachable();      // a finished fiber is never scheduled again
 }
 
 inline void yield_state(int st) {
   Worker* w = W;
   Fiber& f = w->fibers[w->cur];
   f.state = st;
-  swapcontext(&f.ctx, &w->sched);
+  ctx_switch(&f.ctx, &w->sched);
   g_threadIdx = f.tid;  // restored by scheduler too; belt and braces
 }
 
@@ -113,11 +160,7 @@ inline void run_block(Worker* w, dim3 bid, dim3 block) {
     Fiber& f = w->fibers[i];
     f.state = 0;
     f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack;
-    f.ctx.uc_stack.ss_size = kStack;
-    f.ctx.uc_link = &w->sched;
-    makecontext(&f.ctx, (void (*)())trampoline, 0);
+    ctx_make(&f.ctx, f.stack, kStack, trampoline);
   }
   for (;;) {
     bool progressed = false;
@@ -128,7 +171,7 @@ inline void run_block(Worker* w, dim3 bid, dim3 block) {
       if (f.state != 0) continue;
       w->cur = i;
       g_threadIdx = f.tid;
-      swapcontext(&w->sched, &f.ctx);
+      ctx_switch(&w->sched, &f.ctx);
       progressed = true;
     }
     if (done == n) break;
