@@ -563,7 +563,22 @@ class _Conv3d(torch.autograd.Function):
                     _lib.check(L.icl_conv1x1_wgrad(_ptr(planes), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin * 27, cout, s,
                                                    cin * 27 * s, cout * s, _stream(x)), "conv1x1_wgrad")
             else:
+                # One cout block but three (or six, nine ...) cin blocks — up_concat1.conv1, 48 -> 16 @96^3, the U-Net's largest weight
+                # gradient: with the roles of x and dY exchanged, dW[co][ci][t] = sum_q dY[co][q - t] x[ci][q], the z-column kernel stages
+                # ONE halo'd dY block for three x blocks instead of one halo'd x block per dY block (matrix pipe 52 -> 68 %,
+                # profiles/r5_pmc_conv.md); the result comes out as [cin][cout] with mirrored taps and is written back by two tiny copies.
+                swap = (ks == 3 and gb_arg is None and cout == 16 and cin % 48 == 0 and h % 8 == 0 and d >= 8 and w % 4 == 0
+                        and s >= WGRAD_SWAP_MIN_VOXELS and os.environ.get("ICL_WGRAD_SWAP", "1") != "0")
+
                 def wgrad():
+                    if swap:
+                        ws = _ws(L.icl_conv3d_wgrad_ws_bytes(n, cout, cin, ks), x)
+                        gws = torch.empty((cin, cout, ks, ks, ks), dtype=torch.float32, device=x.device)
+                        with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):
+                            _lib.check(L.icl_conv3d_wgrad(_ptr(gy), _ptr(x), _ptr(gws), None, _ptr(ws), n, cout, cin, d, h, w, ks,
+                                                          cout * s, cin * s, _stream(x)), "conv3d_wgrad (roles exchanged)")
+                        gw.copy_(gws.flip(2, 3, 4).transpose(0, 1))
+                        return
                     ws = _ws(L.icl_conv3d_wgrad_ws_bytes(n, cin, cout, ks), x)
                     with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):
                         _lib.check(L.icl_conv3d_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin, cout, d, h, w, ks,
@@ -603,6 +618,7 @@ class _Im2Col3(torch.autograd.Function):
 
 
 SMALL_CONV_MAX_VOXELS = 216      # 6^3
+WGRAD_SWAP_MIN_VOXELS = 24 ** 3    # exchanged-roles weight gradient (see _Conv3d.backward): only where the split-product kernels run
 SMALL_CONV_MIN_WEIGHTS = 128 * 128 * 27
 
 

@@ -969,3 +969,25 @@ def test_lazy_final_convolution_fused_kernels(p):
     ref = torch.clamp_min(t * ss[:, 0].view(n, cin, 1, 1, 1) + ss[:, 1].view(n, cin, 1, 1, 1), 0)
     if p == 0.0:
         assert rel_err(res[0][0], F.conv3d(ref, w, b)) < 2e-5
+
+
+def test_conv3d_weight_gradient_with_exchanged_roles(monkeypatch):
+    """One cout block, three cin blocks (up_concat1.conv1's class, 48 -> 16): ops._Conv3d.backward hands dY to the z-column weight-gradient
+    kernel as the halo operand and x as the three plain blocks, and writes the [cin][cout] result back transposed with mirrored taps.
+    Against torch, with the bias gradient off (the convolution feeds an InstanceNorm: zero_bias_grad) — and equal to the direct path."""
+    monkeypatch.setattr(ops, "WGRAD_SWAP_MIN_VOXELS", 1)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ICL_WGRAD_SWAP", flag)
+        x = _rand((1, 48, 8, 8, 16), 41, True)
+        wt = (_rand((16, 48, 3, 3, 3), 42) * 0.2).requires_grad_()
+        b = (_rand((16,), 43) * 0.1).requires_grad_()
+        gy = _rand((1, 16, 8, 8, 16), 44)
+        y = ops.conv3d(x, wt, b, zero_bias_grad=True)
+        y.backward(gy)
+        got[flag] = wt.grad.clone()
+        xr, wr = x.detach().clone().requires_grad_(), wt.detach().clone().requires_grad_()
+        F.conv3d(xr, wr, b.detach(), padding=1).backward(gy)
+        assert rel_err(wt.grad, wr.grad) < 1e-5 and rel_err(x.grad, xr.grad) < 1e-5, flag
+        assert float(b.grad.abs().max()) == 0.0
+    assert rel_err(got["1"], got["0"]) < 1e-6
