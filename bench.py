@@ -55,7 +55,9 @@ PIPE_BUSY = {"conv3d_mfma_fwd_static_kernel": 0.81, "conv3d_bf16x3_fwd_kernel<1,
              # round 4 (profiles/r4_pmc_conv.md): the loader-wave kernel for one cout block
              "conv3d_bf16x3_fwd_ws_kernel<1>": 0.66,
              # round 5 (profiles/r5_pmc_conv.md, second table): the weight gradient walking z-columns
-             "conv3d_wgrad_zs_kernel<1, 10>": 0.52, "conv3d_wgrad_zs_kernel<2, 8>": 0.50}
+             "conv3d_wgrad_zs_kernel<1, 10>": 0.52, "conv3d_wgrad_zs_kernel<2, 8>": 0.50,
+             # (third table) three cout blocks — in the U-Net the exchanged-roles weight gradient of 48 -> 16
+             "conv3d_wgrad_zs_kernel<3, 8>": 0.68}
 
 
 def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
