@@ -50,6 +50,15 @@ class _Identity(nn.Module):
         return x
 
 
+def _hooked(*modules) -> bool:
+    """True when a forward / forward-pre hook is attached to one of the modules, or globally (nn.modules.module.register_module_*):
+    such hooks expect `Module.__call__` and a tensor output, so the callers below then take the materialised path."""
+    from torch.nn.modules import module as _m
+    if _m._global_forward_hooks or _m._global_forward_pre_hooks or getattr(_m, "_global_forward_hooks_always_called", None):
+        return True
+    return any(m._forward_hooks or m._forward_pre_hooks for m in modules)
+
+
 class ConvBlock(nn.Sequential):
     """Sequential(Conv3d, InstanceNorm3d, ReLU): keys '0.weight', '0.bias' (utils.py:104-106).
     Index 1 fuses norm+ReLU; index 2 is kept as a no-op so the child layout matches the reference."""
@@ -92,7 +101,11 @@ class UnetConv3(nn.Module):
     def forward(self, x, lazy: bool = False):
         """``lazy``: the output may be an ``ops.LazyAct`` (see ConvBlock.forward_lazy); the input may be one never."""
         h = self.conv1(x)
-        return self.conv2.forward_lazy(h) if lazy else self.conv2(h)
+        # the deferred form bypasses conv2's `__call__` and hands a LazyAct to whoever looks at this block's output: only when nothing
+        # is hooked on this block, on conv2 or globally (hooks on conv2's three children: ConvBlock._stock)
+        if lazy and not _hooked(self, self.conv2):
+            return self.conv2.forward_lazy(h)
+        return self.conv2(h)
 
 
 class UnetUp3_CT(nn.Module):
@@ -106,7 +119,7 @@ class UnetUp3_CT(nn.Module):
 
     def forward(self, skip, deep, lazy: bool = False):
         """``skip`` / ``deep`` may be ``ops.LazyAct`` (their normalisation is applied while the concat buffer is written)."""
-        return self.conv(ops.upsample2x_concat(skip, deep), lazy)
+        return self.conv(ops.upsample2x_concat(skip, deep), lazy and not _hooked(self))
 
 
 class Dropout3(nn.Module):

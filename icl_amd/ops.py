@@ -118,6 +118,33 @@ class SideStream:
 
 
 
+class BackwardEnd:
+    """End-of-backward work of a step scope that is NOT driven by ICLTrainer (FusedSGD's scope inside the unchanged reference loop).
+    The lane of the deep levels' weight gradients is joined and the deferred bias / LayerNorm gradients are reduced when the autograd
+    pass that produced them FINISHES (engine.queue_callback, armed by the first backward node that defers something), not in
+    ``optimizer.step()``: code between ``loss.backward()`` and ``step()`` — ``clip_grad_norm_``, gradient logging, a GradScaler — then
+    sees complete ``.grad`` tensors on the caller's stream.  ``hook`` is None unless such a scope is open."""
+    hook = None
+    _armed = False
+
+    @classmethod
+    def arm(cls):
+        if cls.hook is None or cls._armed:
+            return
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(cls._fire)
+            cls._armed = True
+        except RuntimeError:      # not inside a backward pass (a Function.backward called by hand): the scope's close does the work
+            pass
+
+    @classmethod
+    def _fire(cls):
+        cls._armed = False
+        h = cls.hook
+        if h is not None:
+            h()
+
+
 class WgradLane:
     """Weight gradients of the deep levels on a second stream.  From `up3` down (24^3, 12^3, 6^3) a layer's input-gradient and weight-gradient
     launches occupy 54-144 workgroups each on a chip of 256 CUs, and nothing else runs in that part of the backward pass (the aligner
@@ -174,6 +201,7 @@ class WgradLane:
             cls._stream = SideStream._streams.get((dev.index, 1)) or torch.cuda.Stream(device=dev)
         cls._stream.wait_stream(torch.cuda.current_stream(dev))
         cls._used = True
+        BackwardEnd.arm()
 
     @classmethod
     def on_lane(cls, *tensors):
@@ -1587,12 +1615,14 @@ class DeferredBiasGrads:
         g2 = g2.contiguous()
         cls.pending.append((bias, g2))
         cls.note_producer(g2)
+        BackwardEnd.arm()
         return True
 
     @classmethod
-    def flush(cls):
-        items, cls.pending = cls.pending, None
-        producers, cls.producers = cls.producers, None
+    def flush(cls, keep_open: bool = False):
+        """``keep_open``: reduce what is queued and stay open for the next backward pass of the same step scope (BackwardEnd)."""
+        items, cls.pending = cls.pending, ([] if keep_open else None)
+        producers, cls.producers = cls.producers, (set() if keep_open else None)
         if not items:
             return
         if producers:
@@ -1851,6 +1881,7 @@ class _LayerNorm(torch.autograd.Function):
             DeferredBiasGrads.pending.append((ctx.params[0], part[0]))
             DeferredBiasGrads.pending.append((ctx.params[1], part[1]))
             DeferredBiasGrads.note_producer(part)
+            BackwardEnd.arm()
         return gx, dg, db, None
 
 

@@ -20,13 +20,50 @@ SPLIT_MIN_ROWS = 192    # factor rows from which d = g^T x runs on split product
                         # but +2 small launches: a wash inside the step; 256 rows 1244 -> 1029 us, 512 rows 2158 -> 1770 us)
 
 
+_MODEL_OF = {}     # id(parameter) -> (weak reference to the parameter, weak reference to its model)
+
+
 def tag_model_parameters(model: torch.nn.Module) -> torch.nn.Module:
-    """Called by the model factories (networks/net_factory*.py): every parameter remembers the model it belongs to, so that an optimiser
-    built from ``model.parameters()`` alone — the one line of the reference trainers — can find the module to hook (FusedSGD step scope)."""
+    """Called by the model factories (networks/net_factory*.py): the model every parameter belongs to is remembered, so that an optimiser
+    built from ``model.parameters()`` alone — the one line of the reference trainers — can find the module to hook (FusedSGD step scope).
+    The map lives HERE, not on the tensors: a weak reference in a Parameter's ``__dict__`` made ``torch.save(model)`` / pickle of every
+    factory-built model raise.  Entries die with their parameter."""
     ref = weakref.ref(model)
     for p in model.parameters():
-        p._icl_model = ref
+        key = id(p)
+        _MODEL_OF[key] = (weakref.ref(p, lambda _, k=key: _MODEL_OF.pop(k, None)), ref)
     return model
+
+
+def model_of(p):
+    e = _MODEL_OF.get(id(p))
+    if e is None or e[0]() is not p:
+        return None
+    return e[1]()
+
+
+def _no_hook(module, args):
+    return None
+
+
+class _ScopePreHook:
+    """The forward pre-hook that opens FusedSGD's step scope.  A module-level class holding a weak reference (the model does not keep
+    its optimiser alive); pickling a hooked model stores a no-op in its place."""
+
+    def __init__(self, opt):
+        self.opt = weakref.ref(opt)
+
+    def __call__(self, module, args):
+        opt = self.opt()
+        if opt is not None:
+            opt._open_scope(module)
+
+    def __reduce__(self):
+        return (_load_no_hook, ())
+
+
+def _load_no_hook():
+    return _no_hook
 
 
 class FusedSGD(torch.optim.Optimizer):
@@ -62,18 +99,11 @@ class FusedSGD(torch.optim.Optimizer):
         self._train_calls = 0
         self._cap_stream = None      # the stream of every training forward before AND during the capture (see _install_graphed_forward)
         if step_scope:
-            models = {id(m): m for m in (getattr(p, "_icl_model", lambda: None)() for g in self.param_groups for p in g["params"])
-                      if m is not None}
+            models = {id(m): m for m in (model_of(p) for g in self.param_groups for p in g["params"]) if m is not None}
             if len(models) == 1:
                 (model,) = models.values()
                 self._scope_model = weakref.ref(model)
-                me = weakref.ref(self)
-
-                def pre_forward(module, args):
-                    opt = me()
-                    if opt is not None:
-                        opt._open_scope(module)
-                self._scope_hook = model.register_forward_pre_hook(pre_forward)
+                self._scope_hook = model.register_forward_pre_hook(_ScopePreHook(self))
                 if self._graph_on:
                     _install_graphed_forward(self, model)
         self.lr_dev = None   # optional device scalar read by the kernels instead of group['lr'] (hipGraph replay)
@@ -134,7 +164,20 @@ class FusedSGD(torch.optim.Optimizer):
         if self._graph_state is not None and not capturing:
             return                       # the captured graphs carry the scope's work; nothing runs eagerly
         if self._scope_open:
-            self.abandon_step()          # a forward pass whose backward / step never came
+            # A second training forward before step(): gradient accumulation over micro-batches, or several forward
+            # passes whose losses are summed before ONE backward.  The scope stays open — use counts, queued bias gradients and
+            # factored gradients keep accumulating, exactly as `.grad` does — and the packed weights are refreshed (one launch; the
+            # weights may have been touched between the calls).  The one thing that cannot continue: a backward pass that has already
+            # applied this step's update of the big matrices (update_in_backward) followed by another forward without step().
+            if self._updated_in_backward or self._deferred or self._update_stream_used:
+                raise RuntimeError(
+                    "FusedSGD: a training forward pass started after a backward pass that already applied this step's update of the "
+                    "token-axis matrices (update_in_backward=True) and before optimizer.step(): the second micro-batch would see "
+                    "half-updated weights.  Call optimizer.step() after every loss.backward(), or build the optimiser with "
+                    "update_in_backward=False for loops that accumulate gradients over several backward passes (or abandon_step() "
+                    "to discard a failed iteration)")
+            self._scope_packed.begin_step()
+            return
         if ops.PackedWeights.current is not None or ops.FactoredGrads.uses is not None:
             return                       # somebody else (ICLTrainer) has a step open
         if self._scope_packed is None:
@@ -142,25 +185,44 @@ class FusedSGD(torch.optim.Optimizer):
         self._scope_open = True
         self._scope_packed.begin_step()
         BatchNormAct.defer_counters()
-        ops.DeferredBiasGrads.begin()
-        ops.WgradLane.begin_step()
-        ops.WgradLane.open = True        # (only backward functions consult it)
         multi = False
         try:
             import torch.distributed as dist
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         except Exception:                # noqa: BLE001
             multi = False
+        ops.WgradLane.begin_step()
         self._scope_prev_factored = ops.FactoredGrads.enabled
-        if not multi:                    # data-parallel wrappers of an unchanged loop expect dense .grad tensors
+        self._scope_multi = multi
+        if not multi:
+            # single process: weight gradients of the deep levels on a lane, bias / LayerNorm gradients reduced by one launch — both
+            # completed when the backward pass ENDS (ops.BackwardEnd), so `.grad` is whole when loss.backward() returns
+            ops.DeferredBiasGrads.begin()
+            ops.WgradLane.open = True    # (only backward functions consult it)
+            me = weakref.ref(self)
+            ops.BackwardEnd.hook = lambda: (me() is not None and me()._end_of_backward())
             ops.FactoredGrads.enabled = True
             ops.FactoredGrads.world = 1
             ops.FactoredGrads.fused_optimizer = self if self._scope_update_in_backward else None
             ops.FactoredGrads.uses = {} if self._scope_update_in_backward else None
+        # multi-process (a data-parallel wrapper around the unchanged loop): dense `.grad` tensors that pass through autograd's own
+        # accumulation — a wrapper's accumulator hooks fire for every parameter and bucket nothing that another stream is still
+        # writing — so neither the lane nor the bias deferral nor the factored gradients are opened; packed weights and the
+        # BatchNorm counters (forward-only) still are
+
+    def _end_of_backward(self):
+        """Runs when an autograd pass that used the scope's lane / deferrals finishes (on the stream of the caller of backward())."""
+        from . import ops
+        if not self._scope_open:
+            return
+        ops.WgradLane.join()
+        if ops.DeferredBiasGrads.pending is not None:
+            ops.DeferredBiasGrads.flush(keep_open=True)
 
     def _close_scope(self, flush: bool = True):
         from . import ops
         from .networks.layers import BatchNormAct
+        ops.BackwardEnd.hook = None
         ops.WgradLane.join()
         ops.WgradLane.open = False
         ops.WgradLane.uses = None
@@ -169,7 +231,8 @@ class FusedSGD(torch.optim.Optimizer):
         ops.FactoredGrads.uses = None
         if flush:
             BatchNormAct.flush_counters()
-            ops.DeferredBiasGrads.flush()
+            if ops.DeferredBiasGrads.pending is not None:
+                ops.DeferredBiasGrads.flush()
         else:
             BatchNormAct.deferred = None
             ops.DeferredBiasGrads.pending = None
@@ -365,6 +428,11 @@ class FusedSGD(torch.optim.Optimizer):
                 loss = closure()
         if self._scope_open:
             self._close_scope()                 # lane joined, deferred bias gradients assigned, packed weights released
+        if self._graph_state is not None and self.lr_dev is not None and not (
+                self.lr_dev.is_cuda and torch.cuda.is_current_stream_capturing()):
+            # graph mode: a batch whose shape the graphs do not match ran eagerly — its update must not read the learning rate the
+            # last REPLAYED backward left in the device scalar
+            self.lr_dev.fill_(float(self.param_groups[0]["lr"]))
         self.flush_deferred(gate=True)      # a model without a gate hook: the updates start here
         if self._update_stream_used:
             torch.cuda.current_stream(self._update_stream.device).wait_stream(self._update_stream)
@@ -595,8 +663,21 @@ def _install_graphed_forward(opt, model):
                 o._graph_state = None
                 import warnings
                 warnings.warn(f"FusedSGD(graph=True): capture failed, staying eager: {e!r}")
+                # nothing of the aborted capture has run: drop every Python-side trace of it (queued updates, "updated in backward"
+                # marks, gradients and factors that point into the failed capture's pool, the device learning rate the captured
+                # kernels would have read) before the eager scope reopens — the loop's next zero_grad() / step() must find a clean
+                # optimiser
+                o._deferred = []
+                o._update_stream_used = False
+                o._updated_in_backward.clear()
                 if o._scope_open:
                     o._close_scope(flush=False)
+                for g_ in o.param_groups:
+                    for p_ in g_["params"]:
+                        p_.grad = None
+                        if getattr(p_, "_icl_factors", None) is not None:
+                            p_._icl_factors = None
+                o.lr_dev = None
                 o._open_scope(model)
                 return orig(*args)
             o._graph_state = st

@@ -797,7 +797,7 @@ def test_fused_sgd_step_scope_equals_the_plain_loop_with_torch_sgd():
     `FusedSGD(model.parameters(), ...)` — which finds the model through its tagged parameters and opens ICLTrainer's step scope (packed
     weights, factored token-axis gradients, deferred bias gradients, lane bookkeeping) from a forward pre-hook — leaves every parameter
     where `torch.optim.SGD` on dense gradients leaves it, over two iterations (momentum included); the scope is closed after `step()`,
-    an evaluation forward does not open it, and a forward whose step never comes is abandoned by the next one."""
+    an evaluation forward does not open it, and a forward whose step never comes leaves a scope that `abandon_step()` discards."""
     from icl_amd.networks.unet_3D_icl import unet_3D_icl
     from icl_amd.optim import FusedSGD, tag_model_parameters
     from icl_amd.utils import losses
@@ -845,7 +845,7 @@ def test_fused_sgd_step_scope_equals_the_plain_loop_with_torch_sgd():
                 assert ops.PackedWeights.current is None
                 model(vol[:1], vol[1:])                   # opens the scope; no backward, no step
                 assert ops.PackedWeights.current is not None
-                model(vol[:1], vol[1:])                   # ... the next forward abandons it and opens a fresh one
+                model(vol[:1], vol[1:])                   # ... the next forward keeps it open (round 6: accumulation; use counts continue)
                 assert ops.PackedWeights.current is not None
                 opt.abandon_step()
                 assert ops.PackedWeights.current is None and not ops.FactoredGrads.enabled
@@ -861,6 +861,122 @@ def test_fused_sgd_step_scope_equals_the_plain_loop_with_torch_sgd():
         assert not bad, bad[:8]
     finally:
         ops.FactoredGrads.min_elems = old_min
+
+
+@pytest.mark.timeout(1200)
+def test_fused_sgd_gradients_are_complete_after_backward_and_accumulate_over_micro_batches(monkeypatch):
+    """ADVICE round 5 (optim.py).  (1) When `loss.backward()` returns, every `.grad` is whole: the lane of the deep levels' weight gradients
+    is joined and the deferred bias / LayerNorm gradients are reduced by an end-of-backward callback (ops.BackwardEnd), not in `step()` —
+    code between backward and step (`clip_grad_norm_`, logging) sees what it sees with torch.optim.SGD.  (2) forward, backward, forward,
+    backward, step — gradient accumulation with `update_in_backward=False` — ends where torch.optim.SGD ends on the summed dense
+    gradients (factors, bias gradients and use counts keep accumulating; nothing is abandoned).  (3) With `update_in_backward=True` a
+    second forward after a backward that already updated the big matrices raises instead of training on half-updated weights.
+    (4) `torch.save`-style pickling of a factory-tagged, optimiser-hooked model works."""
+    import io
+    import pickle
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.optim import FusedSGD, model_of, tag_model_parameters
+    from icl_amd.utils import losses
+    from icl_amd.utils.hashfill import synthetic_labels
+    nc = 2
+    old_min = ops.FactoredGrads.min_elems
+    ops.FactoredGrads.min_elems = 64 * 64
+    try:
+        vols = [synthetic_volume((2, 1, 16, 16, 16), 900 + i) for i in range(2)]
+        labs = [synthetic_labels((2, 16, 16, 16), 950 + i, nc) for i in range(2)]
+
+        def build():
+            torch.manual_seed(7)
+            model = tag_model_parameters(unet_3D_icl(feature_scale=16, n_classes=nc, in_channels=1, icl_in_resolutions=(1, 2, 4), icl_heads=(8, 4, 2)))
+            for m in model.modules():
+                if hasattr(m, "p") and m.__class__.__name__ == "Dropout3":
+                    m.p = 0.0
+                if hasattr(m, "drop_prob"):
+                    m.drop_prob = 0.0
+            return model
+
+        ce = torch.nn.CrossEntropyLoss()
+        dice, aux, pse = losses.DiceLoss(nc), losses.AuxLoss3D(nc, (16, 16, 16)), losses.PseudoSoftLoss3D(nc, (16, 16, 16))
+
+        def loss_of(model, vol, lab):
+            outputs = model(vol[:1], vol[1:])
+            return (dice(torch.softmax(outputs[0], 1), lab[:1].unsqueeze(1)) + ce(outputs[0], lab[:1]) + aux(outputs[2], lab[:1])
+                    + pse(outputs[3], outputs[1]) + 10 * losses.softmax_mse_loss(outputs[3], outputs[4]))
+
+        def run(fused):
+            model = build()
+            opt = (FusedSGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-2, update_in_backward=False) if fused
+                   else torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-2))
+            opt.zero_grad()
+            norms = None
+            for mb in range(2):
+                loss_of(model, vols[mb], labs[mb]).backward()
+                if mb == 0:
+                    # between backward and step: every gradient the dense path has exists already (factored ones as factors)
+                    have = {k for k, p in model.named_parameters() if p.grad is not None or getattr(p, "_icl_factors", None)}
+                    norms = (have, torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 1e9))
+                    if fused:
+                        assert not ops.DeferredBiasGrads.pending and not ops.WgradLane._used
+            opt.step()
+            return {k: p.detach().clone() for k, p in model.named_parameters()}, norms, model, opt
+
+        a, (have_a, _), _, _ = run(False)
+        b, (have_b, _), model, opt = run(True)
+        assert have_a == have_b, sorted(have_a ^ have_b)[:8]
+        bad = [k for k in a if float((a[k] - b[k]).abs().max()) > 1e-3 * float(a[k].abs().max()) + 1e-6]
+        assert not bad, bad[:8]
+
+        # (3) update inside backward + a second forward before step(): refused loudly
+        model2 = build()
+        # (the size threshold of the one-pass input gradient + update is the 13,824^2 matrices'; lowered to this model's 64^2 ones)
+        monkeypatch.setattr(FusedSGD, "can_update_in_backward",
+                            lambda self, p, rows: rows <= 32 and p.numel() >= 64 * 64 and id(p) in self._group_of())
+        opt2 = FusedSGD(model2.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-2)
+        loss_of(model2, vols[0], labs[0]).backward()
+        assert opt2._updated_in_backward, "the token-axis matrices were expected to take the update-in-backward path"
+        with pytest.raises(RuntimeError, match="update_in_backward"):
+            model2(vols[1][:1], vols[1][1:])
+        opt2.abandon_step()
+
+        # (4) the tag is a registry entry, not a weak reference on the tensor; the scope hook pickles as a no-op
+        assert model_of(next(model.parameters())) is model
+        buf = io.BytesIO()
+        pickle.dump(model, buf)
+        clone = pickle.loads(buf.getvalue())
+        assert sorted(clone.state_dict()) == sorted(model.state_dict())
+    finally:
+        ops.FactoredGrads.min_elems = old_min
+        ops.BackwardEnd.hook = None
+
+
+def test_unet_blocks_take_the_materialised_path_when_they_or_their_parents_are_hooked():
+    """ADVICE round 5 (layers.py): `UnetConv3.forward(lazy=True)` calls `conv2.forward_lazy` directly and may return an ops.LazyAct; with
+    a forward hook on the block, on its `conv2`, on the enclosing `UnetUp3_CT`, or a global module hook, the ordinary `__call__` path runs —
+    the hook fires and sees a tensor — and the results equal the unhooked ones."""
+    from icl_amd.networks.layers import UnetConv3, UnetUp3_CT
+    torch.manual_seed(5)
+    blk = UnetConv3(4, 8)
+    up = UnetUp3_CT(16, 8)
+    x = _rand((1, 4, 4, 8, 16), 9)
+    skip, deep = _rand((1, 8, 4, 8, 16), 10), _rand((1, 16, 2, 4, 8), 11)
+    with torch.no_grad():
+        ref = ops.materialized(blk(x, lazy=True))
+        ref_up = ops.materialized(up(skip, deep, lazy=True))
+        for target, call, want in ((blk, lambda: blk(x, lazy=True), ref), (blk.conv2, lambda: blk(x, lazy=True), ref),
+                                   (up, lambda: up(skip, deep, lazy=True), ref_up), (up.conv, lambda: up(skip, deep, lazy=True), ref_up)):
+            seen = []
+            h = target.register_forward_hook(lambda m, i, o: seen.append(type(o)))
+            out = call()
+            h.remove()
+            assert seen == [torch.Tensor], seen
+            assert isinstance(out, torch.Tensor) and torch.allclose(out, want, rtol=1e-5, atol=1e-6)
+        seen = []
+        h = torch.nn.modules.module.register_module_forward_hook(lambda m, i, o: seen.append(type(o)) if m is blk.conv2 else None)
+        try:
+            out = blk(x, lazy=True)
+        finally:
+            h.remove()
+        assert seen == [torch.Tensor] and isinstance(out, torch.Tensor)
 
 
 def test_conv_block_falls_back_to_its_children_when_they_are_hooked_or_swapped():
