@@ -176,6 +176,52 @@ def reference_loop_bench(nc: int, steps: int, warmup: int, dev, fused: bool, gra
             del sys.modules[name]
 
 
+def other_workload(model_name: str, nc: int, steps: int, warmup: int, dev):
+    """One of BASELINE.json's other single-GPU configurations (configs[3]: SwinUNETR ICL, configs[4]: nc = 16), timed like the headline —
+    capture, the faster of replay / eager (3-step probe), K steps between synchronisations — on a model of its own, AFTER the headline
+    region.  Driver-observed numbers for these configurations; the headline fields stay configs[1]."""
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    from icl_amd.utils.hashfill import synthetic_labels, synthetic_volume
+    torch.manual_seed(1337)
+    if model_name == "swinunetr_icl":
+        from icl_amd.networks.swinunetr_icl import SwinUNETR_icl
+        model = SwinUNETR_icl(img_size=(96, 96, 96), in_channels=1, out_channels=nc, feature_size=48, device=dev)
+    else:
+        model = unet_3D_icl(n_classes=nc, in_channels=1, device=dev)
+    model.train()
+    cfg = ICLConfig(num_classes=nc, labeled_bs=1, base_lr=0.02 if nc == 16 else 0.01, w_pse=0.1 if nc == 16 else 1.0)
+    tr = ICLTrainer(model, cfg, None)
+    vol = synthetic_volume((2, 1, 96, 96, 96), 1337, device=dev)
+    lab = synthetic_labels((1, 96, 96, 96), 4242, nc, device=dev)
+    tr.capture(vol, lab, warmup=max(warmup, 2))
+
+    def timed(k):
+        tr.step(vol, lab)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(k):
+            last = tr.step(vol, lab)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / k, last
+    tr.use_graph = True
+    t_graph, _ = timed(3)
+    tr.use_graph = False
+    t_eager, _ = timed(3)
+    tr.use_graph = t_graph <= t_eager
+    dt, last = timed(steps)
+    loss = float(last["loss"])
+    finite = loss == loss and abs(loss) != float("inf") and all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    out = {"workload": f"{'SwinUNETR' if model_name == 'swinunetr_icl' else '3D U-Net'} ICL BraTS-shape synthetic 96x96x96, num_classes={nc}, "
+                       "batch=2 (1 labeled + 1 unlabeled), full ICL step incl. SGD",
+           "ms_per_step": round(dt * 1e3, 3), "value": round(2.0 / dt, 3), "unit": "volumes/s", "steps": steps,
+           "launch": "hipGraph replay" if tr.use_graph else "eager",
+           "launch_probe": {"graph_ms": round(t_graph * 1e3, 3), "eager_ms": round(t_eager * 1e3, 3)}, "finite_after_timed_steps": finite}
+    del tr, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def hbm_traffic(kernel: str):
     """HBM bytes per launch of a kernel from the committed PMC run (FETCH_SIZE and WRITE_SIZE passes of rocprofv3 on one
     reference layer of that kernel, gfx950 correction applied) — counters cannot be collected from inside this process, so the
@@ -253,6 +299,8 @@ def main():
                     help="unet_3D_icl = BASELINE configs[1] (the headline line); swinunetr_icl = configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip config.other_workloads (the nc = 16 and SwinUNETR-ICL steps timed for 10 steps each after the headline region)")
     ap.add_argument("--no-exact-compare", action="store_true",
                     help="skip the reference timing of the same step with the convolutions on the exact-fp32 MFMA kernels")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
@@ -499,10 +547,14 @@ def main():
     if rank == 0 and not args.no_kernel_timer:
         trainer.graph = trainer.graph_forward = trainer.graph_update = None   # per-kernel HIP-event timing needs eager launches ...
         trainer.ddp = None                              # ... of this rank's step alone: the other ranks are done
+        side_was = ops.SideStream.enabled
         ops.SideStream.enabled = False                  # ... on ONE stream: a kernel's duration is its own, not a share of the GPU
-        with ops.KernelTimer() as kt:
-            for _ in range(3):
-                trainer.step(vol, lab)
+        try:
+            with ops.KernelTimer() as kt:
+                for _ in range(3):
+                    trainer.step(vol, lab)
+        finally:
+            ops.SideStream.enabled = side_was           # (config.other_workloads below is timed with the lanes on, like the headline)
         summ = kt.summary()
         conv = {k: v for k, v in summ.items() if k.startswith("conv3d_")}
         if conv:
@@ -627,8 +679,20 @@ def main():
                        **({"feed": feed} if feed else {})},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not use_ddp and not args.no_other_workloads and args.model == "unet_3D_icl" and nc == 2:
+            # BASELINE.json configs[4] and configs[3] on this GPU, after the headline region and before the CPU baseline
             del trainer, model
+            trainer = model = None
+            torch.cuda.empty_cache()
+            other = {}
+            for key, (mname, mnc) in (("unet3d_icl_nc16", ("unet_3D_icl", 16)), ("swinunetr_icl_nc2", ("swinunetr_icl", 2))):
+                try:
+                    other[key] = other_workload(mname, mnc, 10, args.warmup, dev)
+                except Exception as e:      # noqa: BLE001 — the headline line must still be printed
+                    other[key] = {"error": repr(e)}
+            out["config"]["other_workloads"] = other
+        if world == 1 and not args.no_cpu_baseline:
+            trainer = model = None
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(nc, args.model)
         try:    # RCCL / HIP banners sit in the C stdio buffer of a piped stdout: push them out first, the JSON line comes last

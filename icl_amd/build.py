@@ -25,12 +25,15 @@ def needs_build() -> bool:
     return any(os.path.getmtime(s) > t for s in _sources())
 
 
+# the compile flags of the shipped library (tests/test_host_logic.py scans the device assembly built with exactly these)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17"]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-I", CSRC, "-o", LIB, os.path.join(CSRC, "icl_hip.hip")]
+    cmd = [hipcc, *FLAGS, "-shared", "-fPIC", "-I", CSRC, "-o", LIB, os.path.join(CSRC, "icl_hip.hip")]
     if verbose:
         print("[icl_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -28,8 +28,14 @@ __device__ __forceinline__ void row_chunk_summary(const float* __restrict__ xr, 
       const float4 v = x4[i];
       if (n == 0.f) shift = v.x;
       const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
-      s1 += (d0 + d1) + (d2 + d3);
-      s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      // the pair sums are pinned in registers of their own (ICL_PIN1: an empty asm, no instruction): left alone hipcc packs (a1, a2)
+      // and (b1, b2) into register pairs and forms a + b as `v_pk_add_f32 d, d, d op_sel:[0,1] op_sel_hi:[1,0]` — the crossed form with
+      // destination == source that lost a term in layernorm_bwd_wgrad_kernel under concurrent streams (round 5);
+      // no kernel of the library keeps that form (tests/test_host_logic.py scans the device assembly).  Same sums, same order.
+      float a1 = d0 + d1, b1 = d2 + d3, a2 = d0 * d0 + d1 * d1, b2 = d2 * d2 + d3 * d3;
+      ICL_PIN1(a1); ICL_PIN1(b1); ICL_PIN1(a2); ICL_PIN1(b2);
+      s1 += a1 + b1;
+      s2 += a2 + b2;
       n += 4.f;
     }
   } else {

@@ -117,6 +117,34 @@ def test_bench_self_launches_its_ranks_and_relays_rank0_json():
         assert r.returncode == 2 and f"{torch.cuda.device_count()} HIP device(s)" in r.stderr and r.stdout.strip() == ""
 
 
+@pytest.mark.timeout(900)
+def test_no_kernel_of_the_library_keeps_a_crossed_packed_add(tmp_path):
+    """Round 6: the instruction form behind the round-5 wrong result — `v_pk_add_f32 d, s0, s1 op_sel:[0,1]
+    op_sel_hi:[1,0]` (halves crossed; in every case found the destination pair was also a source) — must not appear in ANY kernel of
+    the library: the device assembly of the whole library, built with the flags of icl_amd/build.py, is scanned kernel by kernel.
+    The mechanism of the loss is unreproduced outside the full step, so the form itself is banned."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc on this host")
+    from icl_amd import build as icl_build
+    csrc = os.path.join(ROOT, "icl_amd", "csrc")
+    out = tmp_path / "icl.s"
+    subprocess.check_call([hipcc, *icl_build.FLAGS, "-I", csrc, "-S", "--cuda-device-only", "-o", str(out), os.path.join(csrc, "icl_hip.hip")],
+                          stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    kernels, bad = 0, []
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
+        kernels += 1
+        for ln in m.group(2).splitlines():
+            if "v_pk_add_f32" in ln and "op_sel:[0,1]" in ln and "op_sel_hi:[1,0]" in ln:
+                bad.append((m.group(1), ln.strip()))
+    assert kernels >= 200, kernels          # the whole library was scanned (212 kernels in round 6)
+    assert not bad, bad[:4]
+
+
 def test_layernorm_backward_keeps_its_bias_sums_out_of_packed_adds(tmp_path):
     """Round 5: with `b[k] += gv` packed into one `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (halves crossed,
     destination pair = second source) layernorm_bwd_wgrad_kernel lost one row's term of dbeta in lanes 48..63 under concurrent streams.

@@ -22,15 +22,15 @@ task() {
   local t=$1; shift
   case $t in
     suite) python -m pytest tests -m gpu -q -x 2>&1 | tail -${TAIL:-6} ;;
-    bench) timeout 600 python bench.py --no-cpu-baseline --no-exact-compare "$@" 2>/dev/null | line "bench $*" ;;
+    bench) timeout 600 python bench.py --no-cpu-baseline --no-exact-compare --no-other-workloads "$@" 2>/dev/null | line "bench $*" ;;
     ab) local var=$1 a=$2 b=$3; shift 3
         for rep in 1 2; do for v in "$a" "$b"; do
           # (a runtime knob that makes the replay hang must not hold the box until gpurun's own limit)
-          env "$var=$v" timeout 300 python bench.py --no-cpu-baseline --no-exact-compare --steps 30 "$@" 2>/dev/null | line "$var=$v" || echo "$var=$v: no result (timeout or error)"
+          env "$var=$v" timeout 300 python bench.py --no-cpu-baseline --no-exact-compare --no-other-workloads --steps 30 "$@" 2>/dev/null | line "$var=$v" || echo "$var=$v: no result (timeout or error)"
         done; done ;;
     stats) local name=$1; shift
         ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$O/${name}_prof" -o b --output-format csv -- python3 "$R/bench.py" \
-            --no-cpu-baseline --no-exact-compare --no-kernel-timer --launch graph --steps 24 --warmup 3 "$@" > /dev/null 2>&1 )
+            --no-cpu-baseline --no-exact-compare --no-other-workloads --no-kernel-timer --launch graph --steps 24 --warmup 3 "$@" > /dev/null 2>&1 )
         f=$(find "$O/${name}_prof" -name "*kernel_stats.csv" | head -1)
         cp "$f" "$O/${name}_kernel_stats.csv"
         python - "$f" <<'PY'
@@ -49,7 +49,7 @@ PY
     critical-path) python tools/critical_path.py 2>&1 | tail -${TAIL:-24} ;;
     timeline)
         ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$O/tl_prof" -o b --output-format csv -- python3 "$R/bench.py" \
-            --no-cpu-baseline --no-exact-compare --launch graph --steps 8 --warmup 2 > /dev/null 2>&1 )
+            --no-cpu-baseline --no-exact-compare --no-other-workloads --launch graph --steps 8 --warmup 2 > /dev/null 2>&1 )
         T=$(find "$O/tl_prof" -name "*kernel_trace.csv" | head -1)
         python3 tools/timeline.py "$T" 3 0.25 > "$O/timeline.txt" 2>&1
         python3 tools/queue_tail.py "$T" 70 > "$O/queue_tails.txt" 2>&1      # the tails of the backward chains, per hardware queue
