@@ -78,6 +78,10 @@ typedef Bf3Base Bf3;
 // product terms then add up coherently over a sum of same-sign products).  11 VALU per pair (3 v_cvt_pk_bf16_f32, 4 unpack, 4 sub).
 // Non-finite v (and |v| > 3.39e38, which rounds to a bf16 infinity): s2 and s3 are NaN — the result is non-finite wherever the
 // fp32 kernels give a non-finite result, as NaN where they may give an infinity.
+// (Round 6: hipcc's SLP vectoriser packs the two residual subtractions of a pair into one `v_pk_add_f32 ... neg_lo neg_hi`.  That is the
+// faster form wherever the split runs while the wave's own SIMD multiplies nothing — every kernel of this file and the weight-gradient
+// kernels: 0-5 % slower without it — and the slower one in the loader waves of conv3d_bf16x3_fwd_ws_kernel, which is therefore compiled
+// in a unit of its own with the vectoriser off: csrc/icl_hip_noslp.hip, profiles/r6_pk_add_ab.txt.)
 __device__ __forceinline__ void bf3_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
   p1 = icl_pack_bf16_rn(a, b);
   const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
@@ -169,6 +173,7 @@ __device__ __forceinline__ void bf3_stats_flush(const Bf3RunStats<NBT>& run, flo
 }
 constexpr size_t kBf3StatsLdsBytes = 8 * 48 * 3 * 4;      // scratch of bf3_stats_flush behind the weight planes (every launch reserves it)
 
+#ifndef ICL_SECOND_UNIT      // (the two non-template kernels of this file are defined by the main unit only: csrc/icl_hip_noslp.hip)
 // Split weights, ready for LDS: ws[chunk][stage 3][split * 2 + half][slot 10][CoutP] of 8 packed bf16, from the fp32 pack
 // wp[tap][CinP][CoutP] of the fp32 kernels: slot s of stage g is tap 10 g + s; the 28th slot (stage 2, slot 7) is the zero partner of
 // tap 26, slots 8 / 9 of stage 2 are unused.  One small launch in front of
@@ -241,6 +246,7 @@ __global__ __launch_bounds__(256) void conv_bf16x3_split_weights_multi_kernel(Sp
     d[4 * plane] = o3;
   }
 }
+#endif  // ICL_SECOND_UNIT
 
 #if defined(BF3_DEBUG) && (BF3_DEBUG & 16)
 // in-kernel stamps (debug builds only): waves 0 and 4 of workgroup 0 (they share a SIMD) record s_memtime at the phase boundaries of

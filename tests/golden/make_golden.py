@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz from the REAL reference (run in the build container only).
 
-    python tests/golden/make_golden.py [--only unit|model2|model16|steps|model2d|swin|swin64|swinunet2d]
+    python tests/golden/make_golden.py [--only unit|model2|model16|wgrads|steps|steps10|model2d|swin|swin64|swinunet2d]
 
 The reference (/root/reference/code) is imported as-is; the only stand-ins are the five
 trivial MONAI symbols its U-Net ICL files import: MONAI is
@@ -400,7 +400,21 @@ def gen_model_dense_wgrads(R, out, nc=2):
     vol = synthetic_volume((2, 1, 96, 96, 96), 1337)
     lab = synthetic_labels((1, 96, 96, 96), 4242, nc)
     model.train()
+    # round 6: two INPUT gradients of 96^3 convolutions as well (the tensors the input-gradient kernels produce at their largest shapes):
+    # the inputs of `up_concat1.conv.conv1` (48 channels: the concat buffer) and of `conv1.conv2` (16 channels), kept by forward
+    # pre-hooks on the Conv3d modules; each sample's gradient is stored as a dense 12^3 block plus a stride-8 lattice of the volume
+    kept = {}
+
+    def keep(name):
+        def hook(module, args):
+            args[0].retain_grad()
+            kept.setdefault(name, []).append(args[0])       # (the backbone runs once per stream: labeled, then unlabeled)
+        return hook
+    hooks = [model.up_concat1.conv.conv1[0].register_forward_pre_hook(keep("up_concat1.conv.conv1")),
+             model.conv1.conv2[0].register_forward_pre_hook(keep("conv1.conv2"))]
     outs = model(vol[:1], vol[1:])
+    for h in hooks:
+        h.remove()
     soft = torch.softmax(outs[0], 1)
     loss = (L.DiceLoss(nc)(soft, lab.unsqueeze(1)) + nn.CrossEntropyLoss()(outs[0], lab) + L.AuxLoss3D(nc)(outs[2], lab)
             + L.PseudoSoftLoss3D(nc)(outs[3], outs[1]) + 10 * L.softmax_mse_loss(outs[3], outs[4]))
@@ -410,6 +424,12 @@ def gen_model_dense_wgrads(R, out, nc=2):
     for k in ("up_concat1.conv.conv1.0.weight", "up_concat1.conv.conv2.0.weight", "conv1.conv2.0.weight",
               "up_concat2.conv.conv1.0.weight", "conv2.conv2.0.weight"):
         d["grad." + k] = npy(sd_[k].grad)
+    for name, ts in kept.items():
+        assert len(ts) == 2 and all(t.grad is not None for t in ts), name
+        g = torch.cat([t.grad for t in ts], 0)              # [2 (labeled, unlabeled), C, 96, 96, 96]
+        d[f"dgrad.{name}.block"] = npy(g[:, :, 40:52, 40:52, 40:52])
+        d[f"dgrad.{name}.lattice"] = npy(g[:, :, 3::8, 3::8, 3::8])
+        d[f"dgrad.{name}.maxabs"] = np.array([float(g.abs().max())])
     np.savez_compressed(os.path.join(out, f"model_unet3d_icl_nc{nc}_wgrads.npz"), **d)
     print("dense wgrads:", {k: v.shape for k, v in d.items()}, sum(v.nbytes for v in d.values()) / 1e6, "MB (raw)")
 
@@ -468,6 +488,62 @@ def gen_model_steps(R, out, nc=2, steps=3):
     d["momentum." + big + "_sub"] = npy(optimizer.state[named[big]]["momentum_buffer"])[::432, ::432]
     d["momentum.final.weight"] = npy(optimizer.state[named["final.weight"]]["momentum_buffer"])
     np.savez_compressed(os.path.join(out, f"model_unet3d_icl_nc{nc}_steps.npz"), **d)
+
+
+def gen_model_steps10(R, out, nc=2, steps=10, max_iterations=20):
+    """Round 6: TEN iterations of the reference loop body (train_inherent_consistent_unet_3D_BraTS.py:99-121) on
+    the 785 M-parameter model, every step recorded — six loss terms, the learning rate used, all parameter norms, and per step the small
+    tensors and sampled 13,824^2 weights / momentum the three-step golden holds only after its last step.  A longer horizon than
+    gen_model_steps (kept as it is: its file pins steps 1-3 at max_iterations = 10); here max_iterations = 20, so the ten steps run at
+    base_lr * (1 - k / 20) ** 0.9 for k = 0, 0, 1, ..., 8 (the reference computes the rate from the PRE-increment iter_num)."""
+    m3, L = R["m3"], R["losses"]
+    model = m3.unet_3D_icl(n_classes=nc, in_channels=1)
+    parity_mode(model)
+    fill(model)
+    model.train()
+    base_lr = 0.01
+    optimizer = torch.optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=0.0001)
+    ce_loss, dice_loss = nn.CrossEntropyLoss(), L.DiceLoss(nc)
+    aux_loss, pse_loss = L.AuxLoss3D(nc), L.PseudoSoftLoss3D(nc)
+    named = dict(model.named_parameters())
+    big = "sspa.class_decoders.2.mlp2.fc1.weight"
+    w0_big = named[big].detach()[::432, ::432].double().clone()
+    small = ("final.weight", "final.bias", "sspa.class_decoders.0.attn.fc_q.weight", "uscl.attn_convs1.2.weight")
+    d = {"param_keys": np.array(list(named.keys())), "max_iterations": np.array(max_iterations), "base_lr": np.array(base_lr),
+         "small_keys": np.array(small)}
+    losses, lrs = [], []
+    iter_num = 0
+    for s in range(steps):
+        vol = synthetic_volume((2, 1, 96, 96, 96), 1337 + s)
+        lab = synthetic_labels((1, 96, 96, 96), 4242 + s, nc)
+        outputs = model(vol[:1], vol[1:])
+        soft = torch.softmax(outputs[0], dim=1)
+        l_ce = ce_loss(outputs[0], lab[:1])
+        l_dice = dice_loss(soft, lab[:1].unsqueeze(1))
+        l_aux = aux_loss(outputs[2], lab[:1])
+        l_pse = pse_loss(outputs[3], outputs[1])
+        l_con = L.softmax_mse_loss(outputs[3], outputs[4])
+        loss = l_dice + l_ce + l_aux + l_pse + 10 * l_con
+        lrs.append(optimizer.param_groups[0]["lr"])
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        lr_ = base_lr * (1.0 - iter_num / max_iterations) ** 0.9
+        for g in optimizer.param_groups:
+            g["lr"] = lr_
+        iter_num += 1
+        losses.append([float(l_dice), float(l_ce), float(l_aux), float(l_pse), float(l_con), float(loss)])
+        t = s + 1
+        d[f"post_step{t}_norms"] = np.array([float(p.detach().double().pow(2).sum().sqrt()) for p in named.values()])
+        for k in small:
+            d[f"post_step{t}.{k}"] = npy(named[k])
+        d[f"momentum_step{t}.final.weight"] = npy(optimizer.state[named["final.weight"]]["momentum_buffer"])
+        d[f"delta_step{t}.{big}_sub"] = (named[big].detach()[::432, ::432].double() - w0_big).numpy()
+        d[f"momentum_step{t}.{big}_sub"] = npy(optimizer.state[named[big]]["momentum_buffer"])[::432, ::432]
+        print(f"steps10: step {t} lr {lrs[-1]:.6f} losses {losses[-1]}", flush=True)
+    d["losses"] = np.array(losses)
+    d["lr_used"] = np.array(lrs)
+    np.savez_compressed(os.path.join(out, f"model_unet3d_icl_nc{nc}_steps10.npz"), **d)
 
 
 # ---------------------------------------------------------------- 2-D U-Net ICL (BASELINE config 1)
@@ -727,6 +803,8 @@ if __name__ == "__main__":
         gen_model_dense_wgrads(R, HERE)
     if a.only in ("all", "steps"):
         gen_model_steps(R, HERE)
+    if a.only in ("all", "steps10"):
+        gen_model_steps10(R, HERE)
     if a.only in ("all", "model2d"):
         gen_model2d(R, HERE)
     if a.only in ("all", "swin"):

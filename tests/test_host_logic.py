@@ -131,16 +131,19 @@ def test_no_kernel_of_the_library_keeps_a_crossed_packed_add(tmp_path):
         pytest.skip("no hipcc on this host")
     from icl_amd import build as icl_build
     csrc = os.path.join(ROOT, "icl_amd", "csrc")
-    out = tmp_path / "icl.s"
-    subprocess.check_call([hipcc, *icl_build.FLAGS, "-I", csrc, "-S", "--cuda-device-only", "-o", str(out), os.path.join(csrc, "icl_hip.hip")],
-                          stderr=subprocess.DEVNULL)
-    text = out.read_text()
-    kernels, bad = 0, []
-    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
-        kernels += 1
-        for ln in m.group(2).splitlines():
-            if "v_pk_add_f32" in ln and "op_sel:[0,1]" in ln and "op_sel_hi:[1,0]" in ln:
-                bad.append((m.group(1), ln.strip()))
+    kernels, bad, procs = 0, [], []
+    for src, extra in icl_build.UNITS:           # every translation unit of the library, with the flags it ships with; side by side
+        out = tmp_path / (src + ".s")
+        procs.append((out, subprocess.Popen([hipcc, *icl_build.FLAGS, *extra, "-I", csrc, "-S", "--cuda-device-only", "-o", str(out),
+                                             os.path.join(csrc, src)], stderr=subprocess.DEVNULL)))
+    for out, p in procs:
+        assert p.wait() == 0, out
+        text = out.read_text()
+        for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
+            kernels += 1
+            for ln in m.group(2).splitlines():
+                if "v_pk_add_f32" in ln and "op_sel:[0,1]" in ln and "op_sel_hi:[1,0]" in ln:
+                    bad.append((m.group(1), ln.strip()))
     assert kernels >= 200, kernels          # the whole library was scanned (212 kernels in round 6)
     assert not bad, bad[:4]
 
