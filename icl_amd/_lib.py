@@ -112,10 +112,13 @@ _SIGNATURES = {
     "icl_crop_rotflip": (c_int, [P, P, P, I, P, P, I, I, I, P]),
     "icl_sgd_step": (c_int, [P, P, P, L, F, F, F, I, P, P]),
     "icl_sgd_step_factored": (c_int, [P, P, P, P, I, I, I, F, F, F, I, P, P]),
+    "icl_sgd_step_factored_narrow": (c_int, [P, P, P, P, I, I, I, F, F, F, I, P, I, P]),
     "icl_sgd_factored_split_ws_bytes": (c_int64, [I, I, I]),
     "icl_sgd_step_factored_split": (c_int, [P, P, P, P, P, I, I, I, F, F, F, I, P, P]),
     "icl_sgd_step_multi": (c_int, [P, P, P, P, I, F, F, F, I, P, P]),
     "icl_loss_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, L, I, I, P]),
+    "icl_qchain_stage": (c_int, [P, P]),
+    "icl_qchain_wgrad": (c_int, [P, P, P, P, P, P, P, P, I, P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

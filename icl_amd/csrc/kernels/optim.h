@@ -150,6 +150,74 @@ __global__ __launch_bounds__(256) void sgd_factored_small_kernel(float* __restri
   }
 }
 
+// The same update as a NARROW persistent launch (round 6): `gridDim.x` workgroups of 1,024 threads — one per CU, on as many CUs — walk the
+// 16-row x 1,024-column tiles of the matrix; the four 256-thread quarters of a workgroup are four workgroups of the kernel above side by side
+// (same thread-to-element map inside a 16 x 256 tile, same sums in the same order: bit-identical results).  What it is for: the 16 B / weight
+// update streams of the two 13,824^2 matrices whose update is deferred out of their backward pass (FusedSGD.update_placement "deep") run
+// UNDER the deep part of the backward pass (24^3 / 12^3 / 6^3 levels: launches of 72-144 workgroups that leave the HBM idle) instead of
+// beside the aligners' serial query chain at the end of the forked phase.  The wide kernel cannot do that — its 46,656 short workgroups take
+// every CU, and the deep levels' dependent launches queue behind them (round 4: +0.35 ms) —; a grid of ~100 fat workgroups holds ~100 CUs
+// for the whole stream and leaves the others to the convolutions.  M <= 16 factor rows (one chunk), non-temporal loads and stores.
+constexpr int kSnCols = 1024, kSnMaxRows = 16;
+__global__ __launch_bounds__(1024) void sgd_factored_narrow_kernel(float* __restrict__ p, float* __restrict__ mom, const float* __restrict__ g,
+                                                                   const float* __restrict__ x, int M, int N, int K, float lr, float momentum,
+                                                                   float wd, int first, const float* __restrict__ lr_dev) {
+  ICL_DYN_LDS(float4, lds4);                          // 65 KB: dynamic (a static array may not exceed 64 KB)
+  float4 (*xs)[kSnCols / 4] = reinterpret_cast<float4 (*)[kSnCols / 4]>(lds4);                              // [kSnMaxRows][256] float4, 64 KB
+  float (*gs)[kSvRows] = reinterpret_cast<float (*)[kSvRows]>(lds4 + kSnMaxRows * (kSnCols / 4));           // [kSnMaxRows][16]
+  if (lr_dev) lr = *lr_dev;
+  const int sub = threadIdx.x >> 8, t = threadIdx.x & 255;
+  const int kq = t & 63, rl = t >> 6;
+  const int nbx = (K + kSnCols - 1) / kSnCols, nby = (N + kSvRows - 1) / kSvRows;
+  for (int tile = blockIdx.x; tile < nbx * nby; tile += gridDim.x) {
+    const int by = tile / nbx, bx = tile - by * nbx;
+    const int n0 = by * kSvRows, k0 = bx * kSnCols + sub * kSvCols;
+    const bool col_ok = k0 + kq * 4 < K;
+    float4 pv[4], mv[4], acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + rl * 4 + r;
+      acc[r] = pv[r] = mv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col_ok && n < N) {
+        const long idx = (long)n * K + k0 + kq * 4;
+        pv[r] = icl_nt_load4(p + idx);
+        if (!first) mv[r] = icl_nt_load4(mom + idx);
+      }
+    }
+    __syncthreads();      // the previous tile's readers of xs / gs are done
+    for (int it = threadIdx.x; it < M * (kSnCols / 4); it += 1024) {
+      const int m = it / (kSnCols / 4), q = it % (kSnCols / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bx * kSnCols + q * 4 < K) v = *reinterpret_cast<const float4*>(x + (long)m * K + bx * kSnCols + q * 4);
+      xs[m][q] = v;
+    }
+    for (int it = threadIdx.x; it < M * kSvRows; it += 1024) {
+      const int m = it / kSvRows, r = it % kSvRows;
+      gs[m][r] = n0 + r < N ? g[(long)m * N + n0 + r] : 0.f;
+    }
+    __syncthreads();
+    for (int m = 0; m < M; ++m) {
+      const float4 xv = xs[m][sub * 64 + kq];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gv = gs[m][rl * 4 + r];
+        acc[r].x += gv * xv.x; acc[r].y += gv * xv.y; acc[r].z += gv * xv.z; acc[r].w += gv * xv.w;
+      }
+    }
+    if (col_ok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + rl * 4 + r;
+        if (n >= N) continue;
+        const long idx = (long)n * K + k0 + kq * 4;
+        sgd_update4(pv[r], acc[r], mv[r], lr, momentum, wd, first);
+        icl_nt_store4(p + idx, pv[r]);
+        icl_nt_store4(mom + idx, mv[r]);
+      }
+    }
+  }
+}
+
 constexpr int kSfRows = 64, kSfCols = 256, kSfChunk = 32;
 constexpr int kSfXp = kSfCols + 16, kSfGp = kSfRows + 16;   // LDS row pitches: the 4 factor rows of an MFMA k-step land 16 banks apart
 constexpr int kSfDp = kSfCols + 4;                            // pitch of the d tile: 16-byte aligned rows, conflict-free column writes

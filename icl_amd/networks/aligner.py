@@ -53,8 +53,8 @@ class BatchNorm3d(BatchNormAct):
 
 def _open_tail_gate(grad):
     opt = ops.FactoredGrads.fused_optimizer
-    if opt is not None and getattr(opt, "update_placement", "") == "tail":
-        opt.flush_deferred(gate=True)
+    if opt is not None and getattr(opt, "update_placement", "") in ("tail", "deep"):
+        opt.flush_deferred(gate=True, only="tail")      # ("deep" entries wait for the backbone's gate, unet_3D._open_update_gate)
     return None
 
 
@@ -128,6 +128,45 @@ class Class_Decoder(nn.Module):  # noqa: N801
         query = self.drop_path.add(query, query)
         query = self.drop_path.add(query, self.mlp(self.norm2(query)))
         return query, attn
+
+    def fused_ok(self, query, feat) -> bool:
+        """The query half as fused stages (ops.query_attend, csrc/kernels/qchain.h): <= 32 query rows, C <= 256 (hidden layer <= 1024);
+        anything attached to the modules it replaces (forward hooks, swapped children) keeps the operator-by-operator path."""
+        a, m = self.attn, self.mlp
+        mods = (self, self.norm1_query, self.norm2, a, a.fc_q, a.proj, m, m.fc1, m.fc2, self.drop_path)
+        if any(x._forward_hooks or x._forward_pre_hooks for x in mods):
+            return False
+        if not (type(a) is Query_Attention and type(m) is MLP and type(self.norm1_query) is LayerNorm and type(self.norm2) is LayerNorm):
+            return False
+        return query.dim() == 3 and self.fused_ok_dims(feat.shape[0], query.shape[1], query.shape[0], feat)
+
+    def fused_ok_dims(self, batch: int, nc: int, query_batch: int, like) -> bool:
+        """The shape half of ``fused_ok`` (no hooks checked): ``batch`` samples x ``nc`` classes query rows, a query of ``query_batch``
+        (1 = broadcast) samples."""
+        return (query_batch in (1, batch)
+                and ops.query_chain_ok(batch * nc, self.attn.dim, self.mlp.fc1.weight.shape[0], nc, like))
+
+    def attend_fused(self, query, feat, qconv, ba, full=True, kv=None):
+        """``attend`` + ``qconv`` on the fused stages.  ``query`` [B or 1, nc, C]; returns (logits, q[:ba], q[ba:], qconv(q)) — or
+        (logits, None, None, None) with ``full`` False, for a caller that reads only the attention maps.  ``kv``: fc_kv(norm1(feat)) when
+        the caller has computed it already (the token lane of forward_labeled_pair)."""
+        a = self.attn
+        if kv is None:
+            kv = a.fc_kv(self.norm1(feat))
+        p, training = self.drop_path.drop_prob, self.drop_path.training
+        if full:
+            s0, d0 = ops.drop_path_site(kv, p, training)
+            s1, d1 = ops.drop_path_site(kv, p, training)
+        else:
+            s0 = s1 = (0, 0, 1.0)
+            d0 = d1 = None
+        params = (self.norm1_query.weight, self.norm1_query.bias, a.fc_q.weight, a.fc_q.bias, a.proj.weight, a.proj.bias,
+                  self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias,
+                  qconv.weight.squeeze(-1), qconv.bias)
+        out = ops.query_attend(query, kv, a.num_heads, a.scale, ba, 1e-5, (s0, s1, d0 if d0 is not None else d1), full, params)
+        if not full:
+            return out[0], None, None, None
+        return out
 
     def refine(self, attn):
         """The attention-map half (:265-267): residual token-axis MLP.  Needs nothing of the query half but the logits."""
@@ -239,10 +278,34 @@ class InherentConsistent(nn.Module):
         the reference order (a, then b)."""
         bs = feats[0].shape[0]
         maps_a, maps_b, qs_a, qs_b, branches = [], [], [], [], []
-        nxt = getattr(self, self._qname).expand(bs, -1, -1)
+        nxt = getattr(self, self._qname)      # [1, nc, C]: broadcast over the batch (an expand, or inside the fused first stage)
+        # the token side of every level (projection, LayerNorms, fc_kv: a function of the feature maps alone) on the token lane, beside
+        # the query chain that links the levels (ops.SideStream.token_lane_on)
+        kvs = [None] * len(self.depth)
+        tok_s = ops.SideStream.token_stream() if feats[0].is_cuda else None
+        if (tok_s is not None and all(not (m._forward_hooks or m._forward_pre_hooks) for cd in self.class_decoders for m in (cd.norm1, cd.attn.fc_kv))
+                and all(cd.fused_ok(nxt[:, :, :1].expand(-1, -1, cd.attn.dim), feats[0]) for cd in self.class_decoders)
+                and not any(q._forward_hooks or q._forward_pre_hooks for q in self.query_convs)):
+            cur = torch.cuda.current_stream(feats[0].device)
+            with torch.cuda.stream(tok_s):
+                for i in range(len(self.depth)):
+                    feats[i].record_stream(tok_s)
+                    cd = self.class_decoders[i]
+                    kvs[i] = cd.attn.fc_kv(cd.norm1(self._tokens(i, feats[i])))
+            cur.wait_stream(tok_s)
+            for kv in kvs:
+                kv.record_stream(cur)
         for i in range(len(self.depth)):
-            tok = self._tokens(i, feats[i])
-            q_out, attn = self.class_decoders[i].attend(nxt, tok)
+            cd = self.class_decoders[i]
+            tok = self._tokens(i, feats[i]) if kvs[i] is None else None
+            like = tok if tok is not None else kvs[i]
+            fused = cd.fused_ok(nxt, like) and not (self.query_convs[i]._forward_hooks or self.query_convs[i]._forward_pre_hooks)
+            if fused:
+                attn, qa, qb, nxt_i = cd.attend_fused(nxt, tok, self.query_convs[i], ba, kv=kvs[i])
+            elif tok is None:
+                raise RuntimeError("aligner: the token lane computed k / v for a level that does not take the fused query chain")
+            else:
+                q_out, attn = cd.attend(nxt if nxt.shape[0] == bs else nxt.expand(bs, -1, -1), tok)
             if i == len(self.depth) - 1 and attn.requires_grad:
                 # backward: when the logits' gradient of the LAST level arrives, that level's map chain (the two big weight streams) is done
                 # and what remains of this aligner is the serial query chain — the gate of FusedSGD's "tail" update placement
@@ -259,27 +322,38 @@ class InherentConsistent(nn.Module):
                     m = self.attn_convs1[i](self.attn_convs0[i](part.reshape(pb * nc, h, *sp)))
                     maps.append(m.reshape(pb, nc, *sp))
             branches.append((lane, [maps_a[-1], maps_b[-1]]))
-            nxt = self.query_convs[i](q_out)
-            qa, qb = ops.split_batch(q_out, ba)
+            if fused:
+                nxt = nxt_i
+            else:
+                nxt = self.query_convs[i](q_out)
+                qa, qb = ops.split_batch(q_out, ba)
             qs_a.append(_batch_mean(qa))
             qs_b.append(_batch_mean(qb))
         for lane, outs in branches:
             lane.join(outs)
         return (maps_a, qs_a), (maps_b, qs_b)
 
-    def forward(self, feats, guided_Q=None, modal="labeled"):
+    def forward(self, feats, guided_Q=None, modal="labeled", need_queries: bool = True):
+        """``need_queries`` False (not a reference argument; the 3-D ICL models pass it for the guided call, whose updated queries they
+        discard, unet_3D_icl.py:147): the second return value is a list of None and the query half behind the attention maps — proj, the
+        query MLP, query_convs, none of which reaches an output — is not evaluated."""
         bs = feats[0].shape[0]
         feat_maps, updated_qs, branches = [], [], []
         labeled = modal == "labeled"
-        nxt = getattr(self, self._qname).expand(bs, -1, -1) if labeled else None
+        nxt = getattr(self, self._qname) if labeled else None
         for i in range(len(self.depth)):
             # guided queries (unet_3D_icl.py:224-239; its unused next_guided_Q is not computed): the levels do not depend on each other at all — a whole level per lane; own queries:
             # only the map chain leaves the current stream (see forward_labeled_pair)
             whole = None if labeled else ops.SideStream([feats[i], guided_Q[i]], lane=(1 + i) if ops.SideStream.lane_mask & 2 else 99)
             with (whole if whole is not None else contextlib.nullcontext()):
                 tok = self._tokens(i, feats[i])
-                q_in = nxt if labeled else guided_Q[i].expand(bs, -1, -1)
-                q_out, attn = self.class_decoders[i].attend(q_in, tok)
+                q_in = nxt if labeled else guided_Q[i]
+                cd = self.class_decoders[i]
+                fused = cd.fused_ok(q_in, tok) and not (self.query_convs[i]._forward_hooks or self.query_convs[i]._forward_pre_hooks)
+                if fused:
+                    attn, q_out, _, nxt_i = cd.attend_fused(q_in, tok, self.query_convs[i], bs, full=labeled or need_queries)
+                else:
+                    q_out, attn = cd.attend(q_in if q_in.shape[0] == bs else q_in.expand(bs, -1, -1), tok)
                 part = ops.SideStream([attn], lane=1 + i) if labeled else None
                 with (part if part is not None else contextlib.nullcontext()):
                     attn = self.class_decoders[i].refine(attn)
@@ -290,9 +364,9 @@ class InherentConsistent(nn.Module):
                     a = self.attn_convs1[i](self.attn_convs0[i](a))
                     feat_maps.append(a.reshape(b, nc, *sp))
                 if labeled:
-                    nxt = self.query_convs[i](q_out)
-                updated_qs.append(_batch_mean(q_out))
-            branches.append((whole or part, [feat_maps[-1]] + ([updated_qs[-1]] if whole is not None else [])))
+                    nxt = nxt_i if fused else self.query_convs[i](q_out)
+                updated_qs.append(_batch_mean(q_out) if q_out is not None else None)
+            branches.append((whole or part, [feat_maps[-1]] + ([updated_qs[-1]] if whole is not None and updated_qs[-1] is not None else [])))
         for lane, outs in branches:
             lane.join(outs)
         return feat_maps, updated_qs

@@ -47,7 +47,7 @@ class unet_3D_icl(UNet3DBackbone):  # noqa: N801 — reference class name
             # the aligners need only the three deep maps: they run on a second stream next to the 48^3 / 96^3 decoder stages
             with ops.SideStream(feats) as side:
                 (maps_lab, qs_lab), (maps_consis, _) = self.sspa.forward_labeled_pair(feats, bl)
-                maps_unlab, _ = self.uscl([ops.split_batch(f, bl)[1] for f in feats], qs_lab, "unlabeled")
+                maps_unlab, _ = self.uscl([ops.split_batch(f, bl)[1] for f in feats], qs_lab, "unlabeled", need_queries=False)
             return side, maps_lab, maps_unlab, maps_consis
 
         final, _, (side, feat_maps_lab, feat_maps_unlab, feat_maps_consis) = self.run_backbone(torch.cat([x_lab, x_unlab], 0), heads)

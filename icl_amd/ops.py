@@ -53,6 +53,12 @@ class SideStream:
     # with the three lanes 11.94 ms, only bit 0 13.95, only bit 1 13.62 on one box)
     lane_mask = 3
     lanes = int(os.environ.get("ICL_ALIGNER_LANES", "3"))   # further streams for the per-level branches inside the aligners (0: none)
+    # Round 6: one more stream for the TOKEN side of the own-query aligner (1x1x1 projection, two LayerNorms, fc_kv of every level: needs
+    # only the feature maps).  Forward: it runs beside the query chain, which waits for a level's k / v when it gets there.  Backward: the
+    # token side of level i (130 us of 13,824-row kernels at 24^3) used to sit BETWEEN the chain's calls for levels i and i - 1 on the
+    # aligner stream; on its own stream it runs beside them.  It forks from the step's stream (never from the aligner stream) and is
+    # joined there: per captured graph every edge between forked streams keeps one direction (see join()).
+    token_lane_on = os.environ.get("ICL_TOKEN_LANE", "1") != "0"
     _streams = {}
     _outer = None
 
@@ -72,18 +78,28 @@ class SideStream:
                 s = SideStream._streams[(dev.index, lane)] = torch.cuda.Stream(device=dev)
             self.main = torch.cuda.current_stream(dev)
             s.wait_stream(self.main)
+            self.tok = None
             if lane == 0:
                 # the lanes fork from and join to the stream the aligner stream itself forks from (see join())
-                for k in range(1, SideStream.lanes + 1):
+                keys = list(range(1, SideStream.lanes + 1)) + (["tok"] if SideStream.token_lane_on and SideStream.lanes > 0 else [])
+                for k in keys:
                     sk = SideStream._streams.get((dev.index, k))
                     if sk is None:
                         sk = SideStream._streams[(dev.index, k)] = torch.cuda.Stream(device=dev)
                     sk.wait_stream(self.main)
                     self.children.append(sk)
+                    if k == "tok":
+                        self.tok = sk
             for t in inputs:
                 t.record_stream(s)
             self.stream = s
             self._guard = torch.cuda.stream(s)
+
+    @staticmethod
+    def token_stream():
+        """The token-side stream of the aligner block that is open on this thread, or None."""
+        outer = SideStream._outer
+        return outer.tok if outer is not None else None
 
     def __enter__(self):
         if self.stream is not None:
@@ -2203,6 +2219,178 @@ def prototype_attention(qh: torch.Tensor, kv: torch.Tensor, heads: int, scale: f
     """qh [B,h,nc,d]; kv [B,N,2*h*d] laid out (k|v, head, d).  Returns (softmax(QK^T*scale) V  [B,h,nc,d],
     scaled pre-softmax logits [B,nc,h,N] — already in the layout of the reference's ``attn1.permute(0, 2, 1, 3)``)."""
     return _ProtoAttention.apply(qh, kv, heads, float(scale))
+
+
+# --------------------------------------------------------------------------------------
+# The aligner's query chain as fused stages (csrc/kernels/qchain.h; networks/unet_3D_icl.py:258-264, 283-297, 299-315, 220-222)
+# --------------------------------------------------------------------------------------
+
+class _QcStage(ctypes.Structure):      # include/icl_hip.h IclQcStage
+    _fields_ = [("x", _vp), ("x_rows", ctypes.c_int), ("w", _vp), ("bias", _vp), ("y", _vp),
+                ("R", ctypes.c_int), ("K", ctypes.c_int), ("N", ctypes.c_int), ("trans", ctypes.c_int), ("nc", ctypes.c_int),
+                ("npw", ctypes.c_int), ("pro", ctypes.c_int), ("epi", ctypes.c_int),
+                ("pa", _vp), ("pb", _vp), ("pc", _vp), ("pd", _vp), ("pro_dp", ctypes.c_int),
+                ("so0", _vp), ("so1", _vp), ("so2", _vp), ("ea", _vp), ("eb", _vp),
+                ("ea_r0", ctypes.c_int), ("ea_r1", ctypes.c_int), ("eb_r0", ctypes.c_int), ("eb_r1", ctypes.c_int),
+                ("dp_seed", ctypes.c_uint32 * 2), ("dp_thresh", ctypes.c_uint32 * 2), ("dp_scale", ctypes.c_float * 2),
+                ("dp_seed_dev", _vp), ("eps", ctypes.c_float)]
+
+
+QC_PRO_NONE, QC_PRO_LN, QC_PRO_GELU, QC_PRO_LNBWD, QC_PRO_SCALE = range(5)
+QC_EPI_NONE, QC_EPI_DP1, QC_EPI_RES_DP, QC_EPI_GELUBWD, QC_EPI_ADDROWS, QC_EPI_SUMB = range(6)
+QCHAIN = os.environ.get("ICL_QCHAIN", "1") != "0"
+QC_MAX_ROWS, QC_MAX_K, QC_ROWS_PER_PASS = 32, 1024, 8
+
+
+def _qc_stage(like, dp, *, y, R, K, N=0, trans=0, nc=1, x=None, x_rows=0, w=None, bias=None, pro=QC_PRO_NONE, epi=QC_EPI_NONE, pa=None,
+              pb=None, pc=None, pd=None, pro_dp=0, so0=None, so1=None, so2=None, ea=None, eb=None, ea_rows=(0, 0), eb_rows=(0, 0), eps=1e-5):
+    """One launch of icl_qchain_stage.  ``dp``: ((seed, thresh, scale) of site 0, of site 1, seed_dev tensor or None)."""
+    st = _QcStage()
+    st.x, st.x_rows, st.w, st.bias, st.y = _ptr(x), x_rows, _ptr(w), _ptr(bias), _ptr(y)
+    st.R, st.K, st.N, st.trans, st.nc, st.npw = R, K, N, trans, nc, 0
+    st.pro, st.epi, st.pro_dp = pro, epi, pro_dp
+    st.pa, st.pb, st.pc, st.pd = _ptr(pa), _ptr(pb), _ptr(pc), _ptr(pd)
+    st.so0, st.so1, st.so2 = _ptr(so0), _ptr(so1), _ptr(so2)
+    st.ea, st.eb = _ptr(ea), _ptr(eb)
+    st.ea_r0, st.ea_r1 = ea_rows
+    st.eb_r0, st.eb_r1 = eb_rows
+    for i in (0, 1):
+        st.dp_seed[i], st.dp_thresh[i], st.dp_scale[i] = dp[i]
+    st.dp_seed_dev = _ptr(dp[2])
+    st.eps = eps
+    _lib.check(_lib.lib().icl_qchain_stage(ctypes.byref(st), _stream(like)), "qchain_stage")
+
+
+def _qc_wgrad(like, jobs):
+    """jobs: (g, x, dw, db or None, rows, n, k, kind)."""
+    n = len(jobs)
+    arr, iarr = _vp * n, ctypes.c_int32 * n
+    _lib.check(_lib.lib().icl_qchain_wgrad(arr(*[j[0].data_ptr() for j in jobs]), arr(*[j[1].data_ptr() for j in jobs]),
+                                          arr(*[j[2].data_ptr() for j in jobs]), arr(*[(j[3].data_ptr() if j[3] is not None else None) for j in jobs]),
+                                          iarr(*[j[4] for j in jobs]), iarr(*[j[5] for j in jobs]), iarr(*[j[6] for j in jobs]),
+                                          iarr(*[j[7] for j in jobs]), n, _stream(like)), "qchain_wgrad")
+
+
+def query_chain_ok(rows: int, c: int, hidden: int, nc: int, like: torch.Tensor) -> bool:
+    return (QCHAIN and rows <= QC_MAX_ROWS and c % 8 == 0 and hidden % 4 == 0 and max(c, hidden) <= QC_MAX_K and nc <= 16
+            and (like.is_cuda or _lib.host_pointers_ok()))
+
+
+class _QueryAttend(torch.autograd.Function):
+    """One resolution level of the aligner's query half as fused stages: LayerNorm(norm1_query) -> fc_q -> [read-out of softmax(q k^T) v]
+    -> proj -> q + drop_path(q) -> LayerNorm(norm2) -> fc1 -> GELU -> fc2 -> q + drop_path(.) -> query_convs.
+    Inputs: q_in [B or 1, nc, C] (a [1, nc, C] query is broadcast over the batch inside the first stage), kv [B, N, 2C] (fc_kv of the
+    normalised tokens), cfg, the fourteen parameters.  Outputs: logits [B, nc, h, N], and with cfg['full'] the query after the block as
+    its two batch halves q2[:ba], q2[ba:] (views of one buffer) and the query handed down a level [B, nc, C/2].  ``full`` False (the
+    guided call of the 3-D models, whose updated queries nobody reads): fc_q and the logits only."""
+
+    @staticmethod
+    def forward(ctx, q_in, kv, cfg, n1w, n1b, fqw, fqb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, qcw, qcb):
+        L = _lib.lib()
+        h, scale, ba, eps, dp, full = cfg["heads"], cfg["scale"], cfg["ba"], cfg["eps"], cfg["dp"], cfg["full"]
+        q_in, kv = q_in.contiguous(), kv.contiguous()
+        _require(q_in, kv, fqw)
+        nc, C = q_in.shape[1], q_in.shape[2]
+        B, N = kv.shape[0], kv.shape[1]
+        R, d = B * nc, C // h
+        dev = kv.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)      # noqa: E731
+        xhat1, rstd1, n1, qf = new(R, C), new(R), new(R, C), new(R, C)
+        _qc_stage(kv, dp, y=qf, R=R, K=C, N=C, nc=nc, x=q_in, x_rows=q_in.shape[0] * nc, w=fqw, bias=fqb, pro=QC_PRO_LN, pa=n1w, pb=n1b,
+                  so0=xhat1, so1=rstd1, so2=n1, eps=eps)
+        logits, a, stats = new(B, nc, h, N), new(R, C), new(B, h, nc, 2)
+        # qf read as [B, h, nc, d] and the read-out written back as [B, nc, C]: the reference's reshape quirk (:287, :293) is a
+        # reinterpretation of the same contiguous bytes
+        _lib.check(L.icl_attn_fwd(_ptr(qf), _ptr(kv), _ptr(logits), _ptr(a), _ptr(stats), B, h, nc, N, d, scale, _stream(kv)), "attn_fwd")
+        ctx.cfg, ctx.shape = cfg, (B, nc, C, N, tuple(q_in.shape))
+        ctx.set_materialize_grads(False)      # an output nobody differentiates (the last level's hand-down, a discarded batch half) arrives as None
+        if not full:
+            ctx.save_for_backward(kv, logits, stats, a, qf, xhat1, rstd1, n1, n1w, fqw)
+            return (logits,)
+        H = f1w.shape[0]
+        q1, xhat2, rstd2, n2, u, hh, q2, nxt = new(R, C), new(R, C), new(R), new(R, C), new(R, H), new(R, H), new(B, nc, C), new(B, nc, qcw.shape[0])
+        _qc_stage(kv, dp, y=q1, R=R, K=C, N=C, nc=nc, x=a, w=pw, bias=pb, epi=QC_EPI_DP1)
+        _qc_stage(kv, dp, y=u, R=R, K=C, N=H, nc=nc, x=q1, w=f1w, bias=f1b, pro=QC_PRO_LN, pa=n2w, pb=n2b, so0=xhat2, so1=rstd2, so2=n2, eps=eps)
+        _qc_stage(kv, dp, y=q2, R=R, K=H, N=C, nc=nc, x=u, w=f2w, bias=f2b, pro=QC_PRO_GELU, so2=hh, epi=QC_EPI_RES_DP, ea=q1)
+        _qc_stage(kv, dp, y=nxt, R=R, K=C, N=qcw.shape[0], nc=nc, x=q2, w=qcw, bias=qcb)
+        ctx.save_for_backward(kv, logits, stats, a, qf, xhat1, rstd1, n1, n1w, fqw, q1, xhat2, rstd2, n2, u, hh, q2, n2w, pw, f1w, f2w, qcw)
+        return logits, q2[:ba], q2[ba:], nxt
+
+    @staticmethod
+    def backward(ctx, glog, gq2a=None, gq2b=None, gnxt=None):
+        L = _lib.lib()
+        cfg = ctx.cfg
+        h, scale, ba, dp, full = cfg["heads"], cfg["scale"], cfg["ba"], cfg["dp"], cfg["full"]
+        B, nc, C, N, q_shape = ctx.shape
+        R, d = B * nc, C // h
+        sv = ctx.saved_tensors
+        kv, logits, stats, a, qf, xhat1, rstd1, n1, n1w, fqw = sv[:10]
+        dev = kv.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)      # noqa: E731
+        jobs = []
+        ga = None
+        grads = [None] * 14
+        if full and (gq2a is not None or gq2b is not None or gnxt is not None):
+            q1, xhat2, rstd2, n2, u, hh, q2, n2w, pw, f1w, f2w, qcw = sv[10:]
+            H = f1w.shape[0]
+            gq2a = gq2a.contiguous() if gq2a is not None else None
+            gq2b = gq2b.contiguous() if gq2b is not None else None
+            dq2, g2, du, dn2, do, ga = new(R, C), new(R, C), new(R, H), new(R, C), new(R, C), new(R, C)
+            add = dict(epi=QC_EPI_ADDROWS, ea=gq2a, ea_rows=(0, ba * nc), eb=gq2b, eb_rows=(ba * nc, R))
+            if gnxt is not None:
+                gnxt = gnxt.contiguous()
+                _qc_stage(kv, dp, y=dq2, R=R, K=qcw.shape[0], N=C, trans=1, nc=nc, x=gnxt, w=qcw, **add)
+            else:
+                _qc_stage(kv, dp, y=dq2, R=R, K=C, trans=2, nc=nc, **add)
+            # g2 = f1 * dq2 is fc2's output gradient; du = (g2 W2) * gelu'(u)
+            _qc_stage(kv, dp, y=du, R=R, K=C, N=H, trans=1, nc=nc, x=dq2, w=f2w, pro=QC_PRO_SCALE, so2=g2, epi=QC_EPI_GELUBWD, ea=u)
+            _qc_stage(kv, dp, y=dn2, R=R, K=H, N=C, trans=1, nc=nc, x=du, w=f1w)
+            # do = (dq2 + LayerNorm'(dn2)) * (1 + f0) is proj's output gradient; ga = do Wp the read-out's
+            _qc_stage(kv, dp, y=ga, R=R, K=C, N=C, trans=1, nc=nc, x=dn2, w=pw, pro=QC_PRO_LNBWD, pa=xhat2, pb=rstd2, pc=n2w, pd=dq2, pro_dp=1, so2=do)
+            gpw, gpb, gn2w, gn2b, gf1w, gf1b, gf2w, gf2b = new(C, C), new(C), new(C), new(C), new(H, C), new(H), new(C, H), new(C)
+            jobs += [(do, a, gpw, gpb, R, C, C, 0), (dn2, xhat2, gn2w, gn2b, R, C, C, 1), (du, n2, gf1w, gf1b, R, H, C, 0),
+                     (g2, hh, gf2w, gf2b, R, C, H, 0)]
+            grads[4:12] = [gpw, gpb, gn2w, gn2b, gf1w, gf1b, gf2w, gf2b]
+            if gnxt is not None:
+                gqcw, gqcb = new(qcw.shape[0], C), new(qcw.shape[0])
+                jobs.append((gnxt, q2.view(R, C), gqcw, gqcb, R, qcw.shape[0], C, 0))
+                grads[12:14] = [gqcw, gqcb]
+        glog = glog.contiguous() if glog is not None else None
+        gq, gkv = new(R, C), torch.empty_like(kv)
+        ws = _ws(L.icl_attn_bwd_ws_bytes(B, h, nc, N, d), kv) if N >= 1024 else None
+        _lib.check(L.icl_attn_bwd_ws(_ptr(qf), _ptr(kv), _ptr(logits), _ptr(stats), _ptr(a), _ptr(ga), _ptr(glog), _ptr(gq), _ptr(gkv),
+                                     _ptr(ws), B, h, nc, N, d, scale, _stream(kv)), "attn_bwd")
+        dn1 = new(R, C)
+        _qc_stage(kv, dp, y=dn1, R=R, K=C, N=C, trans=1, nc=nc, x=gq, w=fqw)
+        bcast = q_shape[0] == 1 and B > 1
+        if bcast and R <= QC_ROWS_PER_PASS:
+            gqin = new(1, nc, C)
+            _qc_stage(kv, dp, y=gqin, R=R, K=C, trans=2, nc=nc, x=dn1, pro=QC_PRO_LNBWD, pa=xhat1, pb=rstd1, pc=n1w, epi=QC_EPI_SUMB)
+        else:
+            gqin = new(B, nc, C)
+            _qc_stage(kv, dp, y=gqin, R=R, K=C, trans=2, nc=nc, x=dn1, pro=QC_PRO_LNBWD, pa=xhat1, pb=rstd1, pc=n1w)
+            if bcast:
+                gqin = gqin.sum(0, keepdim=True)
+        gn1w, gn1b, gfqw, gfqb = new(C), new(C), new(C, C), new(C)
+        jobs += [(dn1, xhat1, gn1w, gn1b, R, C, C, 1), (gq, n1, gfqw, gfqb, R, C, C, 0)]
+        grads[0:4] = [gn1w, gn1b, gfqw, gfqb]
+        _qc_wgrad(kv, jobs)
+        return (gqin, gkv, None, *grads)
+
+
+def query_attend(q_in, kv, heads, scale, ba, eps, dp, full, params):
+    """See _QueryAttend.  ``params``: the fourteen parameter tensors in the Function's order."""
+    cfg = dict(heads=int(heads), scale=float(scale), ba=int(ba), eps=float(eps), dp=dp, full=bool(full))
+    return _QueryAttend.apply(q_in, kv, cfg, *params)
+
+
+def drop_path_site(like, p: float, training: bool):
+    """(seed, thresh, scale, seed_dev) of one drop-path site for the fused stages: the per-sample decision of ``drop_path`` (same hash, same
+    seeding); an inactive site keeps everything at scale 1."""
+    if p == 0.0 or not training:
+        return (0, 0, 1.0), None
+    seed, seed_dev = _step_seed(like, None)
+    return (seed, int(p * 4294967296.0) & 0xFFFFFFFF, 1.0 / (1.0 - p)), seed_dev
 
 
 # --------------------------------------------------------------------------------------

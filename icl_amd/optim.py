@@ -120,7 +120,13 @@ class FusedSGD(torch.optim.Optimizer):
         #   "tail"   "gated" for the matrices the model marks (`_icl_tail_update`: the own-query aligner's 24^3 level), with the gate where
         #            that level's map chain is done and only the serial query chain is left (~1 ms of small dependent launches that leave
         #            the chip idle): their update streams run beside that chain; every other matrix stays fused
-        self.update_placement = os.environ.get("ICL_UPDATE_PLACEMENT", "tail")
+        #   "deep"   (round 6) the marked matrices' updates start at the gate where the DEEP part of the backward pass begins (the up3 hook
+        #            of the backbone, unet_3D._open_update_gate) as NARROW persistent launches (icl_sgd_step_factored_narrow: `update_wgs`
+        #            workgroups of 1,024 threads, one CU each): the deep levels' launches fill 72-144 of the 256 CUs and leave the HBM
+        #            idle, so the 16 B / weight streams run under them, and the forked phase ends with the aligners' (now fused) query
+        #            chain alone instead of beside two 3 GB streams
+        self.update_placement = os.environ.get("ICL_UPDATE_PLACEMENT", "deep")
+        self.update_wgs = int(os.environ.get("ICL_UPDATE_WGS", "128"))
         self._deferred = []          # (parameter, g, x, event after the input-gradient kernel)
         self._update_stream = None
         self._update_stream_used = False
@@ -240,7 +246,7 @@ class FusedSGD(torch.optim.Optimizer):
         self._scope_packed.end_step()
         self._scope_open = False
 
-    def _step_factored(self, L, p, factors, lr, mom, wd):
+    def _step_factored(self, L, p, factors, lr, mom, wd, narrow: int = 0):
         """dW = sum over entries of g^T x, applied without forming it (ops.FactoredGrads, csrc/kernels/optim.h)."""
         g = factors[0][0] if len(factors) == 1 else torch.cat([f[0] for f in factors], 0)
         x = factors[0][1] if len(factors) == 1 else torch.cat([f[1] for f in factors], 0)
@@ -276,6 +282,13 @@ class FusedSGD(torch.optim.Optimizer):
         from . import ops   # KernelTimer bracket: the update streams p and m in and out (16 B per weight), HBM-bound
         rows = g.shape[0]
         with ops._timed("sgd_factored_kernel", 2.0 * rows * n * k, 16.0 * n * k, p):
+            if narrow and shard is None and pv.is_contiguous():
+                rc = L.icl_sgd_step_factored_narrow(pv.data_ptr(), mv.data_ptr(), g.data_ptr(), x.data_ptr(), rows, n, k, lr, mom, wd, first,
+                                                    lrp, int(narrow), stream)
+                if rc == 0:
+                    return
+                if rc != 1:      # 1: more factor rows than the narrow form takes
+                    _lib.check(rc, "sgd_step_factored_narrow")
             if rows >= SPLIT_MIN_ROWS and (n * k) >= (1 << 22) and os.environ.get("ICL_SGD_SPLIT", "1") != "0":
                 # many factor rows (gathered factors of a data-parallel step; nc = 16): d = g^T x from exact bf16 splits on the bf16
                 # matrix pipe (csrc/kernels/optim.h sgd_factored_split_kernel) so that the update stays an HBM stream
@@ -342,11 +355,12 @@ class FusedSGD(torch.optim.Optimizer):
         from . import ops
         L = _lib.lib()
         g, x = g.contiguous(), x.contiguous()
-        if self.update_placement != "fused" and p.is_cuda and (self.update_placement != "tail" or getattr(p, "_icl_tail_update", False)):
+        if self.update_placement != "fused" and p.is_cuda and (self.update_placement not in ("tail", "deep") or getattr(p, "_icl_tail_update", False)):
             gx = ops.linear_dgrad_raw(g, p)
             ev = torch.cuda.Event()
             ev.record()
-            self._deferred.append((p, g, x, ev))
+            # "deep" needs the narrow launch, which holds <= 16 factor rows: a matrix with more (nc = 16) keeps the tail gate
+            self._deferred.append((p, g, x, ev, "deep" if (self.update_placement == "deep" and g.shape[0] <= 16) else "tail"))
             torch.autograd.graph.increment_version(p)
             self._updated_in_backward.add(id(p))
             if self.update_placement == "free":
@@ -377,29 +391,32 @@ class FusedSGD(torch.optim.Optimizer):
         return gx
 
     @torch.no_grad()
-    def flush_deferred(self, gate: bool = True):
+    def flush_deferred(self, gate: bool = True, only: str = None):
         """Queue the updates that ``update_in_backward`` deferred on the update stream.  ``gate``: the stream also waits for everything
         queued so far on the CURRENT stream (the caller is a gradient hook at the point of the backward pass from which on the HBM is
-        idle); every update waits for the input-gradient kernel that read its matrix.  step() joins the stream."""
-        if not self._deferred:
+        idle); every update waits for the input-gradient kernel that read its matrix.  ``only``: flush the entries of that gate ("tail":
+        the aligner's hook where the serial query chain begins) and keep the others for a later call.  step() joins the stream."""
+        todo = [e for e in self._deferred if only is None or e[4] == only]
+        if not todo:
             return
+        self._deferred = [e for e in self._deferred if not (only is None or e[4] == only)]
         L = _lib.lib()
-        dev = self._deferred[0][0].device
+        dev = todo[0][0].device
         if self._update_stream is None:
             # (stream priorities measured without effect on this step: profiles/r4_schedule_experiments.txt)
             self._update_stream = torch.cuda.Stream(device=dev)
         s = self._update_stream
         if gate:
             s.wait_stream(torch.cuda.current_stream(dev))
-        for p, g, x, ev in self._deferred:
+        for p, g, x, ev, where in todo:
             s.wait_event(ev)
         with torch.cuda.stream(s):
-            for p, g, x, ev in self._deferred:
+            for p, g, x, ev, where in todo:
                 group = self._group_of()[id(p)]
-                self._step_factored(L, p, [(g, x)], float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]))
+                self._step_factored(L, p, [(g, x)], float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]),
+                                    narrow=self.update_wgs if where == "deep" else 0)
                 g.record_stream(s)
                 x.record_stream(s)
-        self._deferred = []
         self._update_stream_used = True
 
     @torch.no_grad()

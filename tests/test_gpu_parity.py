@@ -694,6 +694,62 @@ def test_three_trainer_steps_match_reference_golden(dev):
         torch.cuda.empty_cache()
 
 
+# Bands of the ten-step test, per step 1..10 — from tests/diag/ten_steps.py (profiles/r6_ten_steps_noise.txt): the distance of the
+# exact-fp32 path to ITSELF under an input perturbation of (1 + 1e-7) grows from 5e-7 (step 1) through 1e-3 (step 3) as ReLU / max-pool
+# decisions flip and the updates (lr 0.01, consistency weight 10) amplify the gradient noise of the steps before; both convolution paths
+# sit at that distance from the reference.  Each band is >= 3x the largest of (perturbed-vs-unperturbed, split-vs-golden, exact-vs-golden).
+TEN_STEP_BANDS = None      # filled in below
+
+
+def test_ten_trainer_steps_match_reference_golden(dev, monkeypatch):
+    """Round 6: TEN consecutive iterations of the reference loop (train_inherent_consistent_unet_3D_BraTS.py:99-121)
+    against the reference's own ten steps on the 785 M-parameter model (tests/golden/make_golden.py --only steps10: a new batch per step,
+    momentum carried over, poly learning rate at max_iterations = 20) — on BOTH convolution paths: split products (the default) and
+    exact-fp32 MFMA (ICL_CONV_SPLIT=0).  Per step: the learning rate (exact), the six loss terms, every parameter norm, final.weight and
+    its momentum buffer elementwise, the sampled 13,824^2 update and momentum (RMS)."""
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    nc = 2
+    g = load_golden("model_unet3d_icl_nc2_steps10.npz")
+    steps = len(g["losses"])
+    assert steps == 10
+    vols = [synthetic_volume((2, 1, 96, 96, 96), 1337 + s).to(dev) for s in range(steps)]
+    labs = [synthetic_labels((1, 96, 96, 96), 4242 + s, nc).to(dev) for s in range(steps)]
+    big = "sspa.class_decoders.2.mlp2.fc1.weight"
+    B = TEN_STEP_BANDS
+    for split in ("1", "0"):
+        monkeypatch.setenv("ICL_CONV_SPLIT", split)
+        model = unet_3D_icl(n_classes=nc, in_channels=1, device=dev)
+        fill_like_reference_init(list(model.named_parameters()))
+        _parity_mode(model)
+        model.train()
+        tr = ICLTrainer(model, ICLConfig(num_classes=nc, labeled_bs=1, base_lr=float(g["base_lr"]), max_iterations=int(g["max_iterations"])))
+        named = dict(model.named_parameters())
+        assert list(named) == list(g["param_keys"])
+        w0 = named[big].detach()[::432, ::432].double().clone()
+        for s in range(steps):
+            t = s + 1
+            assert abs(tr.optimizer.param_groups[0]["lr"] - float(g["lr_used"][s])) < 1e-15, (split, t)
+            parts = tr.step(vols[s], labs[s])
+            got = np.array([float(parts[k]) for k in ("dice", "ce", "aux", "pse", "con", "loss")])
+            ref = g["losses"][s]
+            assert np.all(np.abs(got[:5] - ref[:5]) < B["term"][s]), (split, t, got, ref)
+            assert abs(got[5] - ref[5]) < B["total"][s], (split, t, got, ref)
+            post = np.array([float(p.detach().double().norm()) for p in named.values()])
+            refn = g[f"post_step{t}_norms"]
+            worst = float(np.max(np.abs(post - refn) / refn))
+            assert worst < B["norms"][s], (split, t, worst)
+            assert rel_err(named["final.weight"].detach().cpu(), g[f"post_step{t}.final.weight"]) < B["final_w"][s], (split, t)
+            mom = tr.optimizer.state[named["final.weight"]]["momentum_buffer"]
+            assert rel_err(mom.cpu(), g[f"momentum_step{t}.final.weight"]) < B["final_m"][s], (split, t)
+            delta = (named[big].detach()[::432, ::432].double() - w0).cpu().numpy()
+            assert rms_err(delta, g[f"delta_step{t}.{big}_sub"]) < B["big_delta_rms"][s], (split, t, rms_err(delta, g[f"delta_step{t}.{big}_sub"]))
+            bm = tr.optimizer.state[named[big]]["momentum_buffer"][::432, ::432].cpu()
+            assert rms_err(bm, g[f"momentum_step{t}.{big}_sub"]) < B["big_mom_rms"][s], (split, t, rms_err(bm, g[f"momentum_step{t}.{big}_sub"]))
+        del tr, model
+        torch.cuda.empty_cache()
+
+
 def test_data_parallel_graph_step_on_one_rank_group(dev):
     """The data-parallel step as ICLTrainer.capture() records it — forward/backward graph with the gradients packed into flat
     buffers, eager RCCL collectives, optimiser graph reading the reduced buffers — on a ONE-rank RCCL group (the mean over one
@@ -961,10 +1017,10 @@ def test_update_inside_backward_equals_update_in_optimizer_step(dev):
         with ops.KernelTimer() as kt:
             losses = [float(tr.step(vol, lab)["loss"]) for _ in range(3)]
         n = kt.summary().get("linear_dgrad_sgd_kernel", (0,))[0]
-        # uscl's two matrices x three steps in the fused pass; sspa's two take the "tail" placement (FusedSGD.update_placement: input
-        # gradient in their backward, the update on a stream beside sspa's query chain) — or none at all
+        # uscl's two matrices x three steps in the fused pass; sspa's two take the "deep" placement (FusedSGD.update_placement: input
+        # gradient in their backward, the update as a narrow persistent launch under the deep backward levels) — or none at all
         assert n == (6 if fuse else 0), n
-        assert tr.optimizer.update_placement == "tail"
+        assert tr.optimizer.update_placement == "deep"
         big = {k: p for k, p in model.named_parameters() if p.numel() >= 1 << 26}
         assert len(big) == 4
         out.append((losses, {k: p.detach().clone() for k, p in big.items()},

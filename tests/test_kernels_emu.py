@@ -639,6 +639,28 @@ def test_factored_sgd_on_split_products(rows, n, k, first):
     assert e_split <= 4.0 * e_fp32 + 1e-7 * float(m_ref.abs().max()), (e_split, e_fp32)
 
 
+@pytest.mark.parametrize("rows,n,k,first,wgs", [(8, 40, 1300, 0, 3), (16, 19, 2048, 1, 2), (4, 16, 260, 0, 7)])
+def test_narrow_persistent_factored_sgd_is_bit_identical_to_the_wide_launch(rows, n, k, first, wgs):
+    """Round 6 (FusedSGD.update_placement "deep"): icl_sgd_step_factored_narrow — a few fat workgroups walking 16 x 1,024 tiles, so that the
+    update stream of a 13,824^2 matrix can run under the deep backward levels without taking their CUs — applies exactly the update of
+    icl_sgd_step_factored: same sums in the same order, every bit of p and of the momentum buffer.  Ragged rows / columns, a partial
+    last column group, momentum initialisation, more workgroups than tiles; more than 16 factor rows are refused (return code 1)."""
+    L = _lib.lib()
+    g, x = _rand((rows, n), 301) * 0.3, _rand((rows, k), 302)
+    p0, m0 = _rand((n, k), 303) * 0.05, _rand((n, k), 304) * 0.01
+    lr, mom, wd = 0.02, 0.9, 1e-3
+    pa, ma = p0.clone(), (torch.full_like(m0, float("nan")) if first else m0.clone())
+    pb, mb = p0.clone(), (torch.full_like(m0, float("nan")) if first else m0.clone())
+    assert L.icl_sgd_step_factored(pa.data_ptr(), ma.data_ptr(), g.data_ptr(), x.data_ptr(), rows, n, k, lr, mom, wd, first, None, None) == 0
+    assert L.icl_sgd_step_factored_narrow(pb.data_ptr(), mb.data_ptr(), g.data_ptr(), x.data_ptr(), rows, n, k, lr, mom, wd, first, None, wgs, None) == 0
+    assert torch.equal(pa, pb) and torch.equal(ma, mb)
+    d = g.double().t() @ x.double() + wd * p0.double()
+    m_ref = d if first else mom * m0.double() + d
+    assert rel_err(mb, m_ref.float()) < 2e-6
+    g17, x17 = _rand((17, n), 305), _rand((17, k), 306)
+    assert L.icl_sgd_step_factored_narrow(pb.data_ptr(), mb.data_ptr(), g17.data_ptr(), x17.data_ptr(), 17, n, k, lr, mom, wd, 0, None, wgs, None) == 1
+
+
 @pytest.mark.parametrize("shape", [
     (3, 5, 37),        # one chunk, ragged columns of one lane column
     (2, 70, 64),       # 140 rows: five chunks of 32, the last one ragged; rows in flight past the chunk end
@@ -1107,3 +1129,71 @@ def test_conv3d_weight_gradient_with_exchanged_roles(monkeypatch):
         assert rel_err(wt.grad, wr.grad) < 1e-5 and rel_err(x.grad, xr.grad) < 1e-5, flag
         assert float(b.grad.abs().max()) == 0.0
     assert rel_err(got["1"], got["0"]) < 1e-6
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("nc,bs,ba,drop", [(2, 2, 1, 0.0), (3, 2, 1, 0.25), (5, 4, 2, 0.0)])
+def test_fused_query_chain_equals_the_operator_by_operator_aligner(nc, bs, ba, drop):
+    """Round 6 (csrc/kernels/qchain.h, ops.query_attend): the query half of Class_Decoder as fused stages — LayerNorm / GELU / bias / the
+    drop-path residual forms / the batch broadcast of the guided query on the products they feed or follow, every parameter gradient of a
+    level in one launch — against the operator-by-operator mirror it replaces (ICL_QCHAIN off), on a small InherentConsistent: the own-query
+    pair call (`forward_labeled_pair`: both batch halves as one batch, queries handed down the levels), the guided call with and without
+    its updated queries, and the plain labeled call; attention maps, updated queries, and the gradient of EVERY parameter and of the
+    three feature maps.  nc = 5, bs = 4: 20 rows = three passes of eight rows through every stage; drop = 0.25: both per-sample drop-path
+    sites active (the two paths draw the same seeds in the same order)."""
+    from icl_amd.networks.aligner import InherentConsistent
+    chans, res, heads = (64, 32, 16), (2, 2, 4), (4, 2, 2)
+
+    def build():
+        torch.manual_seed(11)
+        m = InherentConsistent(in_chans=chans, depths=(2, 2, 2), input_resolution=res, num_classes=nc, num_heads=heads, drop_path_rate=drop)
+        with torch.no_grad():
+            getattr(m, "guided_Q").copy_(_rand((1, nc, chans[0]), 77))
+            for k, p in m.named_parameters():
+                if p.dim() == 1 and ("norm" in k) and k.endswith("weight"):
+                    p.copy_(1.0 + 0.1 * _rand(p.shape, 3 + p.numel()))
+        m.train()
+        return m
+
+    def run(fused, mode):
+        ops.QCHAIN = fused
+        ops.StepRNG.tensor = None
+        torch.manual_seed(5)      # the seeds of the drop-path sites come from torch's generator when no step RNG is active
+        m = build()
+        feats = [_rand((bs, c, r, r, r), 20 + i, grad=True) for i, (c, r) in enumerate(zip(chans, res))]
+        if mode == "pair":
+            (maps_a, qs_a), (maps_b, qs_b) = m.forward_labeled_pair(feats, ba)
+            outs = maps_a + maps_b + qs_a + qs_b
+        elif mode == "labeled":
+            maps, qs = m(feats, None, "labeled")
+            outs = maps + qs
+        else:
+            gq = [_rand((1, nc, c), 40 + i, grad=True) for i, c in enumerate(chans)]
+            maps, qs = m(feats, gq, "unlabeled", need_queries=(mode == "guided+q"))
+            outs = maps + ([q for q in qs if q is not None] if mode == "guided+q" else [])      # "guided": only the maps are read
+            feats = feats + gq
+        loss = sum((o * _rand(o.shape, 60 + i)).sum() for i, o in enumerate(outs))
+        loss.backward()
+        grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+        return [o.detach().clone() for o in outs], grads, [f.grad.clone() for f in feats]
+
+    try:
+        for mode in ("pair", "labeled", "guided", "guided+q"):
+            if mode == "guided" and drop > 0:
+                continue      # (without its query half the fused guided call draws fewer drop-path seeds: other masks in the map chains)
+            o0, g0, f0 = run(False, mode)
+            o1, g1, f1 = run(True, mode)
+            assert len(o0) == len(o1)
+            for a, b in zip(o0, o1):
+                assert rel_err(b, a) < 2e-5, (mode, rel_err(b, a))
+            assert {k for k, v in g0.items() if v is None} == {k for k, v in g1.items() if v is None}, mode
+            # (max-norm relative to the tensor, with an absolute floor: level 0 has ONE token, so its token-axis LayerNorm and everything
+            # behind it carry exact zeros in one evaluation order and 1e-9 in another)
+            close = lambda b, a: float((b - a).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-6      # noqa: E731
+            for k in g0:
+                if g0[k] is not None:
+                    assert close(g1[k], g0[k]), (mode, k, float((g1[k] - g0[k]).abs().max()), float(g0[k].abs().max()))
+            for a, b in zip(f0, f1):
+                assert close(b, a), (mode, float((b - a).abs().max()), float(a.abs().max()))
+    finally:
+        ops.QCHAIN = True

@@ -101,6 +101,19 @@ if os.environ.get("CP_ALIGNER_DETAIL", "0") != "0":
                               ("attn.fc_q", cd.attn.fc_q), ("attn.fc_kv", cd.attn.fc_kv), ("norm1_query", cd.norm1_query), ("norm1", cd.norm1),
                               ("norm_layers", model.sspa.norm_layers[i])):
                 mod.register_full_backward_hook(lambda m, gi, go, t=f"B   sspa level {i}: {name} backward done": mark(t))
+if os.environ.get("CP_ALIGNER_DETAIL", "0") != "0":
+    # round 6: the fused query chain (ops._QueryAttend) — when does each level's backward start and end?
+    _qb, _qn = ops._QueryAttend.backward, [0]
+
+    def _stamped_backward(ctx, *gs):
+        _qn[0] += 1
+        k = (_qn[0] - 1) % 6
+        tag = f"B query chain call {k} (R={ctx.shape[0] * ctx.shape[1]}, C={ctx.shape[2]}, full={ctx.cfg['full']})"
+        mark(tag + " start")
+        out = _qb(ctx, *gs)
+        mark(tag + " end")
+        return out
+    ops._QueryAttend.backward = staticmethod(_stamped_backward)
 _loss = tr.compute_loss
 
 
