@@ -65,7 +65,7 @@ def exchange_plan(rows_gathered: int, elems: int, world: int, allgather_gbps: fl
 
 
 def project_world(matrices, world: int, base_ms: float, allgather_gbps: float = ASSUMED_ALLGATHER_GBPS, allreduce_gbps: float = 250.0,
-                  small_grad_bytes: float = 34e6, factor_bytes_per_rank: float = 0.0, shard_min_rows: int = None):
+                  small_grad_bytes: float = 34e6, factor_bytes_per_rank: float = 0.0, shard_min_rows: int = None, _nested: bool = False):
     """Projected step time on `world` ranks from a ONE-rank measurement (`base_ms`: the data-parallel step on a one-rank group, whose
     token-axis updates are the whole factored updates at the one-rank row counts) — the arithmetic behind ``config.ddp_plan.projection``
     of bench.py, stated so that it can be checked once a multi-GPU node is available:
@@ -99,7 +99,27 @@ def project_world(matrices, world: int, base_ms: float, allgather_gbps: float = 
     small = (2.0 * (world - 1) / world * small_grad_bytes / (allreduce_gbps * 1e6) if world > 1 else 0.0)
     factors = world * factor_bytes_per_rank / (allgather_gbps * 1e6) if world > 1 else 0.0
     total = base_ms + extra + exposed_ag + small + factors
+    # the link rate at which this configuration still reaches the target of 6x on 8 ranks (efficiency 0.75): the projection re-run at scaled
+    # rates (all-reduce kept in proportion) — how much margin the ASSUMED rates leave
+    break_even = None
+    if world > 1 and not _nested:
+        lo, hi = 5.0, max(allgather_gbps, 5.0)
+        eff = lambda r: project_world(matrices, world, base_ms, r, allreduce_gbps * r / allgather_gbps, small_grad_bytes, factor_bytes_per_rank,     # noqa: E731
+                                      shard_min_rows, _nested=True)["projected_scaling_efficiency"]
+        want = 6.0 / 8.0 if world == 8 else 0.75
+        if eff(hi) >= want:
+            for _ in range(40):
+                mid = 0.5 * (lo + hi)
+                if eff(mid) >= want:
+                    hi = mid
+                else:
+                    lo = mid
+            break_even = {"target_efficiency": want, "allgather_gbps": round(hi, 1), "allreduce_gbps": round(allreduce_gbps * hi / allgather_gbps, 1),
+                          "margin_vs_assumed": round(allgather_gbps / hi, 2)}
+        else:
+            break_even = {"target_efficiency": want, "allgather_gbps": None, "note": "the target is not reached at the assumed rates"}
     return {"world": world, "base_ms_one_rank_group": round(base_ms, 3), "update_extra_ms": round(extra, 3),
+            **({"break_even_link_rate": break_even} if break_even else {}),
             "row_allgather_ms": round(ag_total, 3), "row_allgather_exposed_ms": round(exposed_ag, 3),
             "small_gradient_allreduce_ms": round(small, 3), "factor_row_allgather_ms": round(factors, 3),
             "projected_ms_per_step": round(total, 3), "projected_scaling_efficiency": round(base_ms / total, 3),

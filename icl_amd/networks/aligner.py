@@ -51,6 +51,10 @@ class BatchNorm3d(BatchNormAct):
         super().__init__(c, 1, device)
 
 
+# which lane the guided call's level i takes: 1 + (i + rot) % 3 (rot 0: the lane of the own-query call's level i)
+USCL_LANE_ROT = int(__import__("os").environ.get("ICL_USCL_LANE_ROT", "0"))
+
+
 def _open_tail_gate(grad):
     opt = ops.FactoredGrads.fused_optimizer
     if opt is not None and getattr(opt, "update_placement", "") in ("tail", "deep"):
@@ -344,7 +348,7 @@ class InherentConsistent(nn.Module):
         for i in range(len(self.depth)):
             # guided queries (unet_3D_icl.py:224-239; its unused next_guided_Q is not computed): the levels do not depend on each other at all — a whole level per lane; own queries:
             # only the map chain leaves the current stream (see forward_labeled_pair)
-            whole = None if labeled else ops.SideStream([feats[i], guided_Q[i]], lane=(1 + i) if ops.SideStream.lane_mask & 2 else 99)
+            whole = None if labeled else ops.SideStream([feats[i], guided_Q[i]], lane=(1 + (i + USCL_LANE_ROT) % 3) if ops.SideStream.lane_mask & 2 else 99)
             with (whole if whole is not None else contextlib.nullcontext()):
                 tok = self._tokens(i, feats[i])
                 q_in = nxt if labeled else guided_Q[i]

@@ -2240,6 +2240,11 @@ QC_PRO_NONE, QC_PRO_LN, QC_PRO_GELU, QC_PRO_LNBWD, QC_PRO_SCALE = range(5)
 QC_EPI_NONE, QC_EPI_DP1, QC_EPI_RES_DP, QC_EPI_GELUBWD, QC_EPI_ADDROWS, QC_EPI_SUMB = range(6)
 QCHAIN = os.environ.get("ICL_QCHAIN", "1") != "0"
 QC_MAX_ROWS, QC_MAX_K, QC_ROWS_PER_PASS = 32, 1024, 8
+# Rows up to which the aligner takes the fused chain.  The stages walk the rows in passes of eight, re-reading the workgroup's weight slice per
+# pass: with nc = 16 (32 / 16 rows) the fused chain measured SLOWER than the operator-by-operator path whose products run on the MFMA stream
+# kernel (15.58 against 15.30 ms per step, profiles/r6_qchain_ab.txt), so it is taken for one pass only (nc = 2: 4 / 2 rows); the kernels and
+# their tests cover 32 rows.
+QC_FUSE_MAX_ROWS = int(os.environ.get("ICL_QCHAIN_MAX_ROWS", str(QC_ROWS_PER_PASS)))
 
 
 def _qc_stage(like, dp, *, y, R, K, N=0, trans=0, nc=1, x=None, x_rows=0, w=None, bias=None, pro=QC_PRO_NONE, epi=QC_EPI_NONE, pa=None,
@@ -2272,7 +2277,7 @@ def _qc_wgrad(like, jobs):
 
 
 def query_chain_ok(rows: int, c: int, hidden: int, nc: int, like: torch.Tensor) -> bool:
-    return (QCHAIN and rows <= QC_MAX_ROWS and c % 8 == 0 and hidden % 4 == 0 and max(c, hidden) <= QC_MAX_K and nc <= 16
+    return (QCHAIN and rows <= min(QC_MAX_ROWS, QC_FUSE_MAX_ROWS) and c % 8 == 0 and hidden % 4 == 0 and max(c, hidden) <= QC_MAX_K and nc <= 16
             and (like.is_cuda or _lib.host_pointers_ok()))
 
 

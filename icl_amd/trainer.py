@@ -60,6 +60,10 @@ class ICLTrainer:
         self.graph_update = None
         self.graph_update_rest = None
         self.use_graph = True     # False: launch eagerly although a captured graph exists (bench.py --launch auto compares the two)
+        # data-parallel replay only: set `time_phases` and every step records four events on its stream — start, forward + backward +
+        # pack() done, collectives done, update done; `phase_times()` turns the last step's into milliseconds (bench.py's config.ddp_phases)
+        self.time_phases = False
+        self._phase_events = None
         self.lr_dev = None
 
     def compute_loss(self, outputs, label_batch):
@@ -178,20 +182,41 @@ class ICLTrainer:
                 self.static_vol.copy_(volume_batch)
             if label_batch.data_ptr() != self.static_lab.data_ptr():
                 self.static_lab.copy_(label_batch)
+            ev = None
+            if self.time_phases and self.graph_update is not None:
+                ev = self._phase_events = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                ev[0].record()
             if self.graph_forward is not None:
                 self.graph_forward.replay()
             self.graph.replay()
             if self.graph_update is not None:    # data-parallel: collectives between the graphs
+                if ev:
+                    ev[1].record()
                 self.ddp.communicate()
+                if ev:
+                    ev[2].record()
                 self.graph_update.replay()           # unpack + the updates of the row-sharded matrices
                 self.ddp.post_update(async_op=True)  # their all-gathers, under ...
                 self.graph_update_rest.replay()      # ... the rest of the optimiser step
                 self.ddp.finish_post_update()
+                if ev:
+                    ev[3].record()
             parts = self.static_out
         else:
             parts = self._step_body(volume_batch, label_batch)
         self._advance_lr()
         return parts
+
+    def phase_times(self):
+        """Milliseconds of the last data-parallel replayed step's phases (needs `time_phases`; synchronises): forward + backward + pack(),
+        the collectives as the step's stream sees them (what is NOT hidden under compute: they are issued after backward), the update
+        (both optimiser graphs and whatever of the row all-gathers is not hidden under the second one)."""
+        ev = self._phase_events
+        if not ev:
+            return None
+        ev[3].synchronize()
+        return {"forward_backward_ms": ev[0].elapsed_time(ev[1]), "exposed_collective_ms": ev[1].elapsed_time(ev[2]),
+                "update_ms": ev[2].elapsed_time(ev[3])}
 
     def capture(self, volume_batch: torch.Tensor, label_batch: torch.Tensor, warmup: int = 3):
         """Capture one full iteration into a hipGraph (torch.cuda.CUDAGraph).  Every per-step scalar the kernels need —

@@ -39,6 +39,16 @@ def _parity_mode(model):
             mod.drop_prob = 0.0
 
 
+# Bands of the dense input-gradient samples (see _input_gradient_errors; measured: profiles/r6_dense_dgrad_errors.txt, both paths).  The
+# 12^3 blocks agree to 1e-5 (decoder) / 2-4e-3 (encoder, the deepest gradient of the model); a stride-8 lattice over the whole volume also
+# meets the isolated voxels where a ReLU / max-pool decision of one fp32 evaluation differs from the other's — there the gradient is
+# present in one and absent in the other (1.4e-2 ... 3.0e-2 of the tensor's largest element, on the exact-fp32 path as on the split one):
+# the lattice is held to that size in the max-norm and to a small FRACTION of such voxels.
+DGRAD_BANDS = {("up_concat1.conv.conv1", "block"): 2e-5, ("up_concat1.conv.conv1", "lattice"): 6e-2,
+               ("conv1.conv2", "block"): 8e-3, ("conv1.conv2", "lattice"): 3e-2}
+DGRAD_OUTLIERS = 5e-3      # fraction of sampled elements further than 1e-3 of the largest element from the reference
+
+
 def _reference_loop_body(model, volume_batch, label_batch, labeled_bs, num_classes, base_lr, fused_swap=False):
     """The statements of the reference `train()` between building the optimiser and `optimizer.step()`, with its names.
     ``fused_swap``: the ONE line INTEGRATION.md §2 changes — `icl_amd.optim.FusedSGD` for `optim.SGD`."""
@@ -68,6 +78,39 @@ def _reference_loop_body(model, volume_batch, label_batch, labeled_bs, num_class
     grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
     optimizer.step()
     return [loss_dice.item(), loss_ce.item(), loss_aux.item(), loss_pse.item(), loss_aux_consis.item(), loss.item()], grads
+
+
+def _keep_input_gradients(model):
+    """Forward pre-hooks that keep the gradient of the INPUT of two 96^3 convolution blocks — `up_concat1.conv.conv1` (the 48-channel
+    concat buffer) and `conv1.conv2` (16 channels) — the tensors the input-gradient kernels produce at their largest shapes.  Returns
+    (kept, remove): kept[name] is the input tensor (both streams as one batch: sample 0 labeled, 1 unlabeled) with `.grad` after backward."""
+    kept, hooks = {}, []
+
+    def keep(name):
+        def hook(module, args):
+            if args[0].requires_grad:
+                args[0].retain_grad()
+                kept[name] = args[0]
+        return hook
+    hooks.append(model.up_concat1.conv.conv1.register_forward_pre_hook(keep("up_concat1.conv.conv1")))
+    hooks.append(model.conv1.conv2.register_forward_pre_hook(keep("conv1.conv2")))
+    return kept, lambda: [h.remove() for h in hooks]
+
+
+def _input_gradient_errors(kept, dense):
+    """(name, part, max-norm error relative to the largest element of the whole reference gradient, fraction of elements whose error
+    exceeds 1e-3 of that scale) for the dense 12^3 block and the stride-8 lattice of every stream the reference has a gradient for
+    (golden: make_golden.py --only wgrads)."""
+    out = []
+    for name, t in kept.items():
+        g = t.grad.detach().cpu().numpy()
+        streams = list(dense[f"dgrad.{name}.streams"])
+        scale = float(dense[f"dgrad.{name}.maxabs"][0])
+        got_b, got_l = g[streams][:, :, 40:52, 40:52, 40:52], g[streams][:, :, 3::8, 3::8, 3::8]
+        for part, got, ref in (("block", got_b, dense[f"dgrad.{name}.block"]), ("lattice", got_l, dense[f"dgrad.{name}.lattice"])):
+            e = np.abs(got - ref) / scale
+            out.append((name, part, float(e.max()), float((e > 1e-3).mean())))
+    return out
 
 
 def _check_step(model, g, losses_got, grads, elementwise, norm_skip=lambda k: False):
@@ -109,7 +152,9 @@ def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root, monkeyp
         dev = next(model.parameters()).device
         vol = synthetic_volume((2, 1, 96, 96, 96), 1337).to(dev)
         lab = synthetic_labels((1, 96, 96, 96), 4242, 2).to(dev)
+        kept, unhook = _keep_input_gradients(model)
         got, grads = _reference_loop_body(model, vol, lab, labeled_bs=1, num_classes=2, base_lr=0.01)
+        unhook()
         full = lambda t: t                                             # noqa: E731
         elementwise = [
             ("final.weight", full, 1e-3), ("final.bias", full, 1e-3), ("conv1.conv1.0.weight", full, 2e-2), ("sspa.guided_Q", full, 5e-3),
@@ -130,6 +175,10 @@ def test_reference_loop_body_unet3d_icl_through_compat_root(compat_root, monkeyp
         for key, tol in (("up_concat1.conv.conv1.0.weight", 1.2e-3), ("up_concat1.conv.conv2.0.weight", 5e-4),
                          ("up_concat2.conv.conv1.0.weight", 4e-3), ("conv1.conv2.0.weight", 1.2e-2), ("conv2.conv2.0.weight", 1.3e-2)):
             assert rel_err(grads[key].cpu(), dense["grad." + key]) < tol, (key, conv_split)
+        # Round 6: two INPUT gradients of 96^3 convolutions, dense 12^3 block + stride-8 lattice, relative to the largest element of the
+        # reference's whole tensor (tests/diag/dense_wgrad_errors.py prints them for both paths; bands 2x the larger measurement)
+        for name, part, err, frac in _input_gradient_errors(kept, dense):
+            assert err < DGRAD_BANDS[name, part] and frac < DGRAD_OUTLIERS, (name, part, err, frac, conv_split)
         assert rel_err(model.final.weight.detach().cpu(), g["post_sgd.final.weight"]) < 1e-5
         # the first convolution's gradient is the deepest of the model (2e-2 band above); times lr = 0.01 on O(0.3) weights
         assert rel_err(model.conv1.conv1[0].weight.detach().cpu(), g["post_sgd.conv1.conv1.0.weight"]) < 1e-4

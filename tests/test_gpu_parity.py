@@ -698,7 +698,19 @@ def test_three_trainer_steps_match_reference_golden(dev):
 # exact-fp32 path to ITSELF under an input perturbation of (1 + 1e-7) grows from 5e-7 (step 1) through 1e-3 (step 3) as ReLU / max-pool
 # decisions flip and the updates (lr 0.01, consistency weight 10) amplify the gradient noise of the steps before; both convolution paths
 # sit at that distance from the reference.  Each band is >= 3x the largest of (perturbed-vs-unperturbed, split-vs-golden, exact-vs-golden).
-TEN_STEP_BANDS = None      # filled in below
+# (Bands never shrink from one step to the next: the measured noise of a single run fluctuates, its envelope grows.)  By step 10 the noise
+# of ONE fp32 evaluation against another is 1.6 % of the total loss and 36 % (RMS) of the sampled 13,824^2 momentum — a sample of a
+# cancellation-heavy gradient is mostly rounding noise after ten amplifying updates, so its momentum is asserted for the first five steps
+# only (band < 1) and the accumulated update of the same sample, which averages the noise, for all ten.
+TEN_STEP_BANDS = {
+    "term": (2e-5, 2e-4, 2e-3, 5e-3, 6e-3, 9e-3, 9e-3, 9e-3, 2e-2, 2e-2),
+    "total": (2e-5, 9e-4, 1e-2, 1e-2, 6e-2, 9e-2, 9e-2, 9e-2, 2e-1, 2e-1),
+    "norms": (3e-4, 3e-4, 4e-4, 2e-3, 2e-3, 3e-3, 5e-3, 7e-3, 9e-3, 2e-2),
+    "final_w": (1e-6, 1e-6, 5e-6, 2e-5, 5e-5, 1e-4, 2e-4, 3e-4, 4e-4, 6e-4),
+    "final_m": (3e-6, 6e-5, 5e-4, 2e-3, 3e-3, 6e-3, 1e-2, 2e-2, 2e-2, 2e-2),
+    "big_delta_rms": (5e-2, 6e-2, 1e-1, 2e-1, 3e-1, 3e-1, 4e-1, 4e-1, 5e-1, 5e-1),
+    "big_mom_rms": (5e-2, 8e-2, 3e-1, 4e-1, 6e-1, None, None, None, None, None),
+}
 
 
 def test_ten_trainer_steps_match_reference_golden(dev, monkeypatch):
@@ -744,10 +756,51 @@ def test_ten_trainer_steps_match_reference_golden(dev, monkeypatch):
             assert rel_err(mom.cpu(), g[f"momentum_step{t}.final.weight"]) < B["final_m"][s], (split, t)
             delta = (named[big].detach()[::432, ::432].double() - w0).cpu().numpy()
             assert rms_err(delta, g[f"delta_step{t}.{big}_sub"]) < B["big_delta_rms"][s], (split, t, rms_err(delta, g[f"delta_step{t}.{big}_sub"]))
-            bm = tr.optimizer.state[named[big]]["momentum_buffer"][::432, ::432].cpu()
-            assert rms_err(bm, g[f"momentum_step{t}.{big}_sub"]) < B["big_mom_rms"][s], (split, t, rms_err(bm, g[f"momentum_step{t}.{big}_sub"]))
+            if B["big_mom_rms"][s] is not None:
+                bm = tr.optimizer.state[named[big]]["momentum_buffer"][::432, ::432].cpu()
+                assert rms_err(bm, g[f"momentum_step{t}.{big}_sub"]) < B["big_mom_rms"][s], (split, t, rms_err(bm, g[f"momentum_step{t}.{big}_sub"]))
         del tr, model
         torch.cuda.empty_cache()
+
+
+def test_split_and_exact_paths_stay_together_over_200_steps(dev, monkeypatch):
+    """Round 6: a real horizon.  200 trainer steps from one seed (dropout / drop-path off, eight synthetic batches
+    cycled, lr 0.01) on the split-product convolutions and on the exact-fp32 ones: the two loss trajectories stay within the band that
+    ROUNDING NOISE ALONE produces over the same horizon — the exact path against itself with every input scaled by (1 + 1e-7) measured
+    3.0e-2 / 3.7e-2 / 1.0e-2 as the largest loss difference over steps 1-10 / 11-50 / 51-200 and 0.37 / 0.33 / 0.12 RMS on the sampled
+    13,824^2 momentum at steps 10 / 50 / 200; split against exact measured 3.2e-2 / 3.5e-2 / 1.1e-2 and 0.36 / 0.32 / 0.16
+    (tests/diag/drift_200.py, profiles/r6_drift.txt).  Bands 3x the noise; both losses fall (4.05 -> 2.45)."""
+    from icl_amd.networks.unet_3D_icl import unet_3D_icl
+    from icl_amd.trainer import ICLConfig, ICLTrainer
+    nb, steps = 8, 200
+    vols = [synthetic_volume((2, 1, 96, 96, 96), 1337 + s).to(dev) for s in range(nb)]
+    labs = [synthetic_labels((1, 96, 96, 96), 4242 + s, 2).to(dev) for s in range(nb)]
+    big = "sspa.class_decoders.2.mlp2.fc1.weight"
+    runs = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("ICL_CONV_SPLIT", split)
+        model = unet_3D_icl(n_classes=2, in_channels=1, device=dev)
+        fill_like_reference_init(list(model.named_parameters()))
+        _parity_mode(model)
+        model.train()
+        tr = ICLTrainer(model, ICLConfig(num_classes=2, labeled_bs=1, base_lr=0.01, max_iterations=30000))
+        named = dict(model.named_parameters())
+        losses, moms = [], {}
+        for s in range(steps):
+            losses.append(tr.step(vols[s % nb], labs[s % nb])["loss"])
+            if s + 1 in (10, 50, 200):
+                moms[s + 1] = tr.optimizer.state[named[big]]["momentum_buffer"][::432, ::432].cpu().numpy().copy()
+        runs[split] = (np.array([float(v) for v in losses]), moms)
+        del tr, model
+        torch.cuda.empty_cache()
+    a, b = runs["1"][0], runs["0"][0]
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
+    assert a[-1] < 0.7 * a[0] and b[-1] < 0.7 * b[0]                    # both train
+    d = np.abs(a - b)
+    assert d[:10].max() < 0.1 and d[10:50].max() < 0.11 and d[50:].max() < 0.04, (d[:10].max(), d[10:50].max(), d[50:].max())
+    assert d[-1] / abs(b[-1]) < 5e-3
+    for t, band in ((10, 1.1), (50, 1.0), (200, 0.5)):
+        assert rms_err(runs["1"][1][t], runs["0"][1][t]) < band, (t, rms_err(runs["1"][1][t], runs["0"][1][t]))
 
 
 def test_data_parallel_graph_step_on_one_rank_group(dev):

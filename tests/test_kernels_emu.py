@@ -1157,6 +1157,7 @@ def test_fused_query_chain_equals_the_operator_by_operator_aligner(nc, bs, ba, d
 
     def run(fused, mode):
         ops.QCHAIN = fused
+        ops.QC_FUSE_MAX_ROWS = 32      # (the product takes the fused chain for one pass of eight rows only; the stages hold 32)
         ops.StepRNG.tensor = None
         torch.manual_seed(5)      # the seeds of the drop-path sites come from torch's generator when no step RNG is active
         m = build()
@@ -1197,3 +1198,4 @@ def test_fused_query_chain_equals_the_operator_by_operator_aligner(nc, bs, ba, d
                 assert close(b, a), (mode, float((b - a).abs().max()), float(a.abs().max()))
     finally:
         ops.QCHAIN = True
+        ops.QC_FUSE_MAX_ROWS = ops.QC_ROWS_PER_PASS
