@@ -168,22 +168,38 @@ __global__ __launch_bounds__(1024) void sgd_factored_narrow_kernel(float* __rest
   if (lr_dev) lr = *lr_dev;
   const int sub = threadIdx.x >> 8, t = threadIdx.x & 255;
   const int kq = t & 63, rl = t >> 6;
-  const int nbx = (K + kSnCols - 1) / kSnCols, nby = (N + kSvRows - 1) / kSvRows;
-  for (int tile = blockIdx.x; tile < nbx * nby; tile += gridDim.x) {
+  const int nbx = (K + kSnCols - 1) / kSnCols, nby = (N + kSvRows - 1) / kSvRows, ntiles = nbx * nby;
+  // the p / m rows of the NEXT tile are requested before this tile's products: a workgroup always has one tile's 128 KB in flight while it
+  // multiplies and stores another (without it a CU's 16 waves load, wait, multiply and store in lockstep)
+  float4 pn[4], mn[4];
+  auto request = [&](int tile, float4* pv, float4* mv) __attribute__((always_inline)) {
+    const int by = tile / nbx, bx = tile - by * nbx;
+    const int n0 = by * kSvRows, k0 = bx * kSnCols + sub * kSvCols;
+    const bool ok = tile < ntiles && k0 + kq * 4 < K;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + rl * 4 + r;
+      pv[r] = mv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok && n < N) {
+        const long idx = (long)n * K + k0 + kq * 4;
+        pv[r] = icl_nt_load4(p + idx);
+        if (!first) mv[r] = icl_nt_load4(mom + idx);
+      }
+    }
+  };
+  request(blockIdx.x, pn, mn);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int by = tile / nbx, bx = tile - by * nbx;
     const int n0 = by * kSvRows, k0 = bx * kSnCols + sub * kSvCols;
     const bool col_ok = k0 + kq * 4 < K;
     float4 pv[4], mv[4], acc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + rl * 4 + r;
-      acc[r] = pv[r] = mv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (col_ok && n < N) {
-        const long idx = (long)n * K + k0 + kq * 4;
-        pv[r] = icl_nt_load4(p + idx);
-        if (!first) mv[r] = icl_nt_load4(mom + idx);
-      }
+      pv[r] = pn[r];
+      mv[r] = mn[r];
+      acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    request(tile + gridDim.x, pn, mn);
     __syncthreads();      // the previous tile's readers of xs / gs are done
     for (int it = threadIdx.x; it < M * (kSnCols / 4); it += 1024) {
       const int m = it / (kSnCols / 4), q = it % (kSnCols / 4);

@@ -234,11 +234,11 @@ def test_three_trainer_steps_match_reference():
 
 
 @pytest.mark.slow
-def test_first_four_of_ten_trainer_steps_match_reference():
+def test_first_three_of_ten_trainer_steps_match_reference():
     """Round 6: the ten-step golden (tests/golden/make_golden.py --only steps10; max_iterations = 20, so the poly learning rate moves
     at every step from the third on).  The whole schedule `lr_used` is checked against the oracle's poly_lr; the oracle then runs the
-    first FOUR iterations (a minute of CPU; the full ten are what the GPU test compares the HIP path with): losses, parameter norms
-    after every step, the sampled 13,824^2 update and momentum after step 4."""
+    first THREE iterations (under a minute of CPU; the full ten are what the GPU test compares the HIP path with): losses, parameter norms
+    after every step, the sampled 13,824^2 update and momentum after step 3."""
     g = load_golden("model_unet3d_icl_nc2_steps10.npz")
     nc = 2
     shapes = O.unet_3d_icl_shapes(nc)
@@ -254,7 +254,7 @@ def test_first_four_of_ten_trainer_steps_match_reference():
     big = "sspa.class_decoders.2.mlp2.fc1.weight"
     w0 = p[big].detach()[::432, ::432].double().clone()
     bufs, lr, iter_num = {}, base_lr, 0
-    for s in range(4):
+    for s in range(3):
         vol = synthetic_volume((2, 1, 96, 96, 96), 1337 + s)
         lab = synthetic_labels((1, 96, 96, 96), 4242 + s, nc)
         for k in names:
@@ -275,10 +275,10 @@ def test_first_four_of_ten_trainer_steps_match_reference():
         ref = g[f"post_step{s + 1}_norms"]
         worst = float(np.max(np.abs(post - ref) / ref))
         assert worst < (2e-6, 2e-6, 4e-6, 5e-5)[s], (s, worst)      # (measured at step 4: 2.2e-5 — one small tensor whose update nearly cancels)
-    assert rel_err(p["final.weight"].detach(), g["post_step4.final.weight"]) < 2e-4
+    assert rel_err(p["final.weight"].detach(), g["post_step3.final.weight"]) < 2e-4
     delta = (p[big].detach()[::432, ::432].double() - w0).numpy()
-    assert rel_err(delta, g["delta_step4." + big + "_sub"]) < 1e-2
-    assert rel_err(bufs["final.weight"], g["momentum_step4.final.weight"]) < 2e-4
+    assert rel_err(delta, g["delta_step3." + big + "_sub"]) < 1e-2
+    assert rel_err(bufs["final.weight"], g["momentum_step3.final.weight"]) < 2e-4
 
 
 @pytest.mark.slow
