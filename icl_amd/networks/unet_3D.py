@@ -20,6 +20,15 @@ def _open_update_gate(grad):
     return None
 
 
+def _open_decoder_gate(grad):
+    """The upper decoder's own gradient of up3 is complete: from here the step's stream only waits for the aligners (FusedSGD.open_gate)."""
+    from .. import ops
+    opt = ops.FactoredGrads.fused_optimizer
+    if opt is not None and hasattr(opt, "open_gate"):
+        opt.open_gate()
+    return None
+
+
 class UNet3DBackbone(nn.Module):
     """Everything ``unet_3D`` and ``unet_3D_icl`` share (unet_3D_icl.py:28-68): 5 encoder stages,
     4 decoder stages, 1x1x1 classifier, two Dropout(0.3)."""
@@ -71,7 +80,11 @@ class UNet3DBackbone(nn.Module):
             # follow — the point from which an optimiser with gated update placement streams its big matrices (FusedSGD.flush_deferred)
             up3.register_hook(_open_update_gate)
         extra = heads([center, up4, up3]) if heads is not None else None
-        up2 = self.up_concat2(c2, up3, lazy=True)
+        up3_dec = up3
+        if heads is not None and up3.requires_grad:
+            up3_dec = up3.view_as(up3)      # (a view: its gradient is the upper decoder's share alone)
+            up3_dec.register_hook(_open_decoder_gate)
+        up2 = self.up_concat2(c2, up3_dec, lazy=True)
         up1 = self.up_concat1(c1, up2, lazy=True)
         drop = self.dropout2.p if (self.dropout2.training and self.dropout2.p > 0.0) else 0.0
         if isinstance(up1, ops.LazyAct):

@@ -127,6 +127,14 @@ class FusedSGD(torch.optim.Optimizer):
         #            chain alone instead of beside two 3 GB streams
         self.update_placement = os.environ.get("ICL_UPDATE_PLACEMENT", "deep")
         self.update_wgs = int(os.environ.get("ICL_UPDATE_WGS", "128"))
+        # "deep", early gate: the model may open the gate BEFORE the deferring backward nodes run (unet_3D: when the decoder's own gradient
+        # of up3 is complete — autograd processes the upper decoder before the aligners); `open_gate()` then records an event and every
+        # "deep" entry is queued the moment it is deferred, behind that event: the narrow streams start while the step's stream still waits
+        # for the aligners' query chain instead of after it
+        # Measured and NOT the default (profiles/r6_qchain_ab.txt, item 6): 10.82-11.51 against 10.25-10.37 ms — beside the aligners' chain of
+        # dependent 5 us launches even a half-chip stream costs more (HBM latency under load) than the 0.58 ms head start returns
+        self.update_early = os.environ.get("ICL_UPDATE_EARLY", "0") != "0"
+        self._gate_event = None
         self._deferred = []          # (parameter, g, x, event after the input-gradient kernel)
         self._update_stream = None
         self._update_stream_used = False
@@ -152,6 +160,7 @@ class FusedSGD(torch.optim.Optimizer):
         if self._update_stream is not None and self._update_stream_used:
             torch.cuda.current_stream(self._update_stream.device).wait_stream(self._update_stream)
         self._deferred = []
+        self._gate_event = None
         self._update_stream_used = False
         self._updated_in_backward.clear()
         for group in self.param_groups:
@@ -361,6 +370,8 @@ class FusedSGD(torch.optim.Optimizer):
             ev.record()
             # "deep" needs the narrow launch, which holds <= 16 factor rows: a matrix with more (nc = 16) keeps the tail gate
             self._deferred.append((p, g, x, ev, "deep" if (self.update_placement == "deep" and g.shape[0] <= 16) else "tail"))
+            if self._gate_event is not None and self._deferred[-1][4] == "deep":
+                self.flush_deferred(gate=False, only="deep", after=self._gate_event)
             torch.autograd.graph.increment_version(p)
             self._updated_in_backward.add(id(p))
             if self.update_placement == "free":
@@ -391,7 +402,17 @@ class FusedSGD(torch.optim.Optimizer):
         return gx
 
     @torch.no_grad()
-    def flush_deferred(self, gate: bool = True, only: str = None):
+    def open_gate(self):
+        """Called by the model from a gradient hook at the point of the backward pass from which "deep" updates may run (the current
+        stream's work up to here is what they wait for).  Entries deferred later are queued at once; entries already deferred now."""
+        if self.update_placement != "deep" or not self.update_early:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self._gate_event = ev
+        self.flush_deferred(gate=False, only="deep", after=ev)
+
+    def flush_deferred(self, gate: bool = True, only: str = None, after=None):
         """Queue the updates that ``update_in_backward`` deferred on the update stream.  ``gate``: the stream also waits for everything
         queued so far on the CURRENT stream (the caller is a gradient hook at the point of the backward pass from which on the HBM is
         idle); every update waits for the input-gradient kernel that read its matrix.  ``only``: flush the entries of that gate ("tail":
@@ -406,6 +427,8 @@ class FusedSGD(torch.optim.Optimizer):
             # (stream priorities measured without effect on this step: profiles/r4_schedule_experiments.txt)
             self._update_stream = torch.cuda.Stream(device=dev)
         s = self._update_stream
+        if after is not None:
+            s.wait_event(after)
         if gate:
             s.wait_stream(torch.cuda.current_stream(dev))
         for p, g, x, ev, where in todo:
@@ -451,6 +474,7 @@ class FusedSGD(torch.optim.Optimizer):
             # last REPLAYED backward left in the device scalar
             self.lr_dev.fill_(float(self.param_groups[0]["lr"]))
         self.flush_deferred(gate=True)      # a model without a gate hook: the updates start here
+        self._gate_event = None
         if self._update_stream_used:
             torch.cuda.current_stream(self._update_stream.device).wait_stream(self._update_stream)
             self._update_stream_used = False
@@ -619,6 +643,7 @@ class _GraphedStep:
             ops.StepRNG.end_step()
         # nothing of the capture has run: forget the Python-side traces of a backward pass that never executed
         opt._deferred = []
+        opt._gate_event = None
         opt._update_stream_used = False
         opt._updated_in_backward.clear()
         self.grads = [(p, p.grad) for p in params if p.grad is not None]
