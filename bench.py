@@ -100,7 +100,7 @@ def cpu_baseline(num_classes: int, model: str = "unet_3D_icl"):
             "sample": f"{steps} full ICL step(s) of the same workload (2 volumes 96^3 each, nc={num_classes}) after a 32^3 conv warm-up: {t:.2f} s"}
 
 
-HBM_TRAFFIC_FILE = "profiles/r5_hbm_traffic.json"
+HBM_TRAFFIC_FILE = "profiles/r6_hbm_traffic.json"
 
 
 def reference_loop_bench(nc: int, steps: int, warmup: int, dev, fused: bool, graph: bool = False):
