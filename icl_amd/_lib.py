@@ -41,6 +41,8 @@ _SIGNATURES = {
     "icl_norm_fwd_given_stats": (c_int, [P, P, P, P, P, P, P, P, P, I, I, L, I, I, F, F, P, I, P]),
     "icl_conv3d_wgrad_ws_bytes": (c_int64, [I, I, I, I]),
     "icl_conv3d_wgrad": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, L, L, P]),
+    "icl_conv3d_wgrad_slabs": (c_int, [P, P, P, I, I, I, I, I, I, I, L, L, P, P]),
+    "icl_conv3d_wgrad_reduce_multi": (c_int, [P, P, P, P, P, P, I, P]),
     "icl_norm_ws_bytes": (c_int64, [I, I, L]),
     "icl_norm_fwd": (c_int, [P, P, P, P, P, P, P, P, I, I, L, I, I, I, F, F, P, P]),
     "icl_norm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, L, I, I, I, P, P]),

@@ -181,6 +181,68 @@ __global__ __launch_bounds__(256) void reduce_unpack_wgrad_tall_kernel(const flo
   if (co < Cout && ci < Cin) gw[((long)co * Cin + ci) * T + tap] = acc;
 }
 
+// Both reductions above for MANY weight gradients in one launch (round 6): inside a step scope the slab sums of all convolution
+// weight gradients of a backward pass are leaves — only the optimiser reads them — so they are queued (ops.DeferredWgradReduce) and
+// summed by ONE launch when the pass ends instead of one launch behind every weight-gradient kernel (23 per U-Net step).  Job j takes
+// the element-per-slab-lane form of the kernel its stand-alone launch would have taken (`tall`), so every sum keeps its order:
+// bit-identical results.  grid (blocks, jobs), grid-stride over the job's packed elements.
+constexpr int kReduceMulti = 32;
+struct ReduceMulti {
+  const float* gwp[kReduceMulti];
+  float* gw[kReduceMulti];
+  int cout[kReduceMulti], cin[kReduceMulti], taps[kReduceMulti], nslabs[kReduceMulti], tall[kReduceMulti];
+};
+__global__ __launch_bounds__(256) void reduce_unpack_wgrad_multi_kernel(ReduceMulti m) {
+  const int j = blockIdx.y;
+  const float* __restrict__ gwp = m.gwp[j];
+  float* __restrict__ gw = m.gw[j];
+  const int Cout = m.cout[j], Cin = m.cin[j], T = m.taps[j], nslabs = m.nslabs[j];
+  const int CinP = (Cin + 3) / 4 * 4, CoutP = (Cout + 15) / 16 * 16;
+  const long pe = (long)T * CinP * CoutP;
+  __shared__ float part[16][17];
+  if (m.tall[j]) {
+    const int le = threadIdx.x & 15, ls = threadIdx.x >> 4;
+    for (long base = (long)blockIdx.x * 16; base < pe; base += (long)gridDim.x * 16) {
+      const long idx = base + le;
+      float acc = 0.f;
+      if (idx < pe) {
+#pragma unroll 8
+        for (int s = ls; s < nslabs; s += 16) acc += gwp[s * pe + idx];
+      }
+      __syncthreads();
+      part[ls][le] = acc;
+      __syncthreads();
+      if (ls == 0 && idx < pe) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) acc += part[k][le];
+        const int co = (int)(idx % CoutP);
+        const long t = idx / CoutP;
+        const int ci = (int)(t % CinP), tap = (int)(t / CinP);
+        if (co < Cout && ci < Cin) gw[((long)co * Cin + ci) * T + tap] = acc;
+      }
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float (*part4)[64] = reinterpret_cast<float (*)[64]>(&part[0][0]);      // [4][64] inside the 16 x 17 array
+  for (long base = (long)blockIdx.x * 64; base < pe; base += (long)gridDim.x * 64) {
+    const long idx = base + lane;
+    float acc = 0.f;
+    if (idx < pe)
+      for (int s = wid; s < nslabs; s += 4) acc += gwp[s * pe + idx];
+    __syncthreads();
+    part4[wid][lane] = acc;
+    __syncthreads();
+    if (wid == 0 && idx < pe) {
+      const float v = ((part4[0][lane] + part4[1][lane]) + part4[2][lane]) + part4[3][lane];
+      const int co = (int)(idx % CoutP);
+      const long t = idx / CoutP;
+      const int ci = (int)(t % CinP), tap = (int)(t / CinP);
+      if (co < Cout && ci < Cin) gw[((long)co * Cin + ci) * T + tap] = v;
+    }
+  }
+}
+
 // y[b][c][v] = bias[c] + sum_ks slab[ks][b][c][v]   (fixed order; per = Cout*DHW elements per batch item)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
                                                             float* __restrict__ y, int ksplit, int n, long per, long DHW, long y_bstride) {

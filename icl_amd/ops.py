@@ -232,6 +232,58 @@ class WgradLane:
             torch.cuda.current_stream(cls._stream.device).wait_stream(cls._stream)
             cls._used = False
 
+class DeferredWgradReduce:
+    """While open (a step scope: ICLTrainer, or FusedSGD's from the model's forward hook), the slab sums of the convolution weight
+    gradients are not launched behind their kernels: `_Conv3d.backward` runs the weight-gradient kernel only (icl_conv3d_wgrad_slabs),
+    hands autograd the still-unwritten gradient tensor and queues (slabs, gradient); ``flush()`` sums all of them in ONE launch
+    (icl_conv3d_wgrad_reduce_multi) when the backward pass has ended and the weight-gradient lane is joined.  Only for a gradient that
+    autograd ADOPTS untouched (one use of the weight in the step, no .grad yet, no hooks: WgradLane.adoptable) — anything that reads or
+    accumulates the gradient during backward gets it complete, as before.  ``ICL_WGRAD_DEFER_REDUCE=0`` keeps every sum in line."""
+    enabled = os.environ.get("ICL_WGRAD_DEFER_REDUCE", "1") != "0"
+    pending = None
+
+    @classmethod
+    def begin(cls):
+        cls.pending = [] if cls.enabled else None
+
+    @classmethod
+    def wants(cls, weight) -> bool:
+        return cls.pending is not None and isinstance(weight, torch.nn.Parameter) and WgradLane.adoptable(weight)
+
+    @classmethod
+    def defer(cls, ws, gw, cout, cin, ks, nslabs, weight=None):
+        # an ALIAS of the gradient's memory, not the tensor autograd is handed: AccumulateGrad adopts a gradient only while nobody else
+        # holds it (use count) and clones it otherwise — it would clone the unwritten bytes and the sum would land in the original
+        # (its STORAGE and address: a view would keep `gw` itself alive through `_base`)
+        cls.pending.append((ws, (gw.untyped_storage(), gw.data_ptr(), gw.device, weight, tuple(gw.shape)), cout, cin, ks, nslabs))
+        BackwardEnd.arm()
+
+    @classmethod
+    def flush(cls, keep_open: bool = False):
+        items, cls.pending = cls.pending, ([] if (keep_open and cls.enabled) else None)
+        if not items:
+            return
+        dev = items[0][1][2]
+        here = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        n = len(items)
+        arr, iarr = _vp * n, ctypes.c_int32 * n
+        if here is not None:
+            for ws, _gw, *_ in items:
+                ws.record_stream(here)      # (the gradients themselves live until the optimiser has read them on this stream)
+        def target(rec):
+            # belt and braces: should autograd have CLONED the unwritten tensor after all (a condition `adoptable` does not foresee),
+            # the parameter's .grad is that clone — the only gradient it has (it had none before): the sum goes there
+            _st, ptr, _dev, weight, shape = rec
+            g = getattr(weight, "grad", None) if weight is not None else None
+            if g is not None and g.data_ptr() != ptr and tuple(g.shape) == shape and g.is_contiguous() and g.dtype == torch.float32:
+                return g.data_ptr()
+            return ptr
+        _lib.check(_lib.lib().icl_conv3d_wgrad_reduce_multi(arr(*[it[0].data_ptr() for it in items]), arr(*[target(it[1]) for it in items]),
+                                                           iarr(*[it[2] for it in items]), iarr(*[it[3] for it in items]),
+                                                           iarr(*[it[4] for it in items]), iarr(*[it[5] for it in items]), n,
+                                                           _vp(here.cuda_stream) if here is not None else None), "wgrad_reduce_multi")
+
+
 class KernelTimer:
     """HIP-event timing of individual kernel launches on the stream they are launched on (bench.py roofline).
     Usage: ``with KernelTimer() as kt: step()``; ``kt.summary()`` -> {name: (launches, ms_total, flops, bytes)}."""
@@ -624,6 +676,14 @@ class _Conv3d(torch.autograd.Function):
                         gw.copy_(gws.flip(2, 3, 4).transpose(0, 1))
                         return
                     ws = _ws(L.icl_conv3d_wgrad_ws_bytes(n, cin, cout, ks), x)
+                    if gb_arg is None and DeferredWgradReduce.wants(weight):
+                        # the slab sum is a leaf of the pass: queued, one launch for all of them when backward has ended
+                        ns = ctypes.c_int32(0)
+                        with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):
+                            _lib.check(L.icl_conv3d_wgrad_slabs(_ptr(x), _ptr(gy), _ptr(ws), n, cin, cout, d, h, w, ks, cin * s, cout * s,
+                                                                ctypes.byref(ns), _stream(x)), "conv3d_wgrad_slabs")
+                        DeferredWgradReduce.defer(ws, gw, cout, cin, ks, ns.value, weight)
+                        return
                     with _timed("conv3d_mfma_wgrad_kernel", flops, nbytes, x):
                         _lib.check(L.icl_conv3d_wgrad(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb_arg), _ptr(ws), n, cin, cout, d, h, w, ks,
                                                       cin * s, cout * s, _stream(x)), "conv3d_wgrad")

@@ -213,6 +213,7 @@ class FusedSGD(torch.optim.Optimizer):
             # single process: weight gradients of the deep levels on a lane, bias / LayerNorm gradients reduced by one launch — both
             # completed when the backward pass ENDS (ops.BackwardEnd), so `.grad` is whole when loss.backward() returns
             ops.DeferredBiasGrads.begin()
+            ops.DeferredWgradReduce.begin()
             ops.WgradLane.open = True    # (only backward functions consult it)
             me = weakref.ref(self)
             ops.BackwardEnd.hook = lambda: (me() is not None and me()._end_of_backward())
@@ -231,6 +232,8 @@ class FusedSGD(torch.optim.Optimizer):
         if not self._scope_open:
             return
         ops.WgradLane.join()
+        if ops.DeferredWgradReduce.pending is not None:
+            ops.DeferredWgradReduce.flush(keep_open=True)
         if ops.DeferredBiasGrads.pending is not None:
             ops.DeferredBiasGrads.flush(keep_open=True)
 
@@ -239,6 +242,10 @@ class FusedSGD(torch.optim.Optimizer):
         from .networks.layers import BatchNormAct
         ops.BackwardEnd.hook = None
         ops.WgradLane.join()
+        if ops.DeferredWgradReduce.pending is not None:
+            if flush:
+                ops.DeferredWgradReduce.flush()
+            ops.DeferredWgradReduce.pending = None
         ops.WgradLane.open = False
         ops.WgradLane.uses = None
         ops.FactoredGrads.enabled = self._scope_prev_factored

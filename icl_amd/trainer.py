@@ -101,6 +101,7 @@ class ICLTrainer:
         BatchNormAct.defer_counters()
         ops.DeferredBiasGrads.begin()
         ops.WgradLane.begin_step()      # per-weight use counts of the step (a lane gradient must be adopted, not accumulated)
+        ops.DeferredWgradReduce.begin()  # (needs those counts: only adopted gradients are deferred)
         try:
             ops.FactoredGrads.world = self.ddp.world if (self.ddp is not None and self.ddp.active) else 1
             rows_default = ops.FactoredGrads.max_rows_gathered
@@ -118,7 +119,9 @@ class ICLTrainer:
                 ops.WgradLane.open = True
                 loss.backward()
                 ops.WgradLane.join()
+                ops.DeferredWgradReduce.flush()      # the slab sums of every convolution weight gradient of the pass: one launch
         finally:
+            ops.DeferredWgradReduce.pending = None
             if "rows_default" in locals():
                 ops.FactoredGrads.max_rows_gathered = rows_default
             ops.WgradLane.open = False

@@ -78,6 +78,15 @@ int icl_conv3d_fwd(const float* x, const float* wp, const float* bias, float* y,
 int64_t icl_conv3d_wgrad_ws_bytes(int n, int cin, int cout, int ks);
 int icl_conv3d_wgrad(const float* x, const float* gy, float* gw, float* gbias, void* ws, int n, int cin, int cout, int d,
                      int h, int w, int ks, int64_t x_bstride, int64_t gy_bstride, void* stream);
+/* The two halves of icl_conv3d_wgrad apart (round 6): `_slabs` runs the weight-gradient kernel only and leaves its per-workgroup partial
+ * sums in ws (*nslabs of them); `_reduce_multi` sums the slabs of up to any number of such calls (HOST arrays of `count` entries) into
+ * their [Cout, Cin, k, k, k] gradients in ONE launch, each in the order icl_conv3d_wgrad uses (bit-identical).  The weight gradient is
+ * a leaf of the backward pass (only the optimiser reads it, utils.py:104-107 / trainer :113-115), so a step scope queues the sums and
+ * runs them once at the end of backward (ops.DeferredWgradReduce) instead of one small launch behind each of 23 weight-gradient kernels. */
+int icl_conv3d_wgrad_slabs(const float* x, const float* gy, void* ws, int n, int cin, int cout, int d, int h, int w, int ks,
+                           int64_t x_bstride, int64_t gy_bstride, int32_t* nslabs, void* stream);
+int icl_conv3d_wgrad_reduce_multi(const void* const* ws, void* const* gw, const int32_t* cout, const int32_t* cin, const int32_t* ks,
+                                  const int32_t* nslabs, int count, void* stream);
 
 /* ---- InstanceNorm3d(+ReLU) (networks/utils.py:105-106,108-109) and BatchNorm3d(+ReLU)
  * (networks/unet_3D_icl.py:325-340).  mode 0 = instance (group = (n,c)), 1 = batch (group = c).
