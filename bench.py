@@ -224,6 +224,23 @@ def other_workload(model_name: str, nc: int, steps: int, warmup: int, dev):
     return out
 
 
+def other_workload_child(model_name: str, nc: int, steps: int, warmup: int):
+    """``other_workload`` in a CHILD process (started, never exec'ed: this process has the GPU open): whatever happens to it — an
+    exception, a crash inside the HIP runtime, a hang (10-minute limit) — the headline line of this process is still printed."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--other-workload", f"{model_name}:{nc}", "--steps", str(steps), "--warmup", str(warmup)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": f"child exited with {r.returncode}", "stderr_tail": r.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"error": "child timed out after 600 s"}
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def hbm_traffic(kernel: str):
     """HBM bytes per launch of a kernel from the committed PMC run (FETCH_SIZE and WRITE_SIZE passes of rocprofv3 on one
     reference layer of that kernel, gfx950 correction applied) — counters cannot be collected from inside this process, so the
@@ -301,6 +318,8 @@ def main():
                     help="unet_3D_icl = BASELINE configs[1] (the headline line); swinunetr_icl = configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--other-workload", default=None, metavar="MODEL:NC",
+                    help="internal (the child of config.other_workloads): time that workload alone and print its JSON object")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip config.other_workloads (the nc = 16 and SwinUNETR-ICL steps timed for 10 steps each after the headline region)")
     ap.add_argument("--no-exact-compare", action="store_true",
@@ -328,6 +347,13 @@ def main():
                          "rank-0 JSON relay) on a gloo group with a sleep as the step: no GPU, no kernels; used by tests/")
     args = ap.parse_args()
 
+    if args.other_workload:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device")
+        mname, mnc = args.other_workload.split(":")
+        torch.cuda.set_device(0)
+        print(json.dumps(other_workload(mname, int(mnc), args.steps, args.warmup, torch.device("cuda", 0))), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -642,7 +668,9 @@ def main():
                 roof["sgd_factored_update"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": sg[0] // 3,
                                                "avg_launch_us": round(sg[1] * 1e3 / sg[0], 2),
-                                               "algorithmic_bytes_per_launch": int(sg[3] / sg[0])}
+                                               "algorithmic_bytes_per_launch": int(sg[3] / sg[0]),
+                                               "note": "one rank: sspa's two 13,824^2 matrices as NARROW persistent launches (128 of the 256 CUs by design, "
+                                                       "FusedSGD.update_placement 'deep': they run under the deep backward levels) + the four 1,728^2 ones"}
             wa = {k: v for k, v in summ.items() if k.startswith("window_attn")}
             if wa:   # SwinUNETR: the fused window-attention kernels (fp32 MFMA), forward and backward (dQKV + bias gradient)
                 roof["window_attention"] = {k: {"launches_per_step": v[0] // 3, "ms_per_step": round(v[1] / 3, 3),
@@ -708,10 +736,7 @@ def main():
             torch.cuda.empty_cache()
             other = {}
             for key, (mname, mnc) in (("unet3d_icl_nc16", ("unet_3D_icl", 16)), ("swinunetr_icl_nc2", ("swinunetr_icl", 2))):
-                try:
-                    other[key] = other_workload(mname, mnc, 10, args.warmup, dev)
-                except Exception as e:      # noqa: BLE001 — the headline line must still be printed
-                    other[key] = {"error": repr(e)}
+                other[key] = other_workload_child(mname, mnc, 10, args.warmup)
             out["config"]["other_workloads"] = other
         if world == 1 and not args.no_cpu_baseline:
             trainer = model = None

@@ -81,15 +81,12 @@ class SideStream:
             self.tok = None
             if lane == 0:
                 # the lanes fork from and join to the stream the aligner stream itself forks from (see join())
-                keys = list(range(1, SideStream.lanes + 1)) + (["tok"] if SideStream.token_lane_on and SideStream.lanes > 0 else [])
-                for k in keys:
+                for k in range(1, SideStream.lanes + 1):
                     sk = SideStream._streams.get((dev.index, k))
                     if sk is None:
                         sk = SideStream._streams[(dev.index, k)] = torch.cuda.Stream(device=dev)
                     sk.wait_stream(self.main)
                     self.children.append(sk)
-                    if k == "tok":
-                        self.tok = sk
             for t in inputs:
                 t.record_stream(s)
             self.stream = s
@@ -97,9 +94,22 @@ class SideStream:
 
     @staticmethod
     def token_stream():
-        """The token-side stream of the aligner block that is open on this thread, or None."""
+        """The token-side stream of the aligner block that is open on this thread, or None.  Forked from the step's stream on FIRST
+        request (and joined there with the lanes): a block that never asks for it — nc = 16, SwinUNETR, whose aligners take the
+        operator-by-operator path — captures no empty fork / join of it (a forked-but-unused token stream in the THIRD capture of a
+        process made the replay of that graph crash inside hipGraphLaunch on ROCm 7.2: bench.py's default run, round 6)."""
         outer = SideStream._outer
-        return outer.tok if outer is not None else None
+        if outer is None or outer.stream is None or not SideStream.token_lane_on or SideStream.lanes <= 0:
+            return None
+        if outer.tok is None:
+            dev = outer.stream.device
+            sk = SideStream._streams.get((dev.index, "tok"))
+            if sk is None:
+                sk = SideStream._streams[(dev.index, "tok")] = torch.cuda.Stream(device=dev)
+            sk.wait_stream(outer.main)
+            outer.children.append(sk)
+            outer.tok = sk
+        return outer.tok
 
     def __enter__(self):
         if self.stream is not None:
