@@ -119,6 +119,8 @@ _SIGNATURES = {
     "icl_sgd_step_factored_split": (c_int, [P, P, P, P, P, I, I, I, F, F, F, I, P, P]),
     "icl_sgd_step_multi": (c_int, [P, P, P, P, I, F, F, F, I, P, P]),
     "icl_loss_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, L, I, I, P]),
+    "icl_loss_fwd_multi": (c_int, [P, I, P]),
+    "icl_loss_bwd_multi": (c_int, [P, I, P]),
     "icl_qchain_stage": (c_int, [P, P]),
     "icl_qchain_wgrad": (c_int, [P, P, P, P, P, P, P, P, I, P]),
 }

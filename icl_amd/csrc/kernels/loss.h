@@ -33,17 +33,17 @@ __device__ __forceinline__ void softmax_vec(float* v, int nc, float& lse) {
   lse = m + logf(s);
 }
 
-// grid-stride over the B*S voxels; every block writes its 3*nc+1 partial sums to part[blockIdx.x][...]
+// grid-stride over the B*S voxels; block bx of nbx writes its 3*nc+1 partial sums to part[bx][...]
 template <int NCMAX>
-__global__ __launch_bounds__(256) void loss_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                         const long long* __restrict__ labels, float* __restrict__ part,
-                                                         int B, int nc, long S, int a_is_prob) {
+__device__ __forceinline__ void loss_stats_body(const float* __restrict__ a, const float* __restrict__ b,
+                                                const long long* __restrict__ labels, float* __restrict__ part,
+                                                int B, int nc, long S, int a_is_prob, int bx, int nbx) {
   float s0[NCMAX], s1[NCMAX], s2[NCMAX];
   float sx = 0.f;
 #pragma unroll
   for (int c = 0; c < NCMAX; ++c) { s0[c] = 0.f; s1[c] = 0.f; s2[c] = 0.f; }
   const long total = (long)B * S;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+  for (long e = (long)bx * blockDim.x + threadIdx.x; e < total; e += (long)nbx * blockDim.x) {
     const long bi = e / S, s = e - bi * S;
     const float* ap = a + bi * nc * S + s;
     float p[NCMAX];
@@ -104,16 +104,22 @@ __global__ __launch_bounds__(256) void loss_stats_kernel(const float* __restrict
     if (t == 3 * NCMAX || c < nc) {
       const float v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
       const int slot = (t == 3 * NCMAX) ? 3 * nc : grp * nc + c;
-      part[(long)blockIdx.x * (3 * nc + 1) + slot] = v;
+      part[(long)bx * (3 * nc + 1) + slot] = v;
     }
   }
+}
+template <int NCMAX>
+__global__ __launch_bounds__(256) void loss_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const long long* __restrict__ labels, float* __restrict__ part,
+                                                         int B, int nc, long S, int a_is_prob) {
+  loss_stats_body<NCMAX>(a, b, labels, part, B, nc, S, a_is_prob, blockIdx.x, gridDim.x);
 }
 
 // One block: stats[slot] = sum over the nblk per-block partials in a fixed order (bit-reproducible, no atomics, nothing to
 // pre-zero), then out[0], out[1] from the reduced stats.  weight may be NULL.
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ stats,
-                                                            const float* __restrict__ weight, float* __restrict__ out, int nc,
-                                                            float inv_vox, float inv_elems, int mode) {
+__device__ __forceinline__ void loss_finalize_body(const float* __restrict__ part, int nblk, float* __restrict__ stats,
+                                                   const float* __restrict__ weight, float* __restrict__ out, int nc,
+                                                   float inv_vox, float inv_elems, int mode) {
   // 256 threads = S slot lanes x G block groups (S = power of two >= min(nslot, 64)): thread (slot, grp) adds the partials of
   // blocks grp, grp + G, ... — a wave reads runs of consecutive floats (the slots of consecutive blocks) — and the G sums of a
   // slot are added in group order.  2 classes: 8 x 32; 16 classes: 64 x 4.  (One wave per slot with lanes over the blocks read
@@ -151,16 +157,21 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
   out[1] = (mode == 3) ? 0.f : dice / (float)nc;
   out[0] = (mode == 1) ? stats[3 * nc] * inv_vox : (mode == 3 ? stats[3 * nc] * inv_elems : 0.f);
 }
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ stats,
+                                                            const float* __restrict__ weight, float* __restrict__ out, int nc,
+                                                            float inv_vox, float inv_elems, int mode) {
+  loss_finalize_body(part, nblk, stats, weight, out, nc, inv_vox, inv_elems, mode);
+}
 
 // Per-class coefficients of the gradient, recomputed by every thread from the (3*nc+1) reduced statistics:
 //   dL/dp_c(v) = alpha_c*T_c(v) + beta_c*p_c(v) + gamma_c, T = one-hot | q;  kappa scales the cross-entropy logit gradient
 //   (p - t).  g0 / g1 = upstream gradients of out[0] / out[1] (NULL = that output is unused).
 template <int NCMAX>
-__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                        const long long* __restrict__ labels, const float* __restrict__ stats,
-                                                        const float* __restrict__ weight, const float* __restrict__ gout0,
-                                                        const float* __restrict__ gout1, float* __restrict__ ga, int B, int nc,
-                                                        long S, int mode, float inv_vox, float inv_elems, int a_is_prob) {
+__device__ __forceinline__ void loss_grad_body(const float* __restrict__ a, const float* __restrict__ b,
+                                               const long long* __restrict__ labels, const float* __restrict__ stats,
+                                               const float* __restrict__ weight, const float* __restrict__ gout0,
+                                               const float* __restrict__ gout1, float* __restrict__ ga, int B, int nc,
+                                               long S, int mode, float inv_vox, float inv_elems, int a_is_prob, int bx, int nbx) {
   float al[NCMAX], be[NCMAX], gm[NCMAX];
   const float g0 = gout0 ? gout0[0] : 0.f, g1 = gout1 ? gout1[0] : 0.f;
 #pragma unroll
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
   }
   const float kappa = (mode == 1) ? g0 * inv_vox : 0.f;
   const long total = (long)B * S;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+  for (long e = (long)bx * blockDim.x + threadIdx.x; e < total; e += (long)nbx * blockDim.x) {
     const long bi = e / S, s = e - bi * S;
     const float* ap = a + bi * nc * S + s;
     float* gp = ga + bi * nc * S + s;
@@ -212,6 +223,48 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
       }
     }
   }
+}
+template <int NCMAX>
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const long long* __restrict__ labels, const float* __restrict__ stats,
+                                                        const float* __restrict__ weight, const float* __restrict__ gout0,
+                                                        const float* __restrict__ gout1, float* __restrict__ ga, int B, int nc,
+                                                        long S, int mode, float inv_vox, float inv_elems, int a_is_prob) {
+  loss_grad_body<NCMAX>(a, b, labels, stats, weight, gout0, gout1, ga, B, nc, S, mode, inv_vox, inv_elems, a_is_prob, blockIdx.x, gridDim.x);
+}
+
+// ---------------------------------------------------------------- all loss terms of a step in one launch per pass (round 6)
+// The five-part objective of the trainer (:105-112) is ten reductions — CE + Dice on the logits, three AuxLoss3D maps, three
+// PseudoSoftLoss3D maps, three softmax-MSE pairs — each a statistics launch and a one-block finalize, one behind the other on the step's
+// stream with nothing beside them (0.2 ms of 5-10 us launches), and ten gradient launches at the head of the backward pass.  Job j of
+// these kernels IS launch j of the single-term kernels (same blocks, same partial sums, same order: bit-identical); grid (blocks, jobs).
+constexpr int kLossMulti = 12;
+struct LossMulti {
+  const float* a[kLossMulti]; const float* b[kLossMulti]; const long long* lab[kLossMulti]; const float* weight[kLossMulti];
+  float* stats[kLossMulti]; float* out[kLossMulti];
+  const float* g0[kLossMulti]; const float* g1[kLossMulti]; float* ga[kLossMulti];
+  long S[kLossMulti];
+  int B[kLossMulti], nc[kLossMulti], mode[kLossMulti], aip[kLossMulti], nblk[kLossMulti];
+};
+template <int NCMAX>
+__global__ __launch_bounds__(256) void loss_stats_multi_kernel(LossMulti m) {
+  const int j = blockIdx.y;
+  if ((int)blockIdx.x >= m.nblk[j]) return;
+  loss_stats_body<NCMAX>(m.a[j], m.b[j], m.lab[j], m.stats[j] + (3 * m.nc[j] + 1), m.B[j], m.nc[j], m.S[j], m.aip[j], blockIdx.x, m.nblk[j]);
+}
+__global__ __launch_bounds__(256) void loss_finalize_multi_kernel(LossMulti m) {
+  const int j = blockIdx.x;
+  const float total = (float)((long)m.B[j] * m.S[j]);
+  loss_finalize_body(m.stats[j] + (3 * m.nc[j] + 1), m.nblk[j], m.stats[j], m.weight[j], m.out[j], m.nc[j], 1.0f / total,
+                     1.0f / (total * (float)m.nc[j]), m.mode[j]);
+}
+template <int NCMAX>
+__global__ __launch_bounds__(256) void loss_grad_multi_kernel(LossMulti m) {
+  const int j = blockIdx.y;
+  if ((int)blockIdx.x >= m.nblk[j]) return;
+  const float total = (float)((long)m.B[j] * m.S[j]);
+  loss_grad_body<NCMAX>(m.a[j], m.b[j], m.lab[j], m.stats[j], m.weight[j], m.g0[j], m.g1[j], m.ga[j], m.B[j], m.nc[j], m.S[j], m.mode[j],
+                        1.0f / total, 1.0f / (total * (float)m.nc[j]), m.aip[j], blockIdx.x, m.nblk[j]);
 }
 
 }  // namespace icl

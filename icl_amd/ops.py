@@ -403,11 +403,45 @@ class PackedWeights:
     def __init__(self):
         self.entries = {}     # id(parameter) -> [parameter, wp, wpt, valid, wsplit_fwd, wsplit_dgrad, planes valid, wants planes]
 
+    # Round 6: the two launches of begin_step() (every weight packed, every split-product layer's planes: ~45 us) run on a stream of their
+    # own, forked from the caller's; the first convolution of the backbones (one input channel: natural weight layout, conv_cin1.h) and
+    # its normalisation do not read packed weights and run beside them; `get()` / `split_of()` order the calling stream behind the pack
+    # the first time it asks in a step.  ICL_PACK_STREAM=0: in line.
+    pack_stream_on = os.environ.get("ICL_PACK_STREAM", "1") != "0"
+    _pack_streams = {}
+
+    def _wait_pack(self):
+        ev = getattr(self, "_pack_event", None)
+        if ev is None:
+            return
+        cur = torch.cuda.current_stream(self._pack_device)
+        key = cur.cuda_stream
+        if key not in self._pack_synced:
+            cur.wait_event(ev)
+            self._pack_synced.add(key)
+
     def begin_step(self):
         PackedWeights.current = self
+        self._pack_event = None
         live = list(self.entries.values())
         if not live:
             return
+        dev = live[0][0].device
+        if PackedWeights.pack_stream_on and dev.type == "cuda":
+            cur = torch.cuda.current_stream(dev)
+            ps = PackedWeights._pack_streams.get(dev.index)
+            if ps is None:
+                ps = PackedWeights._pack_streams[dev.index] = torch.cuda.Stream(device=dev)
+            ps.wait_stream(cur)
+            with torch.cuda.stream(ps):
+                self._begin_step_launches(live)
+                ev = torch.cuda.Event()
+                ev.record(ps)
+            self._pack_event, self._pack_device, self._pack_synced = ev, dev, set()
+            return
+        self._begin_step_launches(live)
+
+    def _begin_step_launches(self, live):
         L = _lib.lib()
         n = len(live)
         arr = ctypes.c_void_p * n
@@ -450,9 +484,11 @@ class PackedWeights:
         e = cache.entries.get(id(weight)) if cache is not None else None
         if e is None or e[0] is not weight or not e[3] or not e[6]:
             return None, None
+        cache._wait_pack()
         return e[4], e[5]
 
     def end_step(self):
+        self._pack_event = None
         for e in self.entries.values():
             e[3] = e[6] = False
         if PackedWeights.current is self:
@@ -467,6 +503,8 @@ class PackedWeights:
         e = cache.entries.get(id(weight)) if cache is not None else None
         if e is not None and e[0] is not weight:
             e = None
+        if cache is not None:
+            cache._wait_pack()      # (also before a per-call re-pack into the same buffers below)
         if e is not None and e[3]:
             return e[1], e[2]
         if e is not None:
@@ -2514,6 +2552,105 @@ class _FusedLoss(torch.autograd.Function):
         _lib.check(L.icl_loss_bwd(_ptr(a), None if hard else _ptr(target), _ptr(target) if hard else None, _ptr(weight),
                                   _ptr(stats), _ptr(g0), _ptr(g1), _ptr(ga), B, nc, S, mode, aip, _stream(a)), "loss_bwd")
         return ga, None, None, None, None
+
+
+class _LossJob(ctypes.Structure):      # include/icl_hip.h IclLossJob
+    _fields_ = [("a", _vp), ("b", _vp), ("labels", _vp), ("weight", _vp), ("stats", _vp), ("out", _vp), ("gout0", _vp), ("gout1", _vp),
+                ("ga", _vp), ("s", ctypes.c_int64), ("batch", ctypes.c_int), ("nc", ctypes.c_int), ("mode", ctypes.c_int),
+                ("a_is_prob", ctypes.c_int)]
+
+
+LOSS_MULTI_MAX = 12
+LOSS_MULTI = os.environ.get("ICL_LOSS_MULTI", "1") != "0"
+
+
+class _FusedLossMulti(torch.autograd.Function):
+    """Several `_FusedLoss` terms — (a_j, target_j, mode_j) — in ONE statistics launch, one finalize launch and one gradient launch
+    (icl_loss_fwd_multi / icl_loss_bwd_multi).  ``modes``: tuple of icl_loss_fwd modes; tensors: a_0, t_0, a_1, t_1, ...; returns
+    (term0_0, term1_0, term0_1, term1_1, ...), each the 0-dim tensor `_FusedLoss` would have returned (bit-identical)."""
+
+    @staticmethod
+    def forward(ctx, modes, *tensors):
+        L = _lib.lib()
+        n = len(modes)
+        assert 1 <= n <= LOSS_MULTI_MAX and len(tensors) == 2 * n
+        a_s = [tensors[2 * j].contiguous() for j in range(n)]
+        t_s = [tensors[2 * j + 1].contiguous() for j in range(n)]
+        _require(*a_s, *t_s)
+        dev = a_s[0].device
+        nc = a_s[0].shape[1]
+        per = (3 * nc + 1) * (1 + LOSS_MAX_BLOCKS)
+        stats = torch.empty((n, per), dtype=torch.float32, device=dev)
+        out = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        jobs = (_LossJob * n)()
+        for j in range(n):
+            a, t, mode = a_s[j], t_s[j], modes[j]
+            B = a.shape[0]
+            S = a.numel() // (B * nc)
+            hard = mode <= 1
+            assert a.shape[1] == nc
+            if hard:
+                assert t.dtype == torch.int64 and t.numel() == B * S, "labels must be int64 [B, ...]"
+            else:
+                assert t.shape == a.shape and t.dtype == torch.float32
+            q = jobs[j]
+            q.a, q.b, q.labels, q.weight = a.data_ptr(), (None if hard else t.data_ptr()), (t.data_ptr() if hard else None), None
+            q.stats, q.out = stats[j].data_ptr(), out[j].data_ptr()
+            q.s, q.batch, q.nc, q.mode, q.a_is_prob = S, B, nc, mode, 0
+        _lib.check(L.icl_loss_fwd_multi(jobs, n, _stream(a_s[0])), "loss_fwd_multi")
+        ctx.save_for_backward(stats, *a_s, *t_s)
+        ctx.modes = tuple(modes)
+        ctx.set_materialize_grads(False)
+        return tuple(out[j, k] for j in range(n) for k in (0, 1))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        L = _lib.lib()
+        modes = ctx.modes
+        n = len(modes)
+        stats = ctx.saved_tensors[0]
+        a_s, t_s = ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:1 + 2 * n]
+        nc = a_s[0].shape[1]
+        gas = [None] * n
+        keep = []
+        live = [j for j in range(n) if ctx.needs_input_grad[1 + 2 * j] and (gs[2 * j] is not None or gs[2 * j + 1] is not None)]
+        jobs = (_LossJob * max(len(live), 1))()
+        for i, j in enumerate(live):
+            a, t, mode = a_s[j], t_s[j], modes[j]
+            B = a.shape[0]
+            S = a.numel() // (B * nc)
+            hard = mode <= 1
+            g0 = gs[2 * j].contiguous() if gs[2 * j] is not None else None
+            g1 = gs[2 * j + 1].contiguous() if gs[2 * j + 1] is not None else None
+            keep += [g0, g1]
+            gas[j] = torch.empty_like(a)
+            q = jobs[i]
+            q.a, q.b, q.labels, q.weight = a.data_ptr(), (None if hard else t.data_ptr()), (t.data_ptr() if hard else None), None
+            q.stats, q.out = stats[j].data_ptr(), None
+            q.gout0, q.gout1, q.ga = _ptr(g0), _ptr(g1), gas[j].data_ptr()
+            q.s, q.batch, q.nc, q.mode, q.a_is_prob = S, B, nc, mode, 0
+        if live:
+            _lib.check(L.icl_loss_bwd_multi(jobs, len(live), _stream(a_s[0])), "loss_bwd_multi")
+        res = [None]
+        for j in range(n):
+            res += [gas[j], None]
+        return tuple(res)
+
+
+def fused_losses(terms):
+    """``terms``: list of (a, target, mode) with mode 1 = (cross-entropy, Dice(softmax)) on int64 labels, 2 = soft Dice against logits,
+    3 = softmax MSE against logits (the targets of modes 2 / 3 are detached).  Returns the list of (term0, term1) pairs — one statistics
+    launch, one finalize launch, one gradient launch for all of them when there are at most 12 with one class count."""
+    if not terms:
+        return []
+    ncs = {t[0].shape[1] for t in terms}
+    if not LOSS_MULTI or len(terms) > LOSS_MULTI_MAX or len(ncs) != 1:
+        return [_FusedLoss.apply(a, (t.long() if m <= 1 else t.detach()), None, m, False) for a, t, m in terms]
+    flat = []
+    for a, t, m in terms:
+        flat += [a, (t.long() if m <= 1 else t.detach())]
+    out = _FusedLossMulti.apply(tuple(m for _, _, m in terms), *flat)
+    return [(out[2 * j], out[2 * j + 1]) for j in range(len(terms))]
 
 
 class _CombineScalars(torch.autograd.Function):

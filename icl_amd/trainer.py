@@ -70,12 +70,25 @@ class ICLTrainer:
         cfg = self.cfg
         lab = label_batch[:cfg.labeled_bs]
         # CrossEntropyLoss()(out0, y) and DiceLoss(softmax(out0), y) (…BraTS.py:105-108) from one fused pass
-        loss_ce, loss_dice = ops.cross_entropy_dice_parts(outputs[0], lab, cfg.num_classes)
+        n_terms = 1 + len(outputs[2]) + len(outputs[3]) + len(outputs[4])
+        if hasattr(self.aux_loss, "terms") and hasattr(self.pse_loss, "terms") and n_terms <= ops.LOSS_MULTI_MAX:
+            # round 6: the ten reductions of the objective — CE + Dice on the logits, the AuxLoss3D / PseudoSoftLoss3D maps, the
+            # softmax-MSE pairs — in ONE statistics launch + one finalize (and one gradient launch in backward): ops.fused_losses
+            terms = ([(outputs[0], lab, 1)] + self.aux_loss.terms(outputs[2], lab) + self.pse_loss.terms(outputs[3], outputs[1])
+                     + [(a, b, 3) for a, b in zip(outputs[3], outputs[4])])
+            pairs = ops.fused_losses(terms)
+            na_, np_ = len(outputs[2]), len(outputs[3])
+            loss_ce, loss_dice = pairs[0]
+            aux = [v for p in pairs[1:1 + na_] for v in p]                     # [ce_0, dice_0, ce_1, ...]
+            pse = [p[1] for p in pairs[1 + na_:1 + na_ + np_]]
+            con = [p[0] for p in pairs[1 + na_ + np_:]]
+        else:
+            loss_ce, loss_dice = ops.cross_entropy_dice_parts(outputs[0], lab, cfg.num_classes)
+            aux = self.aux_loss.leaves(outputs[2], lab)
+            pse = self.pse_loss.leaves(outputs[3], outputs[1])
+            con = L.softmax_mse_leaves(outputs[3], outputs[4])
         # every term of the five-part objective as a leaf scalar, the weighted sums (loss = dice + ce + aux + w_pse pse + w_con con,
         # aux / pse / con = means over the scales) in ONE launch: out = [loss, aux, pse, con]
-        aux = self.aux_loss.leaves(outputs[2], lab)
-        pse = self.pse_loss.leaves(outputs[3], outputs[1])
-        con = L.softmax_mse_leaves(outputs[3], outputs[4])
         leaves = [loss_dice, loss_ce] + aux + pse + con
         if len(leaves) > 16:      # more scales than the combine kernel takes: the class-level means, then the sum
             loss_aux = self.aux_loss(outputs[2], lab)

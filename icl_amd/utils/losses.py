@@ -124,6 +124,10 @@ class AuxLoss3D(nn.Module):
             out += list(ops.cross_entropy_dice_parts(_resize(fm, self.resize), labels.long(), self.n_classes))
         return out
 
+    def terms(self, feat_maps, labels):
+        """The same terms as (logits, target, mode) triples for ops.fused_losses (all loss terms of a step in one launch per pass)."""
+        return [(_resize(fm, self.resize), labels, 1) for fm in feat_maps]
+
     def forward(self, feat_maps, labels):
         lv = self.leaves(feat_maps, labels)
         return ops.combine_scalars(lv, [[1.0 / len(feat_maps)] * len(lv)])[0]
@@ -139,6 +143,10 @@ class PseudoSoftLoss3D(nn.Module):
     def leaves(self, feat_maps, predicts):
         tgt = predicts.detach()
         return [softmax_dice_loss(_resize(fm, self.resize), tgt) for fm in feat_maps]
+
+    def terms(self, feat_maps, predicts):
+        tgt = predicts.detach()
+        return [(_resize(fm, self.resize), tgt, 2) for fm in feat_maps]
 
     def forward(self, feat_maps, predicts):
         return _mean_of(self.leaves(feat_maps, predicts))

@@ -213,6 +213,19 @@ int icl_loss_fwd(const float* a, const float* b, const int64_t* labels, const fl
 int icl_loss_bwd(const float* a, const float* b, const int64_t* labels, const float* weight, const float* stats,
                  const float* gout0, const float* gout1, float* ga, int batch, int nc, int64_t s, int mode, int a_is_prob,
                  void* stream);
+/* All loss terms of a step in one statistics launch + one finalize launch (icl_loss_fwd_multi) and one gradient launch
+ * (icl_loss_bwd_multi): job j is call j of icl_loss_fwd / icl_loss_bwd — same blocks, same partial sums, same order (bit-identical).
+ * The trainer's objective (train_inherent_consistent_unet_3D_BraTS.py:105-112) is ten such terms.  `jobs`: HOST array of <= 12;
+ * per job the arguments of the single-term calls (stats: ICL_LOSS_STATS_FLOATS(nc) floats, out: 2 floats; gout0 / gout1 / ga: backward). */
+typedef struct IclLossJob {
+  const float* a; const float* b; const int64_t* labels; const float* weight;
+  float* stats; float* out;
+  const float* gout0; const float* gout1; float* ga;
+  int64_t s;
+  int batch, nc, mode, a_is_prob;
+} IclLossJob;
+int icl_loss_fwd_multi(const IclLossJob* jobs, int count, void* stream);
+int icl_loss_bwd_multi(const IclLossJob* jobs, int count, void* stream);
 
 /* ---- aligner token operators (networks/unet_3D_icl.py:244-315)
  * LayerNorm over the last axis c of [rows, c] (nn.LayerNorm, eps 1e-5); mean/rstd [rows] are saved for the backward;

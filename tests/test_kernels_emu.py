@@ -1199,3 +1199,44 @@ def test_fused_query_chain_equals_the_operator_by_operator_aligner(nc, bs, ba, d
     finally:
         ops.QCHAIN = True
         ops.QC_FUSE_MAX_ROWS = ops.QC_ROWS_PER_PASS
+
+
+@pytest.mark.parametrize("nc", [2, 5])
+def test_all_loss_terms_in_one_launch_are_bit_identical_to_the_single_term_calls(nc):
+    """Round 6 (ops.fused_losses, icl_loss_fwd_multi / icl_loss_bwd_multi): the ten reductions of the trainer's objective — CE + Dice on the
+    logits, three resized AuxLoss3D maps, three PseudoSoftLoss3D maps, three softmax-MSE pairs at their own resolutions — in one
+    statistics launch, one finalize launch and one gradient launch: every term and every gradient equals the single-term `_FusedLoss`
+    call bit for bit (job j of the multi kernels is launch j of the single ones), with some outputs unused (no gradient for them)."""
+    B, S = 2, (6, 8, 10)
+    lab = torch.randint(0, nc, (B,) + S, dtype=torch.int64)
+    mk = lambda shape, seed: _rand((B, nc) + shape, seed)      # noqa: E731
+    small = [(3, 4, 5), (6, 4, 5), S]
+
+    def build():
+        logits = mk(S, 1).requires_grad_()
+        aux = [mk(S, 10 + i).requires_grad_() for i in range(3)]
+        pse = [mk(S, 20 + i).requires_grad_() for i in range(3)]
+        con_a = [mk(sh, 30 + i).requires_grad_() for i, sh in enumerate(small)]
+        con_b = [mk(sh, 40 + i) for i, sh in enumerate(small)]
+        tgt = mk(S, 50)
+        terms = [(logits, lab, 1)] + [(a, lab, 1) for a in aux] + [(a, tgt, 2) for a in pse] + [(a, b, 3) for a, b in zip(con_a, con_b)]
+        return terms, [logits] + aux + pse + con_a
+
+    def total(pairs):
+        # every first term, the Dice of the hard / soft-Dice terms; the MSE terms' second output and the soft-Dice terms' first stay unused
+        w = [0.3 + 0.1 * j for j in range(len(pairs))]
+        return sum(w[j] * (p[0] if terms_modes[j] in (1, 3) else p[1]) + (0.5 * p[1] if terms_modes[j] == 1 else 0.0) for j, p in enumerate(pairs))
+
+    terms, leaves = build()
+    terms_modes = [m for _, _, m in terms]
+    single = [ops._FusedLoss.apply(a, (t.long() if m <= 1 else t.detach()), None, m, False) for a, t, m in terms]
+    total(single).backward()
+    g_single = [x.grad.clone() for x in leaves]
+    terms2, leaves2 = build()
+    multi = ops.fused_losses(terms2)
+    assert len(multi) == len(single)
+    for p, q in zip(single, multi):
+        assert torch.equal(p[0].detach(), q[0].detach()) and torch.equal(p[1].detach(), q[1].detach())
+    total(multi).backward()
+    for a, b in zip(g_single, (x.grad for x in leaves2)):
+        assert torch.equal(a, b)
