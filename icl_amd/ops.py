@@ -403,45 +403,11 @@ class PackedWeights:
     def __init__(self):
         self.entries = {}     # id(parameter) -> [parameter, wp, wpt, valid, wsplit_fwd, wsplit_dgrad, planes valid, wants planes]
 
-    # Round 6: the two launches of begin_step() (every weight packed, every split-product layer's planes: ~45 us) run on a stream of their
-    # own, forked from the caller's; the first convolution of the backbones (one input channel: natural weight layout, conv_cin1.h) and
-    # its normalisation do not read packed weights and run beside them; `get()` / `split_of()` order the calling stream behind the pack
-    # the first time it asks in a step.  ICL_PACK_STREAM=0: in line.
-    pack_stream_on = os.environ.get("ICL_PACK_STREAM", "1") != "0"
-    _pack_streams = {}
-
-    def _wait_pack(self):
-        ev = getattr(self, "_pack_event", None)
-        if ev is None:
-            return
-        cur = torch.cuda.current_stream(self._pack_device)
-        key = cur.cuda_stream
-        if key not in self._pack_synced:
-            cur.wait_event(ev)
-            self._pack_synced.add(key)
-
     def begin_step(self):
         PackedWeights.current = self
-        self._pack_event = None
         live = list(self.entries.values())
         if not live:
             return
-        dev = live[0][0].device
-        if PackedWeights.pack_stream_on and dev.type == "cuda":
-            cur = torch.cuda.current_stream(dev)
-            ps = PackedWeights._pack_streams.get(dev.index)
-            if ps is None:
-                ps = PackedWeights._pack_streams[dev.index] = torch.cuda.Stream(device=dev)
-            ps.wait_stream(cur)
-            with torch.cuda.stream(ps):
-                self._begin_step_launches(live)
-                ev = torch.cuda.Event()
-                ev.record(ps)
-            self._pack_event, self._pack_device, self._pack_synced = ev, dev, set()
-            return
-        self._begin_step_launches(live)
-
-    def _begin_step_launches(self, live):
         L = _lib.lib()
         n = len(live)
         arr = ctypes.c_void_p * n
@@ -484,11 +450,9 @@ class PackedWeights:
         e = cache.entries.get(id(weight)) if cache is not None else None
         if e is None or e[0] is not weight or not e[3] or not e[6]:
             return None, None
-        cache._wait_pack()
         return e[4], e[5]
 
     def end_step(self):
-        self._pack_event = None
         for e in self.entries.values():
             e[3] = e[6] = False
         if PackedWeights.current is self:
@@ -503,8 +467,6 @@ class PackedWeights:
         e = cache.entries.get(id(weight)) if cache is not None else None
         if e is not None and e[0] is not weight:
             e = None
-        if cache is not None:
-            cache._wait_pack()      # (also before a per-call re-pack into the same buffers below)
         if e is not None and e[3]:
             return e[1], e[2]
         if e is not None:

@@ -134,7 +134,6 @@ class FusedSGD(torch.optim.Optimizer):
         # Measured and NOT the default (profiles/r6_qchain_ab.txt, item 6): 10.82-11.51 against 10.25-10.37 ms — beside the aligners' chain of
         # dependent 5 us launches even a half-chip stream costs more (HBM latency under load) than the 0.58 ms head start returns
         self.update_early = os.environ.get("ICL_UPDATE_EARLY", "0") != "0"
-        self.update_small_at_gate = os.environ.get("ICL_UPDATE_SMALL_AT_GATE", "1") != "0"
         self._gate_event = None
         self._deferred = []          # (parameter, g, x, event after the input-gradient kernel)
         self._update_stream = None
@@ -441,18 +440,6 @@ class FusedSGD(torch.optim.Optimizer):
             s.wait_stream(torch.cuda.current_stream(dev))
         for p, g, x, ev, where in todo:
             s.wait_event(ev)
-        # round 6: at the gate where the deep backward begins (only is None: unet_3D._open_update_gate) the SMALL token-axis matrices whose
-        # factors are complete — the 1,728^2 mlp2 weights of both aligners, four 15 us launches that used to sit in the optimiser phase
-        # behind the backward pass — are updated on the same stream.  Their factors come from the aligner lanes: the update stream waits
-        # for every lane (one direction: no lane ever waits for it).
-        small = []
-        if gate and only is None and self.update_small_at_gate:
-            from . import ops
-            for k, ls in ops.SideStream._streams.items():
-                if k[0] == dev.index:
-                    s.wait_stream(ls)
-            small = [p for g_ in self.param_groups for p in g_["params"]
-                     if getattr(p, "_icl_factors", None) and p.grad is None and id(p) not in self._updated_in_backward and p.is_cuda]
         with torch.cuda.stream(s):
             for p, g, x, ev, where in todo:
                 group = self._group_of()[id(p)]
@@ -460,11 +447,6 @@ class FusedSGD(torch.optim.Optimizer):
                                     narrow=self.update_wgs if where == "deep" else 0)
                 g.record_stream(s)
                 x.record_stream(s)
-            for p in small:
-                for gf, xf in p._icl_factors:
-                    gf.record_stream(s)
-                    xf.record_stream(s)
-            self.step_subset(small)
         self._update_stream_used = True
 
     @torch.no_grad()
