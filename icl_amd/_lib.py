@@ -36,6 +36,8 @@ _SIGNATURES = {
     "icl_conv3d_split_ws_bytes": (c_int64, [I, I]),
     "icl_conv3d_split_weights_multi": (c_int, [P, P, P, P, I, P]),
     "icl_conv3d_fwd_presplit": (c_int, [P, P, P, P, I, I, I, I, I, I, L, L, P]),
+    "icl_conv3d_fwd_presplit_ws_bytes": (c_int64, [I, I, I, I, I, I]),
+    "icl_conv3d_fwd_presplit_ws": (c_int, [P, P, P, P, P, I, I, I, I, I, I, L, L, P]),
     "icl_conv3d_fwd_stats_slots": (c_int, [I, I, I, I, I, I]),
     "icl_conv3d_fwd_presplit_stats": (c_int, [P, P, P, P, P, I, I, I, I, I, I, L, L, P]),
     "icl_norm_fwd_given_stats": (c_int, [P, P, P, P, P, P, P, P, P, I, I, L, I, I, F, F, P, I, P]),

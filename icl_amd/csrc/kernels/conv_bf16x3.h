@@ -41,6 +41,11 @@ struct Bf3Geom {
                               // tile order inside an XCD's share of the tile list, so that z- and x-neighbours run at the same time
                               // and their shared halo lines hit the XCD's L2: measured +-1 % on every layer, removed —
                               // profiles/r4_tile_order_nt_probe.txt.)
+                              // bit 2 (round 6): plain tile order — workgroup blockIdx.x owns tile blockIdx.x and nothing else (grid.x =
+                              // ntiles): the split-K launches of the deep levels, whose 18-72 tiles do not divide into eight XCD shares
+  int ksplit;                 // > 1: blockIdx.z owns the channel chunks [z nchunks / ksplit, (z + 1) nchunks / ksplit) and writes its raw
+  float* slab;                // partial sums (no bias, no statistics) to slab + z * slab_stride as a dense [n][Cout][D][H][W] tensor;
+  long slab_stride;           // splitk_reduce_kernel (conv_mfma.h) adds the slices in a fixed order (+ bias) into y
 };
 
 // Output tile 4 x TY x 16 voxels, one wave per four (z, y) rows: TY = 8 -> 8 waves, 120-150 KB of LDS (one workgroup per CU);
@@ -68,6 +73,18 @@ struct Bf3F24 : Bf3Base {
   static constexpr int XS_U4 = 6 * NPOSP;
   static constexpr int ws_u4(int nb) { return 6 * SLOTS * nb; }
   static constexpr size_t lds_bytes(int nbt, int planes = 1) { return (size_t)(XS_U4 + planes * ws_u4(16 * nbt)) * 16 + 8 * 48 * 3 * 4; }
+};
+// Flat tile for rows of 12 voxels (the 12^3 level, round 6): 4 x 4 x 12 = 192 outputs = 12 row blocks, three per wave of a FOUR-wave
+// workgroup.  78 KB of LDS with two cout blocks (no statistics scratch: these launches are split over the channel chunks and hand raw
+// partial sums to splitk_reduce_kernel) and <= 256 registers: two workgroups per CU, one staging while the other multiplies.
+struct Bf3F12 : Bf3Base {
+  static constexpr int TZ = 4, TY = 4, TX = 12, PZ = TZ + 2, PY = TY + 2, PX = TX + 2;
+  static constexpr int NPOS = PZ * PY * PX;
+  static constexpr int NPOSP = (NPOS + 1 + 15) / 16 * 16;
+  static constexpr int NW = 4, NT = 64 * NW, ITEMS = 2 * NPOS, ROUNDS = (ITEMS + NT - 1) / NT;
+  static constexpr int XS_U4 = 6 * NPOSP;
+  static constexpr int ws_u4(int nb) { return 6 * SLOTS * nb; }
+  static constexpr size_t lds_bytes(int nbt, int planes = 1) { return (size_t)(XS_U4 + planes * ws_u4(16 * nbt)) * 16; }
 };
 typedef Bf3Base Bf3;
 
@@ -263,12 +280,13 @@ __device__ long long g_bf3_stamps[2 * 3 * 32];
 
 
 template <int NBT, int TY, int V = 60, bool FLAT = false>
-__global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
+__global__ __launch_bounds__(64 * TY, 2) void conv3d_bf16x3_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ wsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ y, Bf3Geom g) {
-  typedef typename std::conditional<FLAT, Bf3F24, Bf3T<TY>>::type TC;
+  typedef typename std::conditional<FLAT, typename std::conditional<TY == 8, Bf3F24, Bf3F12>::type, Bf3T<TY>>::type TC;
   constexpr int MB = FLAT ? 3 : 4;                      // row blocks per wave
   static_assert(V == 60, "one schedule (see the comment above the weight-split kernels)");
-  static_assert(!FLAT || TY == 8, "the flat tile exists for eight waves");
+  static_assert(!FLAT || TY == 8 || TY == 4, "flat tiles: 2 x 8 x 24 on eight waves, 4 x 4 x 12 on four");
+  static_assert(TC::NW == TY && TC::NT == 64 * TY, "one wave per four (z, y) rows / three flat row blocks");
   // one cout block: all three weight planes of a chunk resident in LDS; B fragments double-buffered up to two cout blocks (with three
   // the second set does not fit the register budget: B of the next pair is then read behind the last MFMA)
   constexpr bool WHOLE = NBT == 1, PIPE_B2 = NBT < 3;
@@ -401,14 +419,24 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   // Tile order: workgroup b runs on XCD b % 8 (its own L2).  Every XCD walks its own contiguous eighth of the tile list, the
   // workgroups of an XCD side by side in it, so that tiles which share halo planes are staged through the same L2 at about the
   // same time (FETCH_SIZE: the halo re-reads otherwise all go to HBM / MALL).  Needs gridDim.x % 8 == 0 (launcher).
+  // (flags bit 2: one tile per workgroup, tile = blockIdx.x — the split-K launches of the deep levels)
+  const bool plain = (g.flags & 4) != 0;
   const int per_xcd = (g.ntiles + 7) / 8, xcd = blockIdx.x & 7, wgs_per_xcd = gridDim.x >> 3;
-  const int xcd_end = (xcd + 1) * per_xcd < g.ntiles ? (xcd + 1) * per_xcd : g.ntiles;
+  const int xcd_end = plain ? 0 : ((xcd + 1) * per_xcd < g.ntiles ? (xcd + 1) * per_xcd : g.ntiles);
   auto next_tile = [&](int t) { return t + wgs_per_xcd < xcd_end ? t + wgs_per_xcd : g.ntiles; };
-  int tile = xcd * per_xcd + (blockIdx.x >> 3), chunk = 0;
-  if (tile >= xcd_end) tile = g.ntiles;
+  // split over the channel chunks: this workgroup's slice [c_lo, c_hi) and where its partial sums go
+  const bool ksp = g.ksplit > 1;
+  const int c_lo = ksp ? (int)((long)blockIdx.z * g.nchunks / g.ksplit) : 0;
+  const int c_hi = ksp ? (int)((long)(blockIdx.z + 1) * g.nchunks / g.ksplit) : g.nchunks;
+  const int c_n = c_hi - c_lo;
+  float* const yout = ksp ? g.slab + (long)blockIdx.z * g.slab_stride : y;
+  const long yout_bstride = ksp ? (long)g.Cout * DHW : g.y_bstride;
+  int tile = plain ? (int)blockIdx.x : xcd * per_xcd + (blockIdx.x >> 3), chunk = c_lo;
+  if (!plain && tile >= xcd_end) tile = g.ntiles;
+  if (c_n <= 0) tile = g.ntiles;
   if (tile < g.ntiles) {
-    load_w(0, 0);
-    load_x(tile, 0);
+    load_w(c_lo, 0);
+    load_x(tile, c_lo);
   }
   // the bias of the lane's output channels, loaded once (inside the epilogue it is a global load per work item whose latency every wave
   // waits out in front of its stores: conv_bf16x3_ws.h)
@@ -416,7 +444,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #pragma unroll
   for (int j = 0; j < NBT; ++j) {
     const int co = n0 + j * 16 + lr;
-    bvs[j] = (bias && co < g.Cout) ? bias[co] : 0.f;
+    bvs[j] = (bias && !ksp && co < g.Cout) ? bias[co] : 0.f;
     ICL_PIN1(bvs[j]);
   }
   bool first_item = true;
@@ -427,7 +455,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
   int my_sample = -1;
   while (tile < g.ntiles) {
     int ntile = tile, nchunk = chunk + 1;
-    if (nchunk == g.nchunks) { nchunk = 0; ntile = next_tile(tile); }
+    if (nchunk == c_hi) { nchunk = c_lo; ntile = next_tile(tile); }
     ++item_no;
     BF3_STAMP(0);
     __syncthreads();                       // everyone has finished reading the previous halo tile and weight plane
@@ -435,7 +463,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
 #if !defined(BF3_DEBUG) || !(BF3_DEBUG & 2)
     store_x();
 #endif
-    if (WHOLE && (g.nchunks > 1 || first_item)) store_w();
+    if (WHOLE && (c_n > 1 || first_item)) store_w();
     first_item = false;
     BF3_STAMP(2);
 #pragma unroll
@@ -451,7 +479,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       } else if (dz == 0) {
         __syncthreads();
         BF3_STAMP(3);
-        if (g.nchunks > 1 && ntile < g.ntiles) load_w(nchunk, 0);
+        if (c_n > 1 && ntile < g.ntiles) load_w(nchunk, 0);
       }
       // the halo loads of the next work item are not issued here as one burst (in-kernel stamps: 2.7-4.1k of a 20k-cycle item during
       // which both waves of a SIMD compute addresses and the matrix pipe idles) but one staging round per tap pair of the dz = 0
@@ -560,11 +588,11 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
       }
     }
     BF3_STAMP(20);
-    if (chunk == g.nchunks - 1) {
+    if (chunk == c_hi - 1) {
       // ---- epilogue: lane holds x = 4 lq + r of row (wid, m), column co = n0 + 16 j + lr
       const int b = tile / tiles_per, bt = tile % tiles_per;
       const int x0 = (bt % g.ntx) * TC::TX, y0 = ((bt / g.ntx) % g.nty) * TC::TY, z0 = (bt / (g.ntx * g.nty)) * TC::TZ;
-      float* yb = y + (long)b * g.y_bstride;
+      float* yb = yout + (long)b * yout_bstride;
       const bool nt = (g.flags & 2) != 0;
 #pragma unroll
       for (int j = 0; j < NBT; ++j) {
@@ -593,7 +621,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
           }
           acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (g.stats) bf3_stats_add(run, j, sv, sok, 4 * MB);
+        if (g.stats && !ksp) bf3_stats_add(run, j, sv, sok, 4 * MB);
       }
       my_sample = b;
     }
@@ -601,7 +629,7 @@ __global__ __launch_bounds__(64 * TY) void conv3d_bf16x3_fwd_kernel(const float*
     tile = ntile;
     chunk = nchunk;
   }
-  if (g.stats)
+  if (g.stats && !ksp)
     bf3_stats_flush<NBT, TC::NW>(run, reinterpret_cast<float*>(Ws + WPL * TC::ws_u4(NB)), g.stats, my_sample, g.nbatch, g.Cout, n0, g.wgs,
                                  (int)blockIdx.x, wid, lane, tid);
 }

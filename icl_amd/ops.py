@@ -485,10 +485,11 @@ class PackedWeights:
     @staticmethod
     def note_volume(weight, voxels: int):
         """Called by the convolution with the size of the volume it runs on: weights that meet a volume of the split-product
-        kernels (>= 24^3 voxels unless ICL_CONV_SPLIT_MIN says otherwise) get their bf16 planes from the next begin_step() on."""
+        kernels (>= 12^3 voxels — the launcher decides per shape — unless ICL_CONV_SPLIT_MIN says otherwise) get their bf16 planes from
+        the next begin_step() on."""
         cache = PackedWeights.current if isinstance(weight, torch.nn.Parameter) else None
         e = cache.entries.get(id(weight)) if cache is not None else None
-        if e is not None and e[0] is weight and voxels >= int(os.environ.get("ICL_CONV_SPLIT_MIN", 24 ** 3)):
+        if e is not None and e[0] is weight and voxels >= int(os.environ.get("ICL_CONV_SPLIT_MIN", 12 ** 3)):
             e[7] = True
 
 
@@ -514,7 +515,15 @@ def conv3d_forward_raw(x, wp, bias, n, cin, cout, d, h, w, ks, x_bstride, y, y_b
                     _lib.check(rc, "conv3d_fwd_presplit_stats")
                     return stats
         if wsplit is not None and ks == 3:
-            rc = L.icl_conv3d_fwd_presplit(_ptr(x), _ptr(wsplit), _ptr(bias), _ptr(y), n, cin, cout, d, h, w, x_bstride, y_bstride, _stream(x))
+            # deep levels (rows of 12 / 24 voxels): the launcher may split the channel chunks over workgroups and needs a slab workspace
+            kneed = L.icl_conv3d_fwd_presplit_ws_bytes(n, cin, cout, d, h, w)
+            if kneed:
+                kws = _ws(kneed, x)
+                rc = L.icl_conv3d_fwd_presplit_ws(_ptr(x), _ptr(wsplit), _ptr(bias), _ptr(y), _ptr(kws), n, cin, cout, d, h, w,
+                                                  x_bstride, y_bstride, _stream(x))
+            else:
+                rc = L.icl_conv3d_fwd_presplit(_ptr(x), _ptr(wsplit), _ptr(bias), _ptr(y), n, cin, cout, d, h, w, x_bstride, y_bstride,
+                                               _stream(x))
             if rc != 1:         # 1: this shape does not run on the split-product kernel -> the fp32 pack below
                 _lib.check(rc, "conv3d_fwd_presplit")
                 return

@@ -62,6 +62,17 @@ int icl_conv3d_split_weights_multi(const void* const* wp, void* const* wsplit, c
                                    void* stream);
 int icl_conv3d_fwd_presplit(const float* x, const void* wsplit, const float* bias, float* y, int n, int cin, int cout, int d, int h, int w,
                             int64_t x_bstride, int64_t y_bstride, void* stream);
+/* Round 6: the deep levels (rows of 12 or 24 voxels: 18 / 72 output tiles for a batch of two) fill the chip by splitting the channel
+ * chunks of a tile over workgroups; every slice writes raw partial sums into a slab of ws and a fixed-order reduction adds them (+ bias)
+ * into y — bitwise reproducible.  icl_conv3d_fwd_presplit_ws_bytes: the bytes of ws the launcher's plan needs for this shape (0: the
+ * launch is not split; icl_conv3d_fwd_presplit does the same work).  icl_conv3d_fwd_presplit_ws = icl_conv3d_fwd_presplit with that
+ * workspace; the 12^3 level (4 x 4 x 12 tiles, Cout % 32 == 0) runs on the split-product kernel only through it.  A split launch hands no
+ * statistics to the normalisation (icl_conv3d_fwd_stats_slots returns 0 for such shapes).  Reference: nn.Conv3d of UnetConv3 at the
+ * conv3 / conv4 / up_concat4 / up_concat3 levels (/root/reference/code/networks/unet_3D.py:41-47,53-54, networks/utils.py:104,107) and
+ * its input gradient.  Environment: ICL_CONV_SPLIT_KSPLIT=0 never splits (the 12^3 level then stays on the fp32 MFMA kernels). */
+int64_t icl_conv3d_fwd_presplit_ws_bytes(int n, int cin, int cout, int d, int h, int w);
+int icl_conv3d_fwd_presplit_ws(const float* x, const void* wsplit, const float* bias, float* y, void* ws, int n, int cin, int cout, int d,
+                               int h, int w, int64_t x_bstride, int64_t y_bstride, void* stream);
 /* Convolution + the InstanceNorm statistics of its output from the epilogue's registers (reference: Conv3d -> InstanceNorm3d,
  * /root/reference/code/networks/utils.py:104-105, :107-108) — the stand-alone statistics pass of icl_norm_fwd re-reads the whole output.
  * icl_conv3d_fwd_stats_slots: the number of (count, mean, M2) summaries per (sample, channel) the launch will write (= its workgroup

@@ -88,6 +88,52 @@ def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w):
     assert e1 <= 3.0 * e0 + 2e-7 * float(ref.abs().max()), (e1, e0)
 
 
+@pytest.mark.parametrize("n,cin,cout,d,h,w,ksplit", [
+    (2, 48, 64, 4, 8, 12, 2),       # rows of 12 voxels: flat 4 x 4 x 12 tiles on four waves, two cout blocks; three chunks in slices of 1 + 2
+    (1, 32, 60, 8, 4, 12, 2),       # ... ragged last cout block (60 -> 64), two z tiles, one chunk per slice
+    (1, 64, 32, 4, 4, 12, 3),       # ... four chunks in three slices (1 + 1 + 2)
+    (1, 48, 32, 4, 8, 24, 3),       # rows of 24 voxels: the flat 2 x 8 x 24 tiles with one chunk per slice
+    (2, 32, 48, 3, 10, 24, 2),      # ... three cout blocks, odd depth, partial y tile, two samples
+    (1, 32, 16, 2, 8, 24, 5),       # ... one cout block (all three weight planes resident), more slices asked than chunks
+])
+def test_conv3d_split_products_split_over_channel_chunks(monkeypatch, n, cin, cout, d, h, w, ksplit):
+    """conv_bf16x3.h, round 6: the deep levels' launches split the channel chunks of a tile over workgroups (grid.z), every slice writes
+    raw partial sums into a slab and splitk_reduce_kernel adds them (+ bias) in a fixed order; rows of 12 voxels run on flat 4 x 4 x 12
+    tiles that exist for such launches only.  Forward and input gradient against torch, through icl_conv3d_fwd (slab behind the split
+    weights) and through icl_conv3d_fwd_presplit_ws (the step's path); a split launch hands out no InstanceNorm statistics.
+    Reference: nn.Conv3d of UnetConv3 at the conv3 / conv4 / up_concat4 / up_concat3 levels (networks/unet_3D.py:41-47,53-54)."""
+    import ctypes
+    monkeypatch.setenv("ICL_CONV_SPLIT_MIN", "1")
+    monkeypatch.setenv("ICL_CONV_SPLIT", "1")
+    monkeypatch.setenv("ICL_CONV_SPLIT_KSPLIT", str(ksplit))
+    L = _lib.lib()
+    s = d * h * w
+    want_slices = min(ksplit, cin // 16)
+    assert L.icl_conv3d_fwd_presplit_ws_bytes(n, cin, cout, d, h, w) == want_slices * n * cout * s * 4
+    assert L.icl_conv3d_fwd_stats_slots(n, cin, cout, d, h, w) == 0
+    _conv_check(n, cin, cout, d, h, w, 3)
+    x = _rand((n, cin, d, h, w), 41)
+    wt = _rand((cout, cin, 3, 3, 3), 42) * 0.2
+    b = _rand((cout,), 43)
+    wp = ops.pack_weights(wt, 0)
+    wsplit = torch.empty(L.icl_conv3d_split_ws_bytes(cin, cout) // 4, dtype=torch.float32)
+    arr, iarr = ctypes.c_void_p * 1, ctypes.c_int32 * 1
+    _lib.check(L.icl_conv3d_split_weights_multi(arr(wp.data_ptr()), arr(wsplit.data_ptr()), iarr(cin), iarr(cout), 1, None), "split")
+    y = torch.full((n, cout, d, h, w), float("nan"))
+    assert ops.conv3d_forward_raw(x, wp, b, n, cin, cout, d, h, w, 3, cin * s, y, cout * s, wsplit=wsplit, want_stats=True) is None
+    name = L.icl_last_kernel_name().decode()
+    assert "bf16x3" in name and ("flat12" in name) == (w == 12), name
+    ref = F.conv3d(x.double(), wt.double(), b.double(), padding=1)
+    assert float((y.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    # unsplit: the same sums in another order (rows of 12 fall back to the fp32 kernels) — close, not equal
+    monkeypatch.setenv("ICL_CONV_SPLIT_KSPLIT", "0")
+    assert L.icl_conv3d_fwd_presplit_ws_bytes(n, cin, cout, d, h, w) == 0
+    y0 = torch.empty_like(y)
+    ops.conv3d_forward_raw(x, wp, b, n, cin, cout, d, h, w, 3, cin * s, y0, cout * s, wsplit=wsplit)
+    assert ("bf16x3" in L.icl_last_kernel_name().decode()) == (w != 12)
+    assert float((y - y0).abs().max()) < 2e-5 * float(ref.abs().max()) and not torch.equal(y, y0)
+
+
 @pytest.mark.parametrize("n,cin,cout,d,h,w,wgs", [
     (2, 16, 16, 10, 16, 16, 3),     # one cout block; 2 samples x 2 columns x 10 tiles on three workgroups: runs that start inside a column and cross into the next
     (1, 20, 32, 9, 8, 40, 2),       # two cout blocks, ragged cin block, three columns in x (the last one 8 of 16 wide), odd depth

@@ -38,11 +38,17 @@ def main():
         gy = torch.randn(nb, cout, s, s, s, device=dev)
         y, gw = torch.empty_like(gy), torch.empty_like(w)
         wp = ops.pack_weights(w, 0)
+        wsplit = None
+        if cin % 16 == 0 and L.icl_conv3d_split_ws_bytes(cin, cout):      # the step's path: bf16 planes split once, outside the timed calls
+            import ctypes
+            wsplit = torch.empty(L.icl_conv3d_split_ws_bytes(cin, cout) // 4, dtype=torch.float32, device=dev)
+            arr, iarr = ctypes.c_void_p * 1, ctypes.c_int32 * 1
+            _lib.check(L.icl_conv3d_split_weights_multi(arr(wp.data_ptr()), arr(wsplit.data_ptr()), iarr(cin), iarr(cout), 1, ops._stream(x)))
         ws = torch.empty(max(L.icl_conv3d_wgrad_ws_bytes(nb, cin, cout, 3) // 4, 1), device=dev)
 
         def run():
             if what == "fwd":
-                ops.conv3d_forward_raw(x, wp, None, nb, cin, cout, s, s, s, 3, cin * S, y, cout * S)
+                ops.conv3d_forward_raw(x, wp, None, nb, cin, cout, s, s, s, 3, cin * S, y, cout * S, wsplit=wsplit)
             else:
                 _lib.check(L.icl_conv3d_wgrad(ops._ptr(x), ops._ptr(gy), ops._ptr(gw), None, ops._ptr(ws), nb, cin, cout, s, s, s, 3,
                                               cin * S, cout * S, ops._stream(x)))
