@@ -485,11 +485,11 @@ class PackedWeights:
     @staticmethod
     def note_volume(weight, voxels: int):
         """Called by the convolution with the size of the volume it runs on: weights that meet a volume of the split-product
-        kernels (>= 12^3 voxels — the launcher decides per shape — unless ICL_CONV_SPLIT_MIN says otherwise) get their bf16 planes from
+        kernels (>= 6^3 voxels — the launcher decides per shape — unless ICL_CONV_SPLIT_MIN says otherwise) get their bf16 planes from
         the next begin_step() on."""
         cache = PackedWeights.current if isinstance(weight, torch.nn.Parameter) else None
         e = cache.entries.get(id(weight)) if cache is not None else None
-        if e is not None and e[0] is weight and voxels >= int(os.environ.get("ICL_CONV_SPLIT_MIN", 12 ** 3)):
+        if e is not None and e[0] is weight and voxels >= int(os.environ.get("ICL_CONV_SPLIT_MIN", 6 ** 3)):
             e[7] = True
 
 
@@ -682,10 +682,22 @@ class _Conv3d(torch.autograd.Function):
                 # gradient: with the roles of x and dY exchanged, dW[co][ci][t] = sum_q dY[co][q - t] x[ci][q], the z-column kernel stages
                 # ONE halo'd dY block for three x blocks instead of one halo'd x block per dY block (matrix pipe 52 -> 68 %,
                 # profiles/r5_pmc_conv.md); the result comes out as [cin][cout] with mirrored taps and is written back by two tiny copies.
+                tiny6 = ks == 3 and (d, h, w) == (6, 6, 6) and _f6_split_ok(x, weight)
                 swap = (ks == 3 and gb_arg is None and cout == 16 and cin % 48 == 0 and h % 8 == 0 and d >= 8 and w % 4 == 0
                         and s >= WGRAD_SWAP_MIN_VOXELS and os.environ.get("ICL_WGRAD_SWAP", "1") != "0")
 
                 def wgrad():
+                    if tiny6:
+                        # dW[cout][cin * 27] = dY^T [cout, n S] x im2col(x) [n S, cin * 27]: the tall / skinny product of ops.linear's
+                        # weight gradient (the form _conv3d_tiny_volume gives it), here beside the split-product input gradient
+                        cols = torch.empty((n * s, cin * 27), dtype=torch.float32, device=x.device)
+                        _lib.check(L.icl_im2col3(_ptr(x), _ptr(cols), n, cin, d, h, w, _stream(x)), "im2col3")
+                        g2 = gy.reshape(n, cout, s).transpose(1, 2).reshape(n * s, cout).contiguous()
+                        gw2, gb2 = _tall_atb(g2, cols, gb_arg is not None)
+                        gw.copy_(gw2.view_as(gw))
+                        if gb_arg is not None:
+                            gb_arg.copy_(gb2)
+                        return
                     if swap:
                         ws = _ws(L.icl_conv3d_wgrad_ws_bytes(n, cout, cin, ks), x)
                         gws = torch.empty((cin, cout, ks, ks, ks), dtype=torch.float32, device=x.device)
@@ -745,6 +757,16 @@ WGRAD_SWAP_MIN_VOXELS = 24 ** 3    # exchanged-roles weight gradient (see _Conv3
 SMALL_CONV_MIN_WEIGHTS = 128 * 128 * 27
 
 
+def _f6_split_ok(x, weight) -> bool:
+    """A 3^3 convolution on a whole 6^3 volume that the split-product kernel takes as ONE flat tile, split over the channel chunks
+    (csrc/kernels/conv_bf16x3.h Bf3F6, round 6): the centre block of the 3-D U-Net.  Forward and input gradient then are one launch + a
+    slab sum each instead of im2col / col2im around a skinny product; the weight gradient keeps the product form."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    return (tuple(x.shape[2:]) == (6, 6, 6) and cin % 16 == 0 and cin >= 32 and ((cout + 15) // 16 * 16) % 32 == 0
+            and os.environ.get("ICL_CONV_SPLIT", "1") != "0" and os.environ.get("ICL_CONV_SPLIT_FLAT6", "1") != "0"
+            and os.environ.get("ICL_CONV_SPLIT_KSPLIT", "-1") != "0" and int(os.environ.get("ICL_CONV_SPLIT_MIN", 216)) <= 216)
+
+
 def _conv3d_tiny_volume(x, weight, bias):
     """3^3 convolution on <= 6^3 voxels with >= 128x128 channels: a skinny GEMM that streams the weights once
     (csrc/kernels/misc.h im2col3 / col2im3 + the weight-streaming / tiled products of csrc/kernels/gemm.h through ``linear``;
@@ -760,7 +782,7 @@ def conv3d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     """Conv3d, kernel 3 (pad 1) or 1 (pad 0), stride 1.  ``zero_bias_grad``: the caller guarantees the output goes
     straight into a mean-removing normalisation, so the bias gradient is identically zero."""
     if (weight.shape[2] == 3 and x.shape[2] * x.shape[3] * x.shape[4] <= SMALL_CONV_MAX_VOXELS
-            and weight.numel() >= SMALL_CONV_MIN_WEIGHTS):
+            and weight.numel() >= SMALL_CONV_MIN_WEIGHTS and not _f6_split_ok(x, weight)):
         return _conv3d_tiny_volume(x, weight, bias)
     return _Conv3d.apply(x, weight, bias, zero_bias_grad)
 
@@ -771,7 +793,7 @@ def conv3d_instance_norm_act(x: torch.Tensor, weight: torch.Tensor, bias: Option
     its epilogue hands the normalisation the per-(sample, channel) statistics and the stand-alone statistics pass is skipped; everywhere
     else this is conv3d followed by instance_norm_act."""
     if (weight.shape[2] == 3 and x.shape[2] * x.shape[3] * x.shape[4] <= SMALL_CONV_MAX_VOXELS
-            and weight.numel() >= SMALL_CONV_MIN_WEIGHTS):
+            and weight.numel() >= SMALL_CONV_MIN_WEIGHTS and not _f6_split_ok(x, weight)):
         return _NormAct.apply(_conv3d_tiny_volume(x, weight, bias), None, None, None, None, 0, True, int(act), eps, 0.0, None)
     y, stats = _Conv3d.apply(x, weight, bias, True, True)
     return _NormAct.apply(y, None, None, None, None, 0, True, int(act), eps, 0.0, stats if stats.numel() else None)
@@ -997,7 +1019,7 @@ def conv3d_instance_norm_add_act(x: torch.Tensor, weight: torch.Tensor, res: tor
     """act(InstanceNorm3d(Conv3d(x)) + res): the second half of MONAI's UnetResBlock (swinunetr_icl.py:128-229), the convolution's
     epilogue handing the normalisation its statistics where it can (see conv3d_instance_norm_act)."""
     if (weight.shape[2] == 3 and x.shape[2] * x.shape[3] * x.shape[4] <= SMALL_CONV_MAX_VOXELS
-            and weight.numel() >= SMALL_CONV_MIN_WEIGHTS):
+            and weight.numel() >= SMALL_CONV_MIN_WEIGHTS and not _f6_split_ok(x, weight)):
         return _InstanceNormAddAct.apply(_conv3d_tiny_volume(x, weight, None), res, int(act), eps)
     y, stats = _Conv3d.apply(x, weight, None, True, True)
     return _InstanceNormAddAct.apply(y, res, int(act), eps, stats if stats.numel() else None)

@@ -103,6 +103,27 @@ def test_maxpool_ties(dev):
     assert torch.equal(xg.grad.cpu(), xr.grad)
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 48, 48, 48), (2, 64, 12, 12, 12), (1, 8, 4, 6, 6)])
+def test_skip_and_pool_backward_adds_both_gradients_in_one_pass(dev, shape):
+    """ops.skip_and_pool: an encoder output feeds the level's skip connection and the next level's pooling
+    (/root/reference/code/networks/unet_3D_icl.py:100-116); the backward adds the skip gradient — a batch-strided channel slice of the
+    concat gradient — inside the pooling backward's pass (maxpool2_bwd_add_x2_kernel: two pooled outputs per thread, 16-byte accesses;
+    rows that pool to an odd width keep maxpool2_bwd_add_kernel).  Bit-exact against autograd on (x, max_pool3d(x)), ties included."""
+    from icl_amd import ops
+    n, c = shape[:2]
+    x = torch.relu(_rand(shape, 61))                       # zeros: ties between the window's elements
+    xg = x.to(dev).requires_grad_()
+    skip, y = ops.skip_and_pool(xg)
+    gfull = _rand((n, c + 5) + tuple(shape[2:]), 62)
+    gsk = gfull[:, 1:c + 1]                                 # non-contiguous over the batch, as the concat gradient hands it over
+    gy = _rand(tuple(y.shape), 63)
+    torch.autograd.backward([skip, y], [gfull.to(dev)[:, 1:c + 1], gy.to(dev)])
+    xr = x.clone().requires_grad_()
+    yr = F.max_pool3d(xr, 2)
+    torch.autograd.backward([xr * 1.0, yr], [gsk, gy])
+    assert torch.equal(y.detach().cpu(), yr.detach()) and torch.equal(xg.grad.cpu(), xr.grad)
+
+
 @pytest.mark.parametrize("ins,outs,c", [((3, 4, 5), (6, 8, 10), 3), ((6, 6, 6), (96, 96, 96), 2), ((12, 12, 12), (96, 96, 96), 2),
                                         ((24, 24, 24), (96, 96, 96), 2), ((24, 24, 24), (48, 48, 48), 16)])
 def test_trilinear(dev, ins, outs, c):

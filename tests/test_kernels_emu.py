@@ -95,6 +95,8 @@ def test_conv3d_split_bf16_products(monkeypatch, n, cin, cout, d, h, w):
     (1, 48, 32, 4, 8, 24, 3),       # rows of 24 voxels: the flat 2 x 8 x 24 tiles with one chunk per slice
     (2, 32, 48, 3, 10, 24, 2),      # ... three cout blocks, odd depth, partial y tile, two samples
     (1, 32, 16, 2, 8, 24, 5),       # ... one cout block (all three weight planes resident), more slices asked than chunks
+    (2, 48, 32, 6, 6, 6, 3),        # a whole 6^3 volume as one flat tile of 16 row blocks (216 of 256 rows live), two samples
+    (1, 32, 60, 6, 6, 6, 2),        # ... ragged last cout block
 ])
 def test_conv3d_split_products_split_over_channel_chunks(monkeypatch, n, cin, cout, d, h, w, ksplit):
     """conv_bf16x3.h, round 6: the deep levels' launches split the channel chunks of a tile over workgroups (grid.z), every slice writes
@@ -122,7 +124,7 @@ def test_conv3d_split_products_split_over_channel_chunks(monkeypatch, n, cin, co
     y = torch.full((n, cout, d, h, w), float("nan"))
     assert ops.conv3d_forward_raw(x, wp, b, n, cin, cout, d, h, w, 3, cin * s, y, cout * s, wsplit=wsplit, want_stats=True) is None
     name = L.icl_last_kernel_name().decode()
-    assert "bf16x3" in name and ("flat12" in name) == (w == 12), name
+    assert "bf16x3" in name and ("flat12" in name) == (w == 12) and ("flat6" in name) == (w == 6), name
     ref = F.conv3d(x.double(), wt.double(), b.double(), padding=1)
     assert float((y.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
     # unsplit: the same sums in another order (rows of 12 fall back to the fp32 kernels) — close, not equal
@@ -130,7 +132,7 @@ def test_conv3d_split_products_split_over_channel_chunks(monkeypatch, n, cin, co
     assert L.icl_conv3d_fwd_presplit_ws_bytes(n, cin, cout, d, h, w) == 0
     y0 = torch.empty_like(y)
     ops.conv3d_forward_raw(x, wp, b, n, cin, cout, d, h, w, 3, cin * s, y0, cout * s, wsplit=wsplit)
-    assert ("bf16x3" in L.icl_last_kernel_name().decode()) == (w != 12)
+    assert ("bf16x3" in L.icl_last_kernel_name().decode()) == (w == 24)
     assert float((y - y0).abs().max()) < 2e-5 * float(ref.abs().max()) and not torch.equal(y, y0)
 
 
@@ -252,13 +254,16 @@ def test_split_batch_gradient_is_one_concatenation(use):
     assert torch.equal(x.grad, want)
 
 
-def test_skip_and_pool_adds_the_two_gradients_in_one_pass():
-    """ops.skip_and_pool (maxpool2_bwd_add_kernel): the gradient of an encoder output = its skip gradient (a batch-strided channel slice
-    of the concat gradient, as _UpCat.backward hands it over) + the pooling backward; reference: autograd on x -> (x, max_pool3d(x))."""
+@pytest.mark.parametrize("w,x2", [(8, "1"), (8, "0"), (12, "1"), (6, "1")])
+def test_skip_and_pool_adds_the_two_gradients_in_one_pass(monkeypatch, w, x2):
+    """ops.skip_and_pool (maxpool2_bwd_add_kernel / maxpool2_bwd_add_x2_kernel: one or two pooled outputs per thread; rows of 6 pool to an
+    odd width and keep the first): the gradient of an encoder output = its skip gradient (a batch-strided channel slice of the concat
+    gradient, as _UpCat.backward hands it over) + the pooling backward; reference: autograd on x -> (x, max_pool3d(x))."""
+    monkeypatch.setenv("ICL_MAXPOOL_BWD_X2", x2)
     torch.manual_seed(0)
-    x = _rand((2, 3, 4, 6, 8), 31, True)
+    x = _rand((2, 3, 4, 6, w), 31, True)
     skip, y = ops.skip_and_pool(x)
-    gsk = _rand((2, 5, 4, 6, 8), 32)[:, :3]          # non-contiguous over the batch
+    gsk = _rand((2, 5, 4, 6, w), 32)[:, :3]          # non-contiguous over the batch
     gy = _rand(tuple(y.shape), 33)
     torch.autograd.backward([skip, y], [gsk, gy])
     xr = x.detach().clone().requires_grad_()
