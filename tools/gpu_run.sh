@@ -56,7 +56,8 @@ PY
         python3 tools/step_trace.py "$T" 2 > "$O/step_trace.txt" 2>&1                   # every kernel of one replayed step
         rm -f "$T"; head -60 "$O/timeline.txt" ;;
     pmc)
-        for spec in "f16 16 16 96 fwd" "f48 48 16 96 fwd" "f32 32 32 48 fwd" "f4848 48 48 96 fwd" "w16 16 16 96 wgrad" "w32 32 32 48 wgrad"; do
+        for spec in "f16 16 16 96 fwd" "f48 48 16 96 fwd" "f32 32 32 48 fwd" "f4848 48 48 96 fwd" "w16 16 16 96 wgrad" "w32 32 32 48 wgrad" \
+                    "f24a 32 64 24 fwd" "f24b 192 64 24 fwd" "f12a 128 128 12 fwd" "f12b 384 128 12 fwd" "f6 256 256 6 fwd"; do
           set -- $spec; tag=$1; shift
           bash tools/pmc_conv.sh "$tag" -- "$1" "$2" "$3" "$4" 5 2
           bash tools/pmc_hbm.sh "$tag" conv "$1" "$2" "$3" "$4" 5 2
