@@ -89,22 +89,22 @@ struct Bf3F12 : Bf3Base {
   static constexpr int ws_u4(int nb) { return 6 * SLOTS * nb; }
   static constexpr size_t lds_bytes(int nbt, int planes = 1) { return (size_t)(XS_U4 + planes * ws_u4(16 * nbt)) * 16; }
 };
-// Flat tile for a WHOLE 6^3 volume (the centre of the U-Net, round 6): 216 outputs on 16 row blocks of the flattened index — four per wave
-// of a four-wave workgroup, the last 40 rows idle (their operand reads run past the halo image into the weight planes: finite garbage
-// in matrix rows that are never stored).  The flattened index of the tile IS the element offset inside the volume, so an epilogue quad
+// Flat tile for a WHOLE 6^3 volume (the centre of the U-Net, round 6): 216 outputs on 16 row blocks of the flattened index — two per wave
+// of an eight-wave workgroup (four per wave on four waves spilled 140 B per lane), the last 40 rows idle (their operand reads run past
+// the halo image into the weight planes: finite garbage in matrix rows that are never stored).  The flattened index of the tile IS the element offset inside the volume, so an epilogue quad
 // that wraps from one row of 6 to the next is still one contiguous 16-byte store.  Split launches only, as Bf3F12.
 struct Bf3F6 : Bf3Base {
   static constexpr int TZ = 6, TY = 6, TX = 6, PZ = TZ + 2, PY = TY + 2, PX = TX + 2;
   static constexpr int NPOS = PZ * PY * PX;
   static constexpr int NPOSP = (NPOS + 1 + 15) / 16 * 16;
-  static constexpr int NW = 4, NT = 64 * NW, ITEMS = 2 * NPOS, ROUNDS = (ITEMS + NT - 1) / NT;
-  static constexpr int MB = 4;
+  static constexpr int NW = 8, NT = 64 * NW, ITEMS = 2 * NPOS, ROUNDS = (ITEMS + NT - 1) / NT;
+  static constexpr int MB = 2;
   static constexpr int XS_U4 = 6 * NPOSP;
   static constexpr int ws_u4(int nb) { return 6 * SLOTS * nb; }
   static constexpr size_t lds_bytes(int nbt, int planes = 1) { return (size_t)(XS_U4 + planes * ws_u4(16 * nbt)) * 16; }
 };
-// waves of the workgroup for the template arguments (TY, FLAT) of conv3d_bf16x3_fwd_kernel: TY = 6 names the 6^3 tile (four waves)
-constexpr int bf3_waves(int ty, bool flat) { return flat && ty == 6 ? 4 : ty; }
+// waves of the workgroup for the template arguments (TY, FLAT) of conv3d_bf16x3_fwd_kernel: TY = 6 names the 6^3 tile (eight waves)
+constexpr int bf3_waves(int ty, bool flat) { return flat && ty == 6 ? 8 : ty; }
 typedef Bf3Base Bf3;
 
 // Two fp32 -> their three bf16 terms, packed pairwise (low half = a).  Round-to-nearest splits: s1 = rn(v), s2 = rn(v - s1),
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64 * bf3_waves(TY, FLAT), 2) void conv3d_bf16x3_fwd
                                     Bf3T<TY>>::type TC;
   constexpr int MB = TC::MB;                            // row blocks per wave
   static_assert(V == 60, "one schedule (see the comment above the weight-split kernels)");
-  static_assert(!FLAT || TY == 8 || TY == 4 || TY == 6, "flat tiles: 2 x 8 x 24 on eight waves, 4 x 4 x 12 and 6 x 6 x 6 on four");
+  static_assert(!FLAT || TY == 8 || TY == 4 || TY == 6, "flat tiles: 2 x 8 x 24 and 6 x 6 x 6 on eight waves, 4 x 4 x 12 on four");
   static_assert(TC::NW == bf3_waves(TY, FLAT), "one wave per four (z, y) rows / MB flat row blocks");
   // one cout block: all three weight planes of a chunk resident in LDS; B fragments double-buffered up to two cout blocks (with three
   // the second set does not fit the register budget: B of the next pair is then read behind the last MFMA)
