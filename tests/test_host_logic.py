@@ -144,7 +144,7 @@ def test_no_kernel_of_the_library_keeps_a_crossed_packed_add(tmp_path):
             for ln in m.group(2).splitlines():
                 if "v_pk_add_f32" in ln and "op_sel:[0,1]" in ln and "op_sel_hi:[1,0]" in ln:
                     bad.append((m.group(1), ln.strip()))
-    assert kernels >= 200, kernels          # the whole library was scanned (212 kernels in round 6)
+    assert kernels >= 200, kernels          # the whole library was scanned (226 kernels at the end of round 6)
     assert not bad, bad[:4]
 
 
