@@ -139,7 +139,7 @@ class FusedSGD(torch.optim.Optimizer):
         self._deferred = []          # (parameter, g, x, event after the input-gradient kernel)
         self._update_stream = None
         self._update_stream_used = False
-        self.step_branches = max(int(os.environ.get("ICL_OPT_BRANCHES", "4")), 1)
+        self.step_branches = max(int(os.environ.get("ICL_OPT_BRANCHES", "1")), 1)      # measured equal at 1 / 2 / 4 (profiles/r6_tail_schedule_ab.txt): the chain stays
         self._step_streams = None
 
     def zero_grad(self, set_to_none: bool = True):
@@ -488,9 +488,10 @@ class FusedSGD(torch.optim.Optimizer):
         if self._update_stream_used:
             torch.cuda.current_stream(self._update_stream.device).wait_stream(self._update_stream)
             self._update_stream_used = False
-        # Round 6: the launches of the step are independent of each other (one parameter each, or one list of small ones): on a device they
-        # are dealt round-robin onto `step_branches` streams forked from and joined to the caller's — parallel branches of a captured
-        # graph — instead of a chain of ~12 launches of 5-20 us at the very end of the iteration with nothing beside it
+        # Round 6: the launches of the step are independent of each other (one parameter each, or one list of small ones): with
+        # `step_branches` > 1 they are dealt round-robin onto that many streams forked from and joined to the caller's — parallel branches
+        # of a captured graph — instead of a chain of ~12 launches of 5-20 us at the end of the iteration.  In the stamps the tail shrinks
+        # (120 -> 85 us), in the step it does not (10.069 / 10.062 / 10.078 ms at 1 / 2 / 4 branches, four interleaved runs each): default 1
         jobs = []
         for group in self.param_groups:
             lr, mom, wd = float(group["lr"]), float(group["momentum"]), float(group["weight_decay"])
