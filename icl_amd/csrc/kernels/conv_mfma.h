@@ -138,8 +138,11 @@ __global__ __launch_bounds__(256) void reduce_unpack_wgrad_kernel(const float* _
   for (long base = (long)blockIdx.x * 64; base < pe; base += (long)gridDim.x * 64) {
     const long idx = base + lane;
     float acc = 0.f;
-    if (idx < pe)
+    if (idx < pe) {
+      // (eight loads in flight per lane, added in slab order: the sum is the chain's, the latency is not)
+#pragma unroll 8
       for (int s = wid; s < nslabs; s += 4) acc += gwp[s * pe + idx];
+    }
     __syncthreads();
     part[wid][lane] = acc;
     __syncthreads();
@@ -228,8 +231,11 @@ __global__ __launch_bounds__(256) void reduce_unpack_wgrad_multi_kernel(ReduceMu
   for (long base = (long)blockIdx.x * 64; base < pe; base += (long)gridDim.x * 64) {
     const long idx = base + lane;
     float acc = 0.f;
-    if (idx < pe)
+    if (idx < pe) {
+      // (eight loads in flight per lane, added in slab order: the sum is the chain's, the latency is not)
+#pragma unroll 8
       for (int s = wid; s < nslabs; s += 4) acc += gwp[s * pe + idx];
+    }
     __syncthreads();
     part4[wid][lane] = acc;
     __syncthreads();
