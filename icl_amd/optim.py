@@ -16,7 +16,6 @@ import torch
 from . import _lib
 
 _BIG = 1 << 20
-SGD_MULTI_PORTION = 48      # tensors per launch of icl_sgd_step_multi (csrc/kernels/optim.h kSgdMulti)
 SPLIT_MIN_ROWS = 192    # factor rows from which d = g^T x runs on split products (tools/sgd_probe.py, 13,824^2: 128 rows 769 -> 720 us
                         # but +2 small launches: a wash inside the step; 256 rows 1244 -> 1029 us, 512 rows 2158 -> 1770 us)
 
@@ -139,8 +138,6 @@ class FusedSGD(torch.optim.Optimizer):
         self._deferred = []          # (parameter, g, x, event after the input-gradient kernel)
         self._update_stream = None
         self._update_stream_used = False
-        self.step_branches = max(int(os.environ.get("ICL_OPT_BRANCHES", "1")), 1)      # measured equal at 1 / 2 / 4 (profiles/r6_tail_schedule_ab.txt): the chain stays
-        self._step_streams = None
 
     def zero_grad(self, set_to_none: bool = True):
         for group in self.param_groups:
@@ -488,11 +485,6 @@ class FusedSGD(torch.optim.Optimizer):
         if self._update_stream_used:
             torch.cuda.current_stream(self._update_stream.device).wait_stream(self._update_stream)
             self._update_stream_used = False
-        # Round 6: the launches of the step are independent of each other (one parameter each, or one list of small ones): with
-        # `step_branches` > 1 they are dealt round-robin onto that many streams forked from and joined to the caller's — parallel branches
-        # of a captured graph — instead of a chain of ~12 launches of 5-20 us at the end of the iteration.  In the stamps the tail shrinks
-        # (120 -> 85 us), in the step it does not (10.069 / 10.062 / 10.078 ms at 1 / 2 / 4 branches, four interleaved runs each): default 1
-        jobs = []
         for group in self.param_groups:
             lr, mom, wd = float(group["lr"]), float(group["momentum"]), float(group["weight_decay"])
             small = {0: [], 1: []}
@@ -512,7 +504,7 @@ class FusedSGD(torch.optim.Optimizer):
                     p.grad = g
                     p._icl_factors = fac = None
                 if fac:
-                    jobs.append((p, lambda p=p, fac=fac, lr=lr, mom=mom, wd=wd: self._step_factored(L, p, fac, lr, mom, wd)))
+                    self._step_factored(L, p, fac, lr, mom, wd)
                     p._icl_factors = None
                     continue
                 if g is None:
@@ -528,55 +520,27 @@ class FusedSGD(torch.optim.Optimizer):
                     first = 1
                 m = st["momentum_buffer"]
                 if p.numel() >= _BIG:
-                    def one(p=p, g=g, m=m, lr=lr, mom=mom, wd=wd, first=first):
-                        stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream) if p.is_cuda else None
-                        lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
-                        _lib.check(L.icl_sgd_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), p.numel(), lr, mom, wd, first, lrp, stream),
-                                   "sgd_step")
-                    jobs.append((p, one))
+                    stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream) if p.is_cuda else None
+                    lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
+                    _lib.check(L.icl_sgd_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), p.numel(), lr, mom, wd, first, lrp, stream),
+                               "sgd_step")
                 else:
                     small[first].append((p, g, m))
             for first, items in small.items():
-                # (icl_sgd_step_multi takes any count and launches once per kSgdMulti tensors: handed over in such portions, one job each)
-                for i0 in range(0, len(items), SGD_MULTI_PORTION):
-                    part = items[i0:i0 + SGD_MULTI_PORTION]
-
-                    def many(part=part, lr=lr, mom=mom, wd=wd, first=first):
-                        n = len(part)
-                        arr = ctypes.c_void_p * n
-                        P_ = arr(*[it[0].data_ptr() for it in part])
-                        G_ = arr(*[it[1].data_ptr() for it in part])
-                        M_ = arr(*[it[2].data_ptr() for it in part])
-                        N_ = (ctypes.c_int64 * n)(*[it[0].numel() for it in part])
-                        p0 = part[0][0]
-                        stream = ctypes.c_void_p(torch.cuda.current_stream(p0.device).cuda_stream) if p0.is_cuda else None
-                        lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
-                        _lib.check(L.icl_sgd_step_multi(P_, G_, M_, N_, n, lr, mom, wd, first, lrp, stream), "sgd_step_multi")
-                    jobs.append((part[0][0], many))
-        self._run_jobs(jobs)
+                if not items:
+                    continue
+                n = len(items)
+                arr = ctypes.c_void_p * n
+                P_ = arr(*[it[0].data_ptr() for it in items])
+                G_ = arr(*[it[1].data_ptr() for it in items])
+                M_ = arr(*[it[2].data_ptr() for it in items])
+                N_ = (ctypes.c_int64 * n)(*[it[0].numel() for it in items])
+                p0 = items[0][0]
+                stream = ctypes.c_void_p(torch.cuda.current_stream(p0.device).cuda_stream) if p0.is_cuda else None
+                lrp = self.lr_dev.data_ptr() if self.lr_dev is not None else None
+                _lib.check(L.icl_sgd_step_multi(P_, G_, M_, N_, n, lr, mom, wd, first, lrp, stream), "sgd_step_multi")
         self._updated_in_backward.clear()
         return loss
-
-    def _run_jobs(self, jobs):
-        if not jobs:
-            return
-        dev = jobs[0][0].device
-        nb = min(self.step_branches, len(jobs)) if dev.type == "cuda" and all(p.device == dev for p, _ in jobs) else 1
-        if nb <= 1:
-            for _, job in jobs:
-                job()
-            return
-        here = torch.cuda.current_stream(dev)
-        if self._step_streams is None or len(self._step_streams) < nb - 1 or self._step_streams[0].device != dev:
-            self._step_streams = [torch.cuda.Stream(device=dev) for _ in range(nb - 1)]
-        lanes = [here] + self._step_streams[:nb - 1]
-        for s in lanes[1:]:
-            s.wait_stream(here)
-        for i, (_, job) in enumerate(jobs):
-            with torch.cuda.stream(lanes[i % nb]):
-                job()
-        for s in lanes[1:]:
-            here.wait_stream(s)      # joined before step() returns: whatever the caller frees or reads next is ordered behind every branch
 
 
 # ------------------------------------------------------------------------------------------------ graphed forward / backward of the unchanged loop
