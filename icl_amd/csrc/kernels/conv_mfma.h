@@ -104,6 +104,10 @@ struct PackMulti {
   int cout[kPackMulti], cin[kPackMulti], taps[kPackMulti];
 };
 
+// Round 6 (second half): through LDS tiles of 16 couts x 16 cins x T taps.  The element-per-thread form above gathers its reads with a
+// stride of Cin * T floats — 418 us for SwinUNETR's weights (16 M packed elements for 768 -> 384 alone), 55-68 us for the U-Net's, one
+// launch at the head of every step with nothing beside it.  Here a tile's rows are read as contiguous runs of 16 T floats and both
+// layouts are written in 64-byte segments (16 consecutive couts of wp0, 16 consecutive cins of wp1).  Same values, zero padding included.
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackMulti m) {
   const int i = blockIdx.y;
   const int Cout = m.cout[i], Cin = m.cin[i], T = m.taps[i];
@@ -111,19 +115,27 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackMulti m) {
   const float* __restrict__ w = m.w[i];
   float* __restrict__ wp0 = m.wp0[i];
   float* __restrict__ wp1 = m.wp1[i];
-  const long t0 = (long)T * KP0 * NP0, t1 = (long)T * KP1 * NP1;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < t0 + t1; e += (long)gridDim.x * blockDim.x) {
-    const bool dg = e >= t0;
-    const long f = dg ? e - t0 : e;
-    const int NP = dg ? NP1 : NP0, KP = dg ? KP1 : KP0;
-    const int n = (int)(f % NP);
-    const long t = f / NP;
-    const int k = (int)(t % KP);
-    const int tap = (int)(t / KP);
-    const int K = dg ? Cout : Cin, N = dg ? Cin : Cout;
-    float v = 0.f;
-    if (k < K && n < N) v = dg ? w[((long)k * Cin + n) * T + (T - 1 - tap)] : w[((long)n * Cin + k) * T + tap];
-    (dg ? wp1 : wp0)[f] = v;
+  constexpr int RS = 16 * 27 + 1;                      // row stride of the tile in LDS (odd: the transposed reads below are conflict-free)
+  __shared__ float tile[16 * RS];
+  const int ntn = NP0 / 16, ntk = NP1 / 16, run = 16 * T;
+  const int tid = threadIdx.x, lo = tid & 15, hi = tid >> 4;
+  for (int t = blockIdx.x; t < ntn * ntk; t += gridDim.x) {
+    const int n0 = (t / ntk) * 16, k0 = (t % ntk) * 16;
+    const int kv = Cin - k0 < 16 ? Cin - k0 : 16;      // cins of this tile that exist
+    __syncthreads();                                    // the previous tile has been written out
+    for (int q = tid; q < 16 * run; q += 256) {
+      const int n = q / run, r = q % run;               // r = k * T + tap inside the row's run
+      float v = 0.f;
+      if (n0 + n < Cout && r < kv * T) v = w[((long)(n0 + n) * Cin + k0) * T + r];
+      tile[n * RS + r] = v;
+    }
+    __syncthreads();
+    // wp0[tap][k][n]: lanes lo = n (64 bytes), hi = k
+    if (k0 + hi < KP0)
+      for (int tap = 0; tap < T; ++tap) wp0[((long)tap * KP0 + k0 + hi) * NP0 + n0 + lo] = tile[lo * RS + hi * T + tap];
+    // wp1[T - 1 - tap][k' = cout][n' = cin]: lanes lo = cin (64 bytes), hi = cout
+    if (n0 + hi < KP1)
+      for (int tap = 0; tap < T; ++tap) wp1[((long)(T - 1 - tap) * KP1 + n0 + hi) * NP1 + k0 + lo] = tile[hi * RS + lo * T + tap];
   }
 }
 

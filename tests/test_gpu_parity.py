@@ -103,6 +103,26 @@ def test_maxpool_ties(dev):
     assert torch.equal(xg.grad.cpu(), xr.grad)
 
 
+def test_pack_weights_multi_equals_the_single_packs(dev):
+    """icl_conv3d_pack_weights_multi (one launch per step for every convolution weight; LDS tiles of 16 couts x 16 cins x taps since round 6)
+    against icl_conv3d_pack_weights per weight and layout, bit for bit, zero padding included: the U-Net's and SwinUNETR's shapes plus
+    ragged ones.  Reference: the nn.Conv3d weights of the backbones (/root/reference/code/networks/utils.py:104)."""
+    import ctypes
+    from icl_amd import _lib, ops
+    L = _lib.lib()
+    shapes = [(16, 1, 3), (16, 16, 3), (16, 48, 3), (128, 384, 3), (256, 256, 3), (384, 768, 3), (48, 96, 1), (20, 7, 3), (3, 20, 1), (2, 16, 1)]
+    ws = [_rand((co, ci, k, k, k), 70 + i).to(dev) for i, (co, ci, k) in enumerate(shapes)]
+    fwd = [torch.full((L.icl_conv3d_packed_elems(co, ci, k, 0),), float("nan"), device=dev) for co, ci, k in shapes]
+    dgr = [torch.full((L.icl_conv3d_packed_elems(co, ci, k, 1),), float("nan"), device=dev) for co, ci, k in shapes]
+    n = len(shapes)
+    arr, iarr = ctypes.c_void_p * n, ctypes.c_int32 * n
+    _lib.check(L.icl_conv3d_pack_weights_multi(arr(*[w.data_ptr() for w in ws]), arr(*[t.data_ptr() for t in fwd]), arr(*[t.data_ptr() for t in dgr]),
+                                               iarr(*[s[0] for s in shapes]), iarr(*[s[1] for s in shapes]), iarr(*[s[2] for s in shapes]), n,
+                                               ops._stream(ws[0])), "pack_weights_multi")
+    for w, f, d in zip(ws, fwd, dgr):
+        assert torch.equal(f, ops.pack_weights(w, 0)) and torch.equal(d, ops.pack_weights(w, 1)), tuple(w.shape)
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 48, 48, 48), (2, 64, 12, 12, 12), (1, 8, 4, 6, 6)])
 def test_skip_and_pool_backward_adds_both_gradients_in_one_pass(dev, shape):
     """ops.skip_and_pool: an encoder output feeds the level's skip connection and the next level's pooling

@@ -277,6 +277,25 @@ def test_skip_and_pool_adds_the_two_gradients_in_one_pass(monkeypatch, w, x2):
     assert torch.equal(x2.grad, torch.autograd.grad(F.max_pool3d(x2, 2).sum(), x2)[0])
 
 
+def test_pack_weights_multi_equals_the_single_packs():
+    """icl_conv3d_pack_weights_multi (LDS tiles of 16 couts x 16 cins x taps, both layouts in one launch, round 6) writes exactly what
+    icl_conv3d_pack_weights writes per weight and layout — zero padding included — for ragged channel counts and both kernel sizes.
+    Reference: the nn.Conv3d weights of the backbones ([Cout][Cin][k][k][k], networks/utils.py:104)."""
+    import ctypes
+    L = _lib.lib()
+    shapes = [(16, 1, 3), (20, 7, 3), (48, 33, 3), (3, 20, 1), (32, 64, 3), (17, 16, 1)]
+    ws = [_rand((co, ci, k, k, k), 70 + i) for i, (co, ci, k) in enumerate(shapes)]
+    fwd = [torch.full((L.icl_conv3d_packed_elems(co, ci, k, 0),), float("nan")) for co, ci, k in shapes]
+    dgr = [torch.full((L.icl_conv3d_packed_elems(co, ci, k, 1),), float("nan")) for co, ci, k in shapes]
+    n = len(shapes)
+    arr, iarr = ctypes.c_void_p * n, ctypes.c_int32 * n
+    _lib.check(L.icl_conv3d_pack_weights_multi(arr(*[w.data_ptr() for w in ws]), arr(*[t.data_ptr() for t in fwd]), arr(*[t.data_ptr() for t in dgr]),
+                                               iarr(*[s[0] for s in shapes]), iarr(*[s[1] for s in shapes]), iarr(*[s[2] for s in shapes]), n, None),
+               "pack_weights_multi")
+    for w, f, d in zip(ws, fwd, dgr):
+        assert torch.equal(f, ops.pack_weights(w, 0)) and torch.equal(d, ops.pack_weights(w, 1)), tuple(w.shape)
+
+
 def test_conv3d_forced_big_tile(monkeypatch):
     monkeypatch.setenv("ICL_CONV_FORCE_TILE", "48")
     _conv_check(1, 16, 16, 6, 8, 16, 3)
