@@ -54,9 +54,13 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     for (int u = 0; u < kLwUnroll; ++u)
 #pragma unroll
       for (int a = 0; a < kLwT; ++a) {
+        if (o0 + a * 16 >= O) continue;                    // (wave-uniform: tiles wholly outside [O] x [I] issue nothing, round 6)
         bsum[a] += av[u][a];
 #pragma unroll
-        for (int b = 0; b < kLwT; ++b) acc[a][b] = icl_mfma_16x16x4(av[u][a], bv[u][b], acc[a][b]);
+        for (int b = 0; b < kLwT; ++b) {
+          if (i0 + b * 16 >= I) continue;
+          acc[a][b] = icl_mfma_16x16x4(av[u][a], bv[u][b], acc[a][b]);
+        }
       }
   }
   float* slab = slabs + (long)split * ((long)O * I + O);
@@ -115,32 +119,49 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restr
     ov[a] = o0 + a * 16 + lr < O;
     iv[a] = i0 + a * 16 + lr < I;
   }
-  for (long q = q0; q < q1; ++q) {
-    const long b = q / gpsr, v = (q - b * gpsr) * 16 + lg * 4;
-    const bool rv = v < S;                                  // S % 4 == 0: a float4 is either fully inside or fully outside
-    float4 av[kLwT], bv[kLwT];
+  // Round 6: tiles of the 48 x 48 block that lie wholly outside [O] x [I] are skipped (wave-uniform tests) — the `final` convolution
+  // (O = 2, I = 16) issued nine tiles' MFMAs for one, 135 us for a 127 MB stream — and two voxel groups are loaded per iteration (their
+  // products stay in group order: the sums are the old ones)
+  bool ot[kLwT], it[kLwT];
 #pragma unroll
-    for (int a = 0; a < kLwT; ++a) {
-      av[a] = make_float4(0.f, 0.f, 0.f, 0.f);
-      bv[a] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rv && ov[a]) av[a] = *reinterpret_cast<const float4*>(g + b * g_bstride + (long)(o0 + a * 16 + lr) * S + v);
-      if (rv && iv[a]) {
-        bv[a] = *reinterpret_cast<const float4*>(x + b * x_bstride + (long)(i0 + a * 16 + lr) * S + v);
-        if (dr.ss) bv[a] = norm_relu4(bv[a], dr.ss[2 * (b * I + (i0 + a * 16 + lr))], dr.ss[2 * (b * I + (i0 + a * 16 + lr)) + 1]);
-        if (dr.mode == 1) bv[a] = drop_apply4(bv[a], dseed, dr.thresh, dr.scale, (b * I + (i0 + a * 16 + lr)) * S + v);
+  for (int a = 0; a < kLwT; ++a) {
+    ot[a] = o0 + a * 16 < O;
+    it[a] = i0 + a * 16 < I;
+  }
+  for (long q = q0; q < q1; q += 2) {
+    float4 av[2][kLwT], bv[2][kLwT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long qq = q + u;
+      const long b = qq / gpsr, v = (qq - b * gpsr) * 16 + lg * 4;
+      const bool rv = qq < q1 && v < S;                     // S % 4 == 0: a float4 is either fully inside or fully outside
+#pragma unroll
+      for (int a = 0; a < kLwT; ++a) {
+        av[u][a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[u][a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rv && ov[a]) av[u][a] = *reinterpret_cast<const float4*>(g + b * g_bstride + (long)(o0 + a * 16 + lr) * S + v);
+        if (rv && iv[a]) {
+          bv[u][a] = *reinterpret_cast<const float4*>(x + b * x_bstride + (long)(i0 + a * 16 + lr) * S + v);
+          if (dr.ss) bv[u][a] = norm_relu4(bv[u][a], dr.ss[2 * (b * I + (i0 + a * 16 + lr))], dr.ss[2 * (b * I + (i0 + a * 16 + lr)) + 1]);
+          if (dr.mode == 1) bv[u][a] = drop_apply4(bv[u][a], dseed, dr.thresh, dr.scale, (b * I + (i0 + a * 16 + lr)) * S + v);
+        }
       }
     }
 #pragma unroll
-    for (int a = 0; a < kLwT; ++a) {
-      bsum[a] += (av[a].x + av[a].y) + (av[a].z + av[a].w);
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int c = 0; c < kLwT; ++c) {
-        acc[a][c] = icl_mfma_16x16x4(av[a].x, bv[c].x, acc[a][c]);
-        acc[a][c] = icl_mfma_16x16x4(av[a].y, bv[c].y, acc[a][c]);
-        acc[a][c] = icl_mfma_16x16x4(av[a].z, bv[c].z, acc[a][c]);
-        acc[a][c] = icl_mfma_16x16x4(av[a].w, bv[c].w, acc[a][c]);
+      for (int a = 0; a < kLwT; ++a) {
+        if (!ot[a]) continue;
+        bsum[a] += (av[u][a].x + av[u][a].y) + (av[u][a].z + av[u][a].w);
+#pragma unroll
+        for (int c = 0; c < kLwT; ++c) {
+          if (!it[c]) continue;
+          acc[a][c] = icl_mfma_16x16x4(av[u][a].x, bv[u][c].x, acc[a][c]);
+          acc[a][c] = icl_mfma_16x16x4(av[u][a].y, bv[u][c].y, acc[a][c]);
+          acc[a][c] = icl_mfma_16x16x4(av[u][a].z, bv[u][c].z, acc[a][c]);
+          acc[a][c] = icl_mfma_16x16x4(av[u][a].w, bv[u][c].w, acc[a][c]);
+        }
       }
-    }
   }
   float* slab = slabs + (long)split * ((long)O * I + O);
 #pragma unroll
