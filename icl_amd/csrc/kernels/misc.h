@@ -89,11 +89,23 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restr
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// Block 256 = 16 consecutive elements x 16 chunk lanes: lane l adds chunks l, l + 16, ... (independent loads, eight in flight), the 16
+// partial sums of an element are combined through LDS in lane order — a fixed order, no atomics.  (Until round 6 one thread per element
+// walked all chunks: 53 us for 64 chunks on SwinUNETR's 48^3 maps.)  grid ceil(E / 16).
 __global__ __launch_bounds__(256) void dwconv3_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gw, int E, int chunks) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
+  __shared__ float red[16][17];
+  const int le = threadIdx.x & 15, ls = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + le;
   float v = 0.f;
-  for (int k = 0; k < chunks; ++k) v += slab[(long)k * E + e];
+  if (e < E) {
+#pragma unroll 8
+    for (int k = ls; k < chunks; k += 16) v += slab[(long)k * E + e];
+  }
+  red[ls][le] = v;
+  __syncthreads();
+  if (ls != 0 || e >= E) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) v += red[k][le];
   gw[e] = v;
 }
 
