@@ -44,7 +44,7 @@ class SwinUNETR_icl(SwinUNETRBackbone):  # noqa: N801 — reference class name
                 maps_unlab, _ = self.uscl([ops.split_batch(t, bl)[1] for t in feats], qs_lab, "unlabeled")
             return side, maps_lab, maps_unlab, maps_con
 
-        logits, _, (side, maps_lab, maps_unlab, maps_con) = self.run_backbone(torch.cat([x_lab, x_unlab], 0), heads)
+        logits, _, (side, maps_lab, maps_unlab, maps_con) = self.run_backbone(ops.cat_batch(x_lab, x_unlab), heads)
         side.join(maps_lab + maps_unlab + maps_con)
         logits_lab, logits_unlab = ops.split_batch(logits, bl)
         return logits_lab, logits_unlab, maps_lab, maps_unlab, maps_con

@@ -50,7 +50,7 @@ class unet_3D_icl(UNet3DBackbone):  # noqa: N801 — reference class name
                 maps_unlab, _ = self.uscl([ops.split_batch(f, bl)[1] for f in feats], qs_lab, "unlabeled", need_queries=False)
             return side, maps_lab, maps_unlab, maps_consis
 
-        final, _, (side, feat_maps_lab, feat_maps_unlab, feat_maps_consis) = self.run_backbone(torch.cat([x_lab, x_unlab], 0), heads)
+        final, _, (side, feat_maps_lab, feat_maps_unlab, feat_maps_consis) = self.run_backbone(ops.cat_batch(x_lab, x_unlab), heads)
         side.join(feat_maps_lab + feat_maps_unlab + feat_maps_consis)
         final_lab, final_unlab = ops.split_batch(final, bl)
         return final_lab, final_unlab, feat_maps_lab, feat_maps_unlab, feat_maps_consis

@@ -2151,6 +2151,18 @@ class _SplitBatch(torch.autograd.Function):
         return torch.cat([ga, gb], 0), None
 
 
+def cat_batch(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat([a, b], 0) — without the copies when the two already ARE one batch: contiguous slices `v[:k]`, `v[k:]` of one tensor
+    that need no gradient (the trainers split their batch that way, train_inherent_consistent_unet_3D_BraTS.py:103-104, and the ICL models
+    run both streams as one batch): a view over both instead of two device copies at the head of every step."""
+    if (a.dim() == b.dim() and a.shape[1:] == b.shape[1:] and a.dtype == b.dtype and a.device == b.device and a.is_contiguous()
+            and b.is_contiguous() and not a.requires_grad and not b.requires_grad and a.numel() > 0 and b.numel() > 0
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size()):
+        return a.as_strided((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride())
+    return torch.cat([a, b], 0)
+
+
 def split_batch(x: torch.Tensor, k: int):
     """x[:k], x[k:] (views) with a single-kernel gradient."""
     return _SplitBatch.apply(x, k)
