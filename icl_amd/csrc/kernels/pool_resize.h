@@ -40,6 +40,45 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
   }
 }
 
+// The same for TWO x-neighbouring outputs per thread (round 6; Wo even, rows 16-byte aligned): one 16-byte load per window row instead
+// of four 4-byte ones (conv1's 96^3 output, batch 2: a 113 MB read at the head of every forward pass, 40 us with the scalar form).
+// Same scan order per window, same maxima and indices.
+__global__ __launch_bounds__(256) void maxpool2_fwd_x2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              unsigned char* __restrict__ idx, long NC, int Do, int Ho, int Wo, int pd,
+                                                              const float* __restrict__ ss) {
+  const int Wo2 = Wo >> 1;
+  const long total = NC * Do * Ho * Wo2;
+  const int H = Ho * 2, W = Wo * 2;
+  const int nk = 4 * pd;
+  for (long o2 = (long)blockIdx.x * blockDim.x + threadIdx.x; o2 < total; o2 += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(o2 % Wo2) * 2;
+    long t = o2 / Wo2;
+    const int oy = (int)(t % Ho);
+    t /= Ho;
+    const int oz = (int)(t % Do);
+    const long nc = t / Do;
+    const long o = ((nc * Do + oz) * Ho + oy) * (long)Wo + ox;
+    const float* p = x + ((nc * (Do * pd) + oz * pd) * H + oy * 2) * (long)W + ox * 2;
+    const float sc = ss ? ss[2 * nc] : 1.f, sh = ss ? ss[2 * nc + 1] : 0.f;
+    float b0 = 0.f, b1 = 0.f;
+    int i0 = 0, i1 = 0;
+    for (int k = 0; k < nk; k += 2) {
+      float4 v = *reinterpret_cast<const float4*>(p + ((k >> 2) * H + ((k >> 1) & 1)) * (long)W);
+      if (ss) { v.x = norm_relu1(v.x, sc, sh); v.y = norm_relu1(v.y, sc, sh); v.z = norm_relu1(v.z, sc, sh); v.w = norm_relu1(v.w, sc, sh); }
+      if (k == 0) { b0 = v.x; b1 = v.z; }
+      else {
+        if (v.x > b0) { b0 = v.x; i0 = k; }
+        if (v.z > b1) { b1 = v.z; i1 = k; }
+      }
+      if (v.y > b0) { b0 = v.y; i0 = k + 1; }
+      if (v.w > b1) { b1 = v.w; i1 = k + 1; }
+    }
+    *reinterpret_cast<float2*>(y + o) = make_float2(b0, b1);
+    idx[o] = (unsigned char)i0;
+    idx[o + 1] = (unsigned char)i1;
+  }
+}
+
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ idx,
                                                            float* __restrict__ gx, long NC, int Do, int Ho, int Wo, int pd) {
   const long total = NC * Do * Ho * Wo;
